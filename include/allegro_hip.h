@@ -1,0 +1,150 @@
+/* allegro_hip.h -- C-ABI of liballegro_hip.so: the MI355X-native `pair_style allegro` hot path.
+ *
+ * Drop-in boundary.  The reference pair style (mir-group/pair_allegro,
+ * pair_nequip_allegro.{h,cpp}) does, per MPI rank:
+ *
+ *     coeff()      : torch::jit::load(model) + metadata            pair_nequip_allegro.cpp:174-330
+ *     compute()    : preprocess() -> call() -> scatter             pair_nequip_allegro.cpp:333-407
+ *
+ * with preprocess()/call() living in libtorch.  This library replaces everything below
+ * `Pair::coeff` / `Pair::compute`: the model file reader, the cutoff filter of the LAMMPS
+ * (skin-inflated) full neighbor list, the Allegro model itself (hand-written HIP kernels,
+ * analytic backward) and the force / energy / virial read-out.  A LAMMPS `Pair` subclass only
+ * marshals pointers into these entry points (pair_allegro_amd/lammps/pair_allegro_hip.cpp;
+ * binding recipe in INTEGRATION.md).
+ *
+ * Conventions: every function returns 0 on success, non-zero on failure; the message is then
+ * available from ahip_last_error() (thread-local).  Nothing here throws, exits or prints
+ * (except the explicit debug dump).  Plain pointers and sizes only, no torch / LAMMPS types.
+ * Pointers are HOST pointers unless the function name ends in `_dev`.
+ * There is NO CPU fallback: every entry point that computes needs a gfx950 device.
+ */
+#ifndef ALLEGRO_HIP_H
+#define ALLEGRO_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ahip_model ahip_model;
+
+#define AHIP_OK 0
+#define AHIP_ERR_ARG 1      /* bad argument / deck error  (-> LAMMPS error->all)            */
+#define AHIP_ERR_FILE 2     /* model file problems (reference throws std::runtime_error, :205) */
+#define AHIP_ERR_DEVICE 3   /* HIP runtime failure / no GPU                                  */
+#define AHIP_ERR_STATE 4    /* call order (compute before neigh_update, ...)                */
+#define AHIP_ERR_UNSUPPORTED 5
+
+/* Message of the last failure on this thread ("" if none). */
+const char *ahip_last_error(void);
+
+/* Number of visible HIP devices; replaces torch::cuda::is_available()/device_count()
+ * (pair_nequip_allegro.cpp:92,102).  The caller maps node-local rank -> device index exactly
+ * like pair_nequip_allegro.cpp:93-120 (modulo wrap-around only in debug mode). */
+int ahip_device_count(int *count);
+
+/* Load `*.nequip.pth` (TorchScript archive carrying the `allegro_hip.bin` section) or a bare
+ * `*.ahip` blob and upload the weights to `device`.  Replaces torch::jit::load + freeze
+ * (pair_nequip_allegro.cpp:214-232).  Any other extension -> AHIP_ERR_FILE, like :197-206. */
+int ahip_model_load(const char *path, int device, ahip_model **out);
+void ahip_model_free(ahip_model *m);
+
+/* Model metadata = the five keys the reference reads from the archive
+ * (pair_nequip_allegro.cpp:214-220; consumed :267-328).  Any out-pointer may be NULL.
+ *   type_names: whitespace-separated, model-type order (:275-294)
+ *   per_edge_type_cutoff: row-major [num_types][num_types] in MODEL type index, or NULL when the
+ *                         model has a single r_max (:303-328)
+ * Returned pointers live as long as the model. */
+int ahip_model_meta(const ahip_model *m, double *r_max, int *num_types, const char **type_names,
+                    const double **per_edge_type_cutoff, int *l_max, int *num_tensor_features,
+                    int *num_scalar_features, int *num_layers, const char **model_dtype);
+
+/* Options (string key/value):
+ *   "path"      = "auto" | "fused" | "generic"   kernel family (auto: fused when the model shape
+ *                                                 and the per-atom edge counts allow it)
+ *   "precision" = "model" | "float64"            compute dtype; float64 is the debug/parity build
+ *   "chunk_edges" = "<n>"                        max edges processed per pass (workspace bound)
+ */
+int ahip_set_option(ahip_model *m, const char *key, const char *value);
+
+/* Hand over the LAMMPS full neighbor list -- only on steps where LAMMPS rebuilt it.
+ * Replaces the list walk of preprocess() (pair_nequip_allegro.cpp:469-480,489-496).
+ *   inum      : number of centre atoms (== nlocal, asserted at :470)
+ *   nall      : nlocal + nghost (size of x / f / type)
+ *   ilist     : [inum] centre atom indices
+ *   numneigh  : indexed by ATOM index i (LAMMPS convention), numneigh[i]
+ *   firstneigh: indexed by atom index i, firstneigh[i][0..numneigh[i])
+ *   neighmask : LAMMPS NEIGHMASK; every j is stored as (j & neighmask) (:496)
+ */
+int ahip_neigh_update(ahip_model *m, int inum, int nall, const int *ilist, const int *numneigh,
+                      const int *const *firstneigh, int neighmask);
+
+/* Same, from a flat CSR list: neighbours of centre ii are neigh[offsets[ii] .. offsets[ii+1]). */
+int ahip_neigh_update_csr(ahip_model *m, int inum, int nall, const int *ilist,
+                          const long long *offsets, const int *neigh, int neighmask);
+/* Same, CSR arrays already on the device (int32 offsets [inum+1]); no copy is made of `neigh`
+ * -- the caller keeps it alive until the next update. */
+int ahip_neigh_update_dev(ahip_model *m, int inum, int nall, const int *ilist_dev,
+                          const int *offsets_dev, const int *neigh_dev, long long nneigh_total);
+
+/* One force evaluation = PairNequIPAllegro<false>::compute (pair_nequip_allegro.cpp:333-407).
+ *   x            [nall][3] f64 positions, locals first then ghosts (atom->x)
+ *   type         [nall] LAMMPS types, 1-based (atom->type)
+ *   ntypes       atom->ntypes
+ *   type_mapper  [ntypes] LAMMPS type-1 -> model type, -1 = unmapped (:274-294)
+ *   cutoff_matrix[ntypes*ntypes] in LAMMPS type index (:303-328); edge kept iff rsq <= cut^2 (:507)
+ *   f            [nall][3]  forces are ADDED (f[i] += ...) for locals AND ghosts (:370-377)
+ *   eatom        [nall] or NULL; eatom[i] = E_i is written for the inum centre atoms (:378)
+ *   eng          out: sum of E_i over centre atoms only (:379)
+ *   virial       out or NULL: xx,yy,zz,xy,xz,yz, no sign change (:387-392)
+ */
+int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const int *type, int ntypes,
+                 const int *type_mapper, const double *cutoff_matrix, double *f, double *eatom,
+                 double *eng, double *virial);
+
+/* Device-resident variant (the pattern of pair_nequip_allegro_kokkos.cpp:109-126,266-268,305-319):
+ * x_dev/f_dev/eatom_dev are device pointers, mtype_dev holds MODEL types (already mapped),
+ * cutoff_matrix_model is a HOST [num_types^2] matrix in model-type index (NULL = r_max).
+ * Forces are accumulated into f_dev; eng_vir_dev receives 7 doubles {eng, xx,yy,zz,xy,xz,yz}.
+ * Asynchronous on `stream` (a hipStream_t, NULL = default) except for one 4-byte read-back of
+ * the edge count (the Kokkos path has the same one, :203-206). */
+int ahip_compute_dev(ahip_model *m, int nlocal, int nghost, const double *x_dev, const int *mtype_dev,
+                     const double *cutoff_matrix_model, double *f_dev, double *eatom_dev,
+                     double *eng_vir_dev, void *stream);
+
+/* Edge list of the last compute: the tensors the reference would have handed to the model
+ * (edge_index i64 [2][E], pair_nequip_allegro.cpp:601-602) plus |r_ij|.  Pass NULL buffers to
+ * query nedges only.  This is what the `_NEQUIP_LOG_LEVEL=DEBUG` dump prints (:562-565,625). */
+int ahip_get_edges(ahip_model *m, long long *nedges, long long *edge_index, double *rij);
+
+/* Print "Allegro edges: i j rij" ... "end Allegro edges" to stdout with 0-based tag-1 ids and
+ * %.10g distances, the exact format of pair_nequip_allegro.cpp:564,625,632.  tag may be NULL
+ * (then atom indices are printed). */
+int ahip_debug_dump_edges(ahip_model *m, const int *tag);
+
+/* Per-stage device timings (ms) of the last compute; names is a static ';'-separated list. */
+int ahip_get_timings(ahip_model *m, const char **names, const double **ms, int *n);
+
+/* Kernel family used by the last compute: "generic_f32" | "generic_f64" | "fused_f32" ("" before). */
+const char *ahip_last_path(ahip_model *m);
+/* Largest number of edges of any centre atom in the last compute. */
+int ahip_last_max_degree(ahip_model *m);
+
+/* ---- mini-MD helpers used by the stand-alone driver / bench (device-resident) ------------- */
+
+/* Build a full neighbor list with cutoff rc_list (= r_max + skin) for nlocal centre atoms among
+ * nall atoms (ghost images already materialised), binned cell list on the GPU.  The result is
+ * owned by the model and installed as its current list (as if ahip_neigh_update_dev was called). */
+int ahip_build_neighbors_dev(ahip_model *m, int nlocal, int nall, const double *x_dev,
+                             const double *lo, const double *hi, double rc_list, void *stream);
+
+/* v += dtf*f/m ; x += dt*v  style velocity-Verlet half steps on device arrays (NVE).
+ *   mode 0: v += 0.5*dt*f*ftm2v/mass[type]; x += dt*v      (initial_integrate)
+ *   mode 1: v += 0.5*dt*f*ftm2v/mass[type]                  (final_integrate)  */
+int ahip_nve_dev(ahip_model *m, int mode, int n, double *x_dev, double *v_dev, const double *f_dev,
+                 const int *mtype_dev, const double *mass_by_mtype, double dt, double ftm2v, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

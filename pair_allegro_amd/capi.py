@@ -1,0 +1,221 @@
+"""ctypes binding of liballegro_hip.so (include/allegro_hip.h).
+
+The library is the product; this file is the thinnest possible Python view of its C-ABI, used by
+the Python host mirror (pair.py), the mini-MD driver (md.py), bench.py and the tests.  It fails
+loudly when the shared library is missing -- there is no Python/CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "liballegro_hip.so")
+
+AHIP_OK, AHIP_ERR_ARG, AHIP_ERR_FILE, AHIP_ERR_DEVICE, AHIP_ERR_STATE, AHIP_ERR_UNSUPPORTED = range(6)
+
+# every symbol declared in include/allegro_hip.h (tests check the .so exports all of them)
+SYMBOLS = [
+    "ahip_last_error", "ahip_device_count", "ahip_model_load", "ahip_model_free", "ahip_model_meta",
+    "ahip_set_option", "ahip_neigh_update", "ahip_neigh_update_csr", "ahip_neigh_update_dev",
+    "ahip_compute", "ahip_compute_dev", "ahip_get_edges", "ahip_debug_dump_edges", "ahip_get_timings",
+    "ahip_last_path", "ahip_last_max_degree", "ahip_build_neighbors_dev", "ahip_nve_dev",
+]
+
+
+class AhipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[ahip {code}] {msg}")
+        self.code = code
+        self.msg = msg
+
+
+def _p(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype)) if a is not None else None
+
+
+class Library:
+    def __init__(self, path: Optional[str] = None):
+        path = path or os.environ.get("ALLEGRO_HIP_LIB") or DEFAULT_LIB
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  allegro-hip has no CPU fallback.")
+        self.path = path
+        self.lib = C.CDLL(path)
+        L = self.lib
+        L.ahip_last_error.restype = C.c_char_p
+        L.ahip_last_path.restype = C.c_char_p
+        L.ahip_last_path.argtypes = [C.c_void_p]
+        L.ahip_last_max_degree.argtypes = [C.c_void_p]
+        L.ahip_device_count.argtypes = [C.POINTER(C.c_int)]
+        L.ahip_model_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.ahip_model_free.argtypes = [C.c_void_p]
+        L.ahip_model_free.restype = None
+        L.ahip_model_meta.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_char_p),
+                                      C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
+        L.ahip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.ahip_neigh_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                        C.POINTER(C.POINTER(C.c_int)), C.c_int]
+        L.ahip_neigh_update_csr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_longlong),
+                                            C.POINTER(C.c_int), C.c_int]
+        L.ahip_neigh_update_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
+        L.ahip_compute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int,
+                                   C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.ahip_compute_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double),
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ahip_get_edges.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
+        L.ahip_debug_dump_edges.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.ahip_get_timings.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int)]
+        L.ahip_build_neighbors_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double),
+                                               C.POINTER(C.c_double), C.c_double, C.c_void_p]
+        L.ahip_nve_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.POINTER(C.c_double), C.c_double, C.c_double, C.c_void_p]
+
+    def check(self, rc: int) -> None:
+        if rc != 0:
+            raise AhipError(rc, self.lib.ahip_last_error().decode(errors="replace"))
+
+    def device_count(self) -> int:
+        n = C.c_int(0)
+        self.check(self.lib.ahip_device_count(C.byref(n)))
+        return n.value
+
+
+_default: Optional[Library] = None
+
+
+def default_library() -> Library:
+    global _default
+    if _default is None:
+        _default = Library()
+    return _default
+
+
+class Model:
+    """Owning handle of an ahip_model."""
+
+    def __init__(self, path: str, device: int = 0, lib: Optional[Library] = None):
+        self.L = lib or default_library()
+        h = C.c_void_p()
+        self.L.check(self.L.lib.ahip_model_load(os.fsencode(path), device, C.byref(h)))
+        self.h = h
+        self._keep = []
+        r = C.c_double(); nt = C.c_int(); tn = C.c_char_p(); pc = C.POINTER(C.c_double)()
+        lm = C.c_int(); U = C.c_int(); S = C.c_int(); nl = C.c_int(); dt = C.c_char_p()
+        self.L.check(self.L.lib.ahip_model_meta(h, C.byref(r), C.byref(nt), C.byref(tn), C.byref(pc), C.byref(lm),
+                                                 C.byref(U), C.byref(S), C.byref(nl), C.byref(dt)))
+        self.r_max = r.value
+        self.num_types = nt.value
+        self.type_names = tn.value.decode().split()
+        self.per_edge_type_cutoff = (np.ctypeslib.as_array(pc, shape=(nt.value, nt.value)).copy() if pc else None)
+        self.l_max, self.num_tensor_features, self.num_scalar_features = lm.value, U.value, S.value
+        self.num_layers, self.model_dtype = nl.value, dt.value.decode()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lib.ahip_model_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key: str, value) -> None:
+        self.L.check(self.L.lib.ahip_set_option(self.h, key.encode(), str(value).encode()))
+
+    # ---- neighbor lists ----------------------------------------------------------------------
+    def neigh_update_csr(self, nall: int, ilist: np.ndarray, offsets: np.ndarray, neigh: np.ndarray,
+                         neighmask: int = 0x1FFFFFFF) -> None:
+        ilist = np.ascontiguousarray(ilist, dtype=np.int32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        neigh = np.ascontiguousarray(neigh, dtype=np.int32)
+        self.L.check(self.L.lib.ahip_neigh_update_csr(self.h, len(ilist), nall, _p(ilist, C.c_int),
+                                                       _p(offsets, C.c_longlong), _p(neigh, C.c_int), neighmask))
+
+    def neigh_update_paged(self, nall: int, ilist: np.ndarray, numneigh: np.ndarray, rows: Sequence[np.ndarray],
+                           neighmask: int = 0x1FFFFFFF) -> None:
+        """LAMMPS-shaped call: numneigh[i] and firstneigh[i] indexed by atom index."""
+        ilist = np.ascontiguousarray(ilist, dtype=np.int32)
+        numneigh = np.ascontiguousarray(numneigh, dtype=np.int32)
+        rows = [np.ascontiguousarray(r, dtype=np.int32) for r in rows]
+        first = (C.POINTER(C.c_int) * len(rows))(*[_p(r, C.c_int) for r in rows])
+        self.L.check(self.L.lib.ahip_neigh_update(self.h, len(ilist), nall, _p(ilist, C.c_int), _p(numneigh, C.c_int),
+                                                   first, neighmask))
+
+    def neigh_update_dev(self, inum: int, nall: int, ilist_ptr: int, off_ptr: int, neigh_ptr: int, total: int) -> None:
+        self.L.check(self.L.lib.ahip_neigh_update_dev(self.h, inum, nall, ilist_ptr, off_ptr, neigh_ptr, total))
+
+    def build_neighbors_dev(self, nlocal: int, nall: int, x_ptr: int, lo, hi, rc_list: float, stream: int = 0) -> None:
+        lo = np.ascontiguousarray(lo, dtype=np.float64)
+        hi = np.ascontiguousarray(hi, dtype=np.float64)
+        self.L.check(self.L.lib.ahip_build_neighbors_dev(self.h, nlocal, nall, x_ptr, _p(lo, C.c_double),
+                                                          _p(hi, C.c_double), rc_list, stream))
+
+    # ---- compute ------------------------------------------------------------------------------
+    def compute(self, nlocal: int, nghost: int, x: np.ndarray, type_: np.ndarray, type_mapper: np.ndarray,
+                cutoff_matrix: np.ndarray, f: np.ndarray, eatom: Optional[np.ndarray] = None, want_virial: bool = True):
+        """f is accumulated in place; returns (eng, virial[6] or None)."""
+        assert x.dtype == np.float64 and x.flags.c_contiguous and f.dtype == np.float64 and f.flags.c_contiguous
+        type_ = np.ascontiguousarray(type_, dtype=np.int32)
+        type_mapper = np.ascontiguousarray(type_mapper, dtype=np.int32)
+        cutoff_matrix = np.ascontiguousarray(cutoff_matrix, dtype=np.float64)
+        ntypes = len(type_mapper)
+        eng = C.c_double(0)
+        vir = np.zeros(6) if want_virial else None
+        self.L.check(self.L.lib.ahip_compute(self.h, nlocal, nghost, _p(x, C.c_double), _p(type_, C.c_int), ntypes,
+                                              _p(type_mapper, C.c_int), _p(cutoff_matrix, C.c_double),
+                                              _p(f, C.c_double), _p(eatom, C.c_double), C.byref(eng),
+                                              _p(vir, C.c_double)))
+        return eng.value, vir
+
+    def compute_dev(self, nlocal: int, nghost: int, x_ptr: int, mtype_ptr: int, f_ptr: int, eatom_ptr: int,
+                    engvir_ptr: int, cutoff_matrix_model: Optional[np.ndarray] = None, stream: int = 0) -> None:
+        cm = None
+        if cutoff_matrix_model is not None:
+            cm = np.ascontiguousarray(cutoff_matrix_model, dtype=np.float64)
+        self.L.check(self.L.lib.ahip_compute_dev(self.h, nlocal, nghost, x_ptr, mtype_ptr, _p(cm, C.c_double), f_ptr,
+                                                  eatom_ptr or None, engvir_ptr, stream or None))
+
+    def nve_dev(self, mode: int, n: int, x_ptr: int, v_ptr: int, f_ptr: int, mtype_ptr: int, mass_by_mtype,
+                dt: float, ftm2v: float, stream: int = 0) -> None:
+        mass = np.ascontiguousarray(mass_by_mtype, dtype=np.float64)
+        self.L.check(self.L.lib.ahip_nve_dev(self.h, mode, n, x_ptr, v_ptr, f_ptr, mtype_ptr, _p(mass, C.c_double),
+                                              dt, ftm2v, stream or None))
+
+    # ---- introspection -----------------------------------------------------------------------
+    def get_edges(self):
+        n = C.c_longlong(0)
+        self.L.check(self.L.lib.ahip_get_edges(self.h, C.byref(n), None, None))
+        E = n.value
+        ei = np.zeros((2, E), dtype=np.int64)
+        r = np.zeros(E)
+        if E:
+            self.L.check(self.L.lib.ahip_get_edges(self.h, C.byref(n), _p(ei, C.c_longlong), _p(r, C.c_double)))
+        return ei, r
+
+    def debug_dump_edges(self, tag: Optional[np.ndarray] = None) -> None:
+        t = np.ascontiguousarray(tag, dtype=np.int32) if tag is not None else None
+        self.L.check(self.L.lib.ahip_debug_dump_edges(self.h, _p(t, C.c_int)))
+
+    def timings(self) -> dict:
+        names = C.c_char_p(); ms = C.POINTER(C.c_double)(); n = C.c_int(0)
+        self.L.check(self.L.lib.ahip_get_timings(self.h, C.byref(names), C.byref(ms), C.byref(n)))
+        if n.value == 0:
+            return {}
+        return dict(zip(names.value.decode().split(";"), [ms[k] for k in range(n.value)]))
+
+    @property
+    def last_path(self) -> str:
+        return self.L.lib.ahip_last_path(self.h).decode()
+
+    @property
+    def last_max_degree(self) -> int:
+        return int(self.L.lib.ahip_last_max_degree(self.h))

@@ -1,0 +1,492 @@
+// liballegro_hip.so -- C-ABI implementation (include/allegro_hip.h).
+//
+// Host orchestration of one force evaluation = PairNequIPAllegro<false>::compute
+// (/root/reference/pair_nequip_allegro.cpp:333-407): list ingestion, cutoff filter + edge build,
+// model forward/backward (generic or fused kernels), force/energy/virial read-out.
+// No libtorch, no Kokkos, no CPU fallback: every compute entry point needs a HIP device.
+#include "../../include/allegro_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "engine.h"
+#include "generic_engine.h"
+
+using namespace ahip;
+
+struct ahip_model : public ahip::Model {};
+
+static thread_local std::string g_err;
+
+const char *ahip_last_error(void) { return g_err.c_str(); }
+
+template <typename F> static int guarded(F &&fn) {
+  try {
+    g_err.clear();
+    fn();
+    return AHIP_OK;
+  } catch (const ArgError &e) { g_err = e.what(); return AHIP_ERR_ARG; }
+  catch (const StateError &e) { g_err = e.what(); return AHIP_ERR_STATE; }
+  catch (const UnsupportedError &e) { g_err = e.what(); return AHIP_ERR_UNSUPPORTED; }
+  catch (const HipError &e) { g_err = e.what(); return AHIP_ERR_DEVICE; }
+  catch (const std::bad_alloc &) { g_err = "out of host memory"; return AHIP_ERR_DEVICE; }
+  catch (const std::exception &e) { g_err = e.what(); return AHIP_ERR_FILE; }
+}
+
+int ahip_device_count(int *count) {
+  return guarded([&] {
+    if (!count) throw ArgError("ahip_device_count: count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count = n;
+  });
+}
+
+static void require_model(const ahip_model *m) { if (!m) throw ArgError("model handle is NULL"); }
+
+static void validate_shape(const HostModel &h) {
+  if (h.l_max < 0 || h.l_max > 2) throw UnsupportedError("l_max must be 0, 1 or 2 (got " + std::to_string(h.l_max) + ")");
+  if (h.num_layers < 1) throw UnsupportedError("num_layers must be >= 1");
+  if (h.num_bessels < 1 || h.S < 1 || h.U < 1 || h.mlp_width < 1) throw UnsupportedError("bad model dimensions");
+  if (h.mlp_depth < 0 || h.readout_depth < 0) throw UnsupportedError("bad MLP depth");
+  if (h.poly_p < 2) throw UnsupportedError("polynomial_cutoff_p must be >= 2");
+  if (!(h.r_max > 0)) throw UnsupportedError("r_max must be positive");
+  // every tensor must be present with the documented shape
+  const int T = h.num_types, B = h.num_bessels, S = h.S, U = h.U, L = h.l_max, W = h.mlp_width, R = h.readout_width;
+  auto need = [&](const std::string &n, std::vector<int> shape) {
+    const HostTensor &t = h.get(n);
+    if (t.shape != shape) throw std::runtime_error("model file: tensor '" + n + "' has unexpected shape");
+  };
+  auto need_mlp = [&](const std::string &pre, int din, int depth, int width, int dout) {
+    std::vector<int> dims{din};
+    for (int k = 0; k < depth; ++k) dims.push_back(width);
+    dims.push_back(dout);
+    for (size_t k = 0; k + 1 < dims.size(); ++k) need(pre + ".w" + std::to_string(k), {dims[k], dims[k + 1]});
+  };
+  const int npf = L == 0 ? AHIP_CG_L0_NPATHS : (L == 1 ? AHIP_CG_L1_NPATHS : AHIP_CG_L2_NPATHS);
+  const int nps = L == 0 ? AHIP_CG_L0_NPATHS_SCALAR : (L == 1 ? AHIP_CG_L1_NPATHS_SCALAR : AHIP_CG_L2_NPATHS_SCALAR);
+  need_mlp("tb", 2 * T + B, h.mlp_depth, W, S);
+  need("emb.w", {S, U * (L + 1)});
+  for (int k = 1; k <= h.num_layers; ++k) {
+    const std::string lk = "l" + std::to_string(k);
+    need(lk + ".env", {S, U * (L + 1)});
+    need(lk + ".tp", {k == h.num_layers ? nps : npf, U});
+    need_mlp(lk + ".lat", S + U, h.mlp_depth, W, S);
+    need(lk + ".res", {2});
+    if (k < h.num_layers) need(lk + ".mix", {L + 1, U, U});
+  }
+  need_mlp("out", S, h.readout_depth, R, 1);
+  need("scale", {T});
+  need("shift", {T});
+}
+
+int ahip_model_load(const char *path, int device, ahip_model **out) {
+  return guarded([&] {
+    if (!path || !out) throw ArgError("ahip_model_load: NULL argument");
+    *out = nullptr;
+    HostModel hm = load_model_file(path);                  // throws runtime_error -> AHIP_ERR_FILE
+    validate_shape(hm);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+      (void)hipGetLastError();
+      throw HipError("no HIP device visible: allegro-hip has no CPU fallback (hipGetDeviceCount failed or returned 0)");
+    }
+    if (device < 0 || device >= n)
+      throw ArgError("pair_allegro: mismatch between number of ranks and number of available GPUs (device " +
+                     std::to_string(device) + " of " + std::to_string(n) + ")");
+    AHIP_CHECK(hipSetDevice(device));
+    ahip_model *m = new ahip_model();
+    try {
+      m->hm = std::move(hm);
+      m->device = device;
+      m->D = (m->hm.l_max + 1) * (m->hm.l_max + 1);
+      m->Ka = 2 * m->hm.num_types + m->hm.num_bessels;
+      const int T = m->hm.num_types;
+      m->rcut_model_host.assign((size_t)T * T, m->hm.r_max);
+      if (!m->hm.per_edge_type_cutoff.empty()) m->rcut_model_host = m->hm.per_edge_type_cutoff;
+      AHIP_CHECK(hipMalloc((void **)&m->rcut_model_dev, (size_t)T * T * sizeof(double)));
+      AHIP_CHECK(hipMemcpy(m->rcut_model_dev, m->rcut_model_host.data(), (size_t)T * T * sizeof(double), hipMemcpyHostToDevice));
+      const AhipCgEntry *tab = m->hm.l_max == 0 ? ahip_cg_l0 : (m->hm.l_max == 1 ? ahip_cg_l1 : ahip_cg_l2);
+      m->ncg_full = m->hm.l_max == 0 ? AHIP_CG_L0_N : (m->hm.l_max == 1 ? AHIP_CG_L1_N : AHIP_CG_L2_N);
+      m->ncg_scalar = m->hm.l_max == 0 ? AHIP_CG_L0_NSCALAR : (m->hm.l_max == 1 ? AHIP_CG_L1_NSCALAR : AHIP_CG_L2_NSCALAR);
+      AHIP_CHECK(hipMalloc(&m->cg_dev, (size_t)m->ncg_full * sizeof(AhipCgEntry)));
+      AHIP_CHECK(hipMemcpy(m->cg_dev, tab, (size_t)m->ncg_full * sizeof(AhipCgEntry), hipMemcpyHostToDevice));
+    } catch (...) { ahip_model_free(m); throw; }
+    *out = m;
+  });
+}
+
+void ahip_model_free(ahip_model *m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  (void)hipDeviceSynchronize();
+  fused_free(*m);
+  neigh_free(*m);
+  free_weights(m->wf);
+  free_weights(m->wd);
+  if (m->cg_dev) (void)hipFree(m->cg_dev);
+  if (m->rcut_model_dev) (void)hipFree(m->rcut_model_dev);
+  for (DevBuf *b : {&m->b_ilist, &m->b_nloff, &m->b_nlj, &m->b_x, &m->b_ftype, &m->b_mtype, &m->b_f, &m->b_eatom,
+                    &m->b_engvir, &m->b_cutsq, &m->b_cnt, &m->b_eoff, &m->b_eii, &m->b_ej, &m->b_rvec, &m->b_partial,
+                    &m->b_ws, &m->b_misc})
+    b->release();
+  for (auto &t : m->slots) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
+  delete m;
+}
+
+int ahip_model_meta(const ahip_model *m, double *r_max, int *num_types, const char **type_names,
+                    const double **per_edge_type_cutoff, int *l_max, int *num_tensor_features,
+                    int *num_scalar_features, int *num_layers, const char **model_dtype) {
+  return guarded([&] {
+    require_model(m);
+    if (r_max) *r_max = m->hm.r_max;
+    if (num_types) *num_types = m->hm.num_types;
+    if (type_names) *type_names = m->hm.type_names_joined.c_str();
+    if (per_edge_type_cutoff) *per_edge_type_cutoff = m->hm.per_edge_type_cutoff.empty() ? nullptr : m->hm.per_edge_type_cutoff.data();
+    if (l_max) *l_max = m->hm.l_max;
+    if (num_tensor_features) *num_tensor_features = m->hm.U;
+    if (num_scalar_features) *num_scalar_features = m->hm.S;
+    if (num_layers) *num_layers = m->hm.num_layers;
+    if (model_dtype) *model_dtype = m->hm.model_dtype.c_str();
+  });
+}
+
+int ahip_set_option(ahip_model *m, const char *key, const char *value) {
+  return guarded([&] {
+    require_model(m);
+    if (!key || !value) throw ArgError("ahip_set_option: NULL key/value");
+    const std::string k(key), v(value);
+    if (k == "path") {
+      if (v != "auto" && v != "fused" && v != "generic") throw ArgError("option path: expected auto|fused|generic");
+      m->opt_path = v;
+    } else if (k == "precision") {
+      if (v != "model" && v != "float64") throw ArgError("option precision: expected model|float64");
+      m->opt_precision = v;
+    } else if (k == "chunk_edges") {
+      long long n = std::atoll(value);
+      if (n < 1) throw ArgError("option chunk_edges: expected a positive integer");
+      m->chunk_edges = n;
+    } else if (k == "timing") {
+      m->timing = (v == "1" || v == "on" || v == "true");
+    } else throw ArgError("unknown option '" + k + "'");
+  });
+}
+
+// ------------------------------------------------------------------------------------ neighbor list
+static void install_list_host(ahip_model *m, int inum, int nall) {
+  AHIP_CHECK(hipSetDevice(m->device));
+  const size_t nn = m->h_flat_j.size();
+  m->b_ilist.reserve(std::max<size_t>(inum, 1) * sizeof(int));
+  m->b_nloff.reserve(((size_t)inum + 1) * sizeof(int));
+  m->b_nlj.reserve(std::max<size_t>(nn, 1) * sizeof(int));
+  AHIP_CHECK(hipMemcpy(m->b_ilist.p, m->h_ilist.data(), (size_t)inum * sizeof(int), hipMemcpyHostToDevice));
+  AHIP_CHECK(hipMemcpy(m->b_nloff.p, m->h_off32.data(), ((size_t)inum + 1) * sizeof(int), hipMemcpyHostToDevice));
+  AHIP_CHECK(hipMemcpy(m->b_nlj.p, m->h_flat_j.data(), nn * sizeof(int), hipMemcpyHostToDevice));
+  m->d_ilist = m->b_ilist.as<int>();
+  m->d_nloff = m->b_nloff.as<int>();
+  m->d_nlj = m->b_nlj.as<int>();
+  m->inum = inum; m->nall = nall; m->nneigh = (long long)nn; m->have_list = true;
+}
+
+static void check_list_dims(int inum, int nall) {
+  if (inum < 0 || nall < inum) throw ArgError("neighbor list: need 0 <= inum <= nall");
+}
+
+int ahip_neigh_update(ahip_model *m, int inum, int nall, const int *ilist, const int *numneigh,
+                      const int *const *firstneigh, int neighmask) {
+  return guarded([&] {
+    require_model(m);
+    check_list_dims(inum, nall);
+    if (inum > 0 && (!ilist || !numneigh || !firstneigh)) throw ArgError("ahip_neigh_update: NULL list pointer");
+    m->h_ilist.assign(ilist, ilist + inum);
+    m->h_off32.resize((size_t)inum + 1);
+    long long tot = 0;
+    for (int ii = 0; ii < inum; ++ii) {
+      int i = ilist[ii];
+      if (i < 0 || i >= nall) throw ArgError("neighbor list: ilist entry out of range");
+      m->h_off32[ii] = (int)tot;
+      tot += numneigh[i];
+      if (tot > 2147483000LL) throw UnsupportedError("neighbor list too large for 32-bit offsets; use more ranks");
+    }
+    m->h_off32[inum] = (int)tot;
+    m->h_flat_j.resize((size_t)tot);
+    for (int ii = 0; ii < inum; ++ii) {
+      int i = ilist[ii];
+      const int *jl = firstneigh[i];
+      int *dst = m->h_flat_j.data() + m->h_off32[ii];
+      for (int jj = 0; jj < numneigh[i]; ++jj) {
+        int j = jl[jj] & neighmask;                          // pair_nequip_allegro.cpp:496
+        if (j < 0 || j >= nall) throw ArgError("neighbor list: neighbour index out of range");
+        dst[jj] = j;
+      }
+    }
+    install_list_host(m, inum, nall);
+  });
+}
+
+int ahip_neigh_update_csr(ahip_model *m, int inum, int nall, const int *ilist, const long long *offsets,
+                          const int *neigh, int neighmask) {
+  return guarded([&] {
+    require_model(m);
+    check_list_dims(inum, nall);
+    if (inum > 0 && (!ilist || !offsets)) throw ArgError("ahip_neigh_update_csr: NULL list pointer");
+    m->h_ilist.assign(ilist, ilist + inum);
+    m->h_off32.resize((size_t)inum + 1);
+    long long tot = inum > 0 ? offsets[inum] : 0;
+    if (tot > 2147483000LL) throw UnsupportedError("neighbor list too large for 32-bit offsets; use more ranks");
+    if (tot > 0 && !neigh) throw ArgError("ahip_neigh_update_csr: NULL neigh");
+    for (int ii = 0; ii <= inum; ++ii) {
+      long long o = inum > 0 ? offsets[ii] : 0;
+      if (o < 0 || o > tot || (ii > 0 && o < offsets[ii - 1])) throw ArgError("neighbor list: offsets not monotone");
+      m->h_off32[ii] = (int)o;
+    }
+    for (int ii = 0; ii < inum; ++ii)
+      if (ilist[ii] < 0 || ilist[ii] >= nall) throw ArgError("neighbor list: ilist entry out of range");
+    m->h_flat_j.resize((size_t)tot);
+    for (long long p = 0; p < tot; ++p) {
+      int j = neigh[p] & neighmask;
+      if (j < 0 || j >= nall) throw ArgError("neighbor list: neighbour index out of range");
+      m->h_flat_j[(size_t)p] = j;
+    }
+    install_list_host(m, inum, nall);
+  });
+}
+
+int ahip_neigh_update_dev(ahip_model *m, int inum, int nall, const int *ilist_dev, const int *offsets_dev,
+                          const int *neigh_dev, long long nneigh_total) {
+  return guarded([&] {
+    require_model(m);
+    check_list_dims(inum, nall);
+    if (inum > 0 && (!ilist_dev || !offsets_dev)) throw ArgError("ahip_neigh_update_dev: NULL list pointer");
+    m->d_ilist = ilist_dev; m->d_nloff = offsets_dev; m->d_nlj = neigh_dev;
+    m->inum = inum; m->nall = nall; m->nneigh = nneigh_total; m->have_list = true;
+  });
+}
+
+// ------------------------------------------------------------------------------------ compute
+static void collect_timings(ahip_model *m) {
+  m->timing_names.clear();
+  m->timing_ms.clear();
+  if (!m->timing) return;
+  for (auto &t : m->slots) {
+    if (!t.used) continue;
+    float ms = 0;
+    if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+      if (!m->timing_names.empty()) m->timing_names += ";";
+      m->timing_names += t.name;
+      m->timing_ms.push_back(ms);
+    }
+    t.used = false;
+  }
+}
+
+static void run_model(ahip_model *m, const ComputeArgs &a) {
+  AHIP_CHECK(hipMemsetAsync(a.engvir, 0, 7 * sizeof(double), a.stream));
+  m->nedges = 0;
+  if (m->inum == 0) return;                                   // empty sub-domain (pair_nequip_allegro.cpp:340-341)
+  const bool f64 = (m->opt_precision == "float64") || (m->hm.model_dtype == "float64");
+  if (f64) {
+    if (m->opt_path == "fused") throw UnsupportedError("the fused MFMA path computes in float32; use path=generic for float64");
+    build_edges<double>(*m, a);
+    generic_run<double>(*m, a);
+    m->last_path = "generic_f64";
+    return;
+  }
+  build_edges<float>(*m, a);
+  std::string why;
+  bool fused_ok = false;
+  if (m->opt_path != "generic") {
+    fused_ok = fused_model_supported(*m, &why) && fused_run(*m, a, &why);
+    if (!fused_ok && m->opt_path == "fused") throw UnsupportedError("fused path unavailable: " + why);
+  }
+  if (fused_ok) { m->last_path = "fused_f32"; return; }
+  generic_run<float>(*m, a);
+  m->last_path = "generic_f32";
+}
+
+int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const int *type, int ntypes,
+                 const int *type_mapper, const double *cutoff_matrix, double *f, double *eatom, double *eng,
+                 double *virial) {
+  return guarded([&] {
+    require_model(m);
+    if (!m->have_list) throw StateError("ahip_compute called before ahip_neigh_update");
+    if (nlocal < 0 || nghost < 0) throw ArgError("ahip_compute: negative atom count");
+    const int nall = nlocal + nghost;
+    if (nall != m->nall) throw StateError("ahip_compute: nlocal+nghost differs from the neighbor list's nall; call ahip_neigh_update after re-neighboring");
+    if (nall > 0 && (!x || !type || !f)) throw ArgError("ahip_compute: NULL x/type/f");
+    if (ntypes <= 0 || !type_mapper || !cutoff_matrix) throw ArgError("ahip_compute: bad ntypes/type_mapper/cutoff_matrix");
+    if (!eng) throw ArgError("ahip_compute: eng is NULL");
+    AHIP_CHECK(hipSetDevice(m->device));
+    hipStream_t s = nullptr;
+    *eng = 0;
+    if (virial) for (int k = 0; k < 6; ++k) virial[k] = 0;
+    if (m->inum == 0) return;
+
+    // types: LAMMPS 1-based -> filter index (type-1) and model type (pair_nequip_allegro.cpp:576)
+    m->h_ftype.resize(nall); m->h_mtype.resize(nall);
+    for (int i = 0; i < nall; ++i) {
+      int t = type[i];
+      if (t < 1 || t > ntypes) throw ArgError("ahip_compute: atom type out of range");
+      int mt = type_mapper[t - 1];
+      if (mt < 0 || mt >= m->hm.num_types) throw ArgError("ahip_compute: LAMMPS type " + std::to_string(t) + " is not mapped to a model type (all pair coeffs are not set)");
+      m->h_ftype[i] = t - 1; m->h_mtype[i] = mt;
+    }
+    std::vector<double> cutsq((size_t)ntypes * ntypes);
+    for (size_t k = 0; k < cutsq.size(); ++k) cutsq[k] = cutoff_matrix[k] * cutoff_matrix[k];
+    m->b_x.reserve((size_t)nall * 3 * sizeof(double));
+    m->b_ftype.reserve((size_t)nall * sizeof(int));
+    m->b_mtype.reserve((size_t)nall * sizeof(int));
+    m->b_f.reserve((size_t)nall * 3 * sizeof(double));
+    m->b_eatom.reserve((size_t)nall * sizeof(double));
+    m->b_engvir.reserve(8 * sizeof(double));
+    m->b_cutsq.reserve(cutsq.size() * sizeof(double));
+    AHIP_CHECK(hipMemcpyAsync(m->b_x.p, x, (size_t)nall * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    AHIP_CHECK(hipMemcpyAsync(m->b_ftype.p, m->h_ftype.data(), (size_t)nall * sizeof(int), hipMemcpyHostToDevice, s));
+    AHIP_CHECK(hipMemcpyAsync(m->b_mtype.p, m->h_mtype.data(), (size_t)nall * sizeof(int), hipMemcpyHostToDevice, s));
+    AHIP_CHECK(hipMemcpyAsync(m->b_cutsq.p, cutsq.data(), cutsq.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    AHIP_CHECK(hipMemsetAsync(m->b_f.p, 0, (size_t)nall * 3 * sizeof(double), s));
+    if (eatom) AHIP_CHECK(hipMemsetAsync(m->b_eatom.p, 0, (size_t)nall * sizeof(double), s));
+
+    ComputeArgs a{nlocal, nghost, m->b_x.as<double>(), m->b_ftype.as<int>(), m->b_cutsq.as<double>(), ntypes,
+                  m->b_mtype.as<int>(), m->b_f.as<double>(), eatom ? m->b_eatom.as<double>() : nullptr,
+                  m->b_engvir.as<double>(), s};
+    run_model(m, a);
+
+    m->h_f.resize((size_t)nall * 3);
+    double ev[7];
+    AHIP_CHECK(hipMemcpyAsync(m->h_f.data(), m->b_f.p, (size_t)nall * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (eatom) {
+      m->h_eatom.resize(nall);
+      AHIP_CHECK(hipMemcpyAsync(m->h_eatom.data(), m->b_eatom.p, (size_t)nall * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    AHIP_CHECK(hipMemcpyAsync(ev, m->b_engvir.p, 7 * sizeof(double), hipMemcpyDeviceToHost, s));
+    AHIP_CHECK(hipStreamSynchronize(s));
+    // scatter: f[i] += forces[i] for locals AND ghosts (pair_nequip_allegro.cpp:370-377)
+    for (size_t k = 0; k < (size_t)nall * 3; ++k) f[k] += m->h_f[k];
+    if (eatom)
+      for (int ii = 0; ii < m->inum; ++ii) { int i = m->h_ilist.empty() ? ii : m->h_ilist[ii]; eatom[i] = m->h_eatom[i]; }
+    *eng = ev[0];
+    if (virial) for (int k = 0; k < 6; ++k) virial[k] = ev[1 + k];
+    collect_timings(m);
+  });
+}
+
+int ahip_compute_dev(ahip_model *m, int nlocal, int nghost, const double *x_dev, const int *mtype_dev,
+                     const double *cutoff_matrix_model, double *f_dev, double *eatom_dev, double *eng_vir_dev,
+                     void *stream) {
+  return guarded([&] {
+    require_model(m);
+    if (!m->have_list) throw StateError("ahip_compute_dev called before a neighbor list was installed");
+    const int nall = nlocal + nghost;
+    if (nall != m->nall) throw StateError("ahip_compute_dev: nlocal+nghost differs from the neighbor list's nall");
+    if (!x_dev || !mtype_dev || !f_dev || !eng_vir_dev) throw ArgError("ahip_compute_dev: NULL device pointer");
+    AHIP_CHECK(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int T = m->hm.num_types;
+    std::vector<double> cutsq((size_t)T * T);
+    for (size_t k = 0; k < cutsq.size(); ++k) {
+      double c = cutoff_matrix_model ? cutoff_matrix_model[k] : m->rcut_model_host[k];
+      cutsq[k] = c * c;
+    }
+    m->b_cutsq.reserve(cutsq.size() * sizeof(double));
+    AHIP_CHECK(hipMemcpyAsync(m->b_cutsq.p, cutsq.data(), cutsq.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    AHIP_CHECK(hipStreamSynchronize(s));                     // cutsq is a stack vector
+    ComputeArgs a{nlocal, nghost, x_dev, mtype_dev, m->b_cutsq.as<double>(), T, mtype_dev, f_dev, eatom_dev, eng_vir_dev, s};
+    run_model(m, a);
+    collect_timings(m);
+  });
+}
+
+int ahip_get_edges(ahip_model *m, long long *nedges, long long *edge_index, double *rij) {
+  return guarded([&] {
+    require_model(m);
+    if (!nedges) throw ArgError("ahip_get_edges: nedges is NULL");
+    *nedges = m->nedges;
+    if (!edge_index && !rij) return;
+    const size_t E = (size_t)m->nedges;
+    if (E == 0) return;
+    AHIP_CHECK(hipSetDevice(m->device));
+    AHIP_CHECK(hipDeviceSynchronize());
+    std::vector<int> eii(E), ej(E), il(m->inum);
+    AHIP_CHECK(hipMemcpy(eii.data(), m->b_eii.p, E * sizeof(int), hipMemcpyDeviceToHost));
+    AHIP_CHECK(hipMemcpy(ej.data(), m->b_ej.p, E * sizeof(int), hipMemcpyDeviceToHost));
+    AHIP_CHECK(hipMemcpy(il.data(), m->d_ilist, (size_t)m->inum * sizeof(int), hipMemcpyDeviceToHost));
+    if (edge_index)
+      for (size_t e = 0; e < E; ++e) { edge_index[e] = il[eii[e]]; edge_index[E + e] = ej[e]; }
+    if (rij) {
+      if (m->edges_T_size == 8) {
+        std::vector<double> r(E * 3);
+        AHIP_CHECK(hipMemcpy(r.data(), m->b_rvec.p, E * 3 * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t e = 0; e < E; ++e) rij[e] = std::sqrt(r[3 * e] * r[3 * e] + r[3 * e + 1] * r[3 * e + 1] + r[3 * e + 2] * r[3 * e + 2]);
+      } else {
+        std::vector<float> r(E * 3);
+        AHIP_CHECK(hipMemcpy(r.data(), m->b_rvec.p, E * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t e = 0; e < E; ++e) {
+          double a = r[3 * e], b = r[3 * e + 1], c = r[3 * e + 2];
+          rij[e] = std::sqrt(a * a + b * b + c * c);
+        }
+      }
+    }
+  });
+}
+
+int ahip_debug_dump_edges(ahip_model *m, const int *tag) {
+  return guarded([&] {
+    require_model(m);
+    long long E = 0;
+    std::vector<long long> ei;
+    std::vector<double> r;
+    if (ahip_get_edges(m, &E, nullptr, nullptr) != AHIP_OK) throw std::runtime_error(g_err);
+    ei.resize((size_t)2 * E); r.resize((size_t)E);
+    if (E > 0 && ahip_get_edges(m, &E, ei.data(), r.data()) != AHIP_OK) throw std::runtime_error(g_err);
+    // exact format of pair_nequip_allegro.cpp:564,625,632
+    std::printf("Allegro edges: i j rij\n");
+    for (long long e = 0; e < E; ++e) {
+      long long i = ei[e], j = ei[E + e];
+      if (tag) std::printf("%d %d %.10g\n", tag[i] - 1, tag[j] - 1, r[e]);
+      else std::printf("%lld %lld %.10g\n", i, j, r[e]);
+    }
+    std::printf("end Allegro edges\n");
+    std::fflush(stdout);
+  });
+}
+
+int ahip_get_timings(ahip_model *m, const char **names, const double **ms, int *n) {
+  return guarded([&] {
+    require_model(m);
+    if (names) *names = m->timing_names.c_str();
+    if (ms) *ms = m->timing_ms.data();
+    if (n) *n = (int)m->timing_ms.size();
+  });
+}
+
+// last kernel family used ("generic_f32" | "generic_f64" | "fused_f32")
+extern "C" const char *ahip_last_path(ahip_model *m) { return m ? m->last_path.c_str() : ""; }
+extern "C" int ahip_last_max_degree(ahip_model *m) { return m ? m->last_max_deg : 0; }
+
+int ahip_build_neighbors_dev(ahip_model *m, int nlocal, int nall, const double *x_dev, const double *lo,
+                             const double *hi, double rc_list, void *stream) {
+  return guarded([&] {
+    require_model(m);
+    if (nlocal < 0 || nall < nlocal) throw ArgError("ahip_build_neighbors_dev: need 0 <= nlocal <= nall");
+    if (!x_dev || !lo || !hi || !(rc_list > 0)) throw ArgError("ahip_build_neighbors_dev: bad argument");
+    AHIP_CHECK(hipSetDevice(m->device));
+    neigh_build(*m, nlocal, nall, x_dev, lo, hi, rc_list, (hipStream_t)stream);
+  });
+}
+
+int ahip_nve_dev(ahip_model *m, int mode, int n, double *x_dev, double *v_dev, const double *f_dev,
+                 const int *mtype_dev, const double *mass_by_mtype, double dt, double ftm2v, void *stream) {
+  return guarded([&] {
+    require_model(m);
+    if (n < 0 || (n > 0 && (!x_dev || !v_dev || !f_dev || !mtype_dev || !mass_by_mtype))) throw ArgError("ahip_nve_dev: bad argument");
+    if (mode != 0 && mode != 1) throw ArgError("ahip_nve_dev: mode must be 0 or 1");
+    AHIP_CHECK(hipSetDevice(m->device));
+    nve_step(mode, n, x_dev, v_dev, f_dev, mtype_dev, mass_by_mtype, m->hm.num_types, dt, ftm2v, (hipStream_t)stream);
+  });
+}

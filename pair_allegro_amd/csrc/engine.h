@@ -1,0 +1,159 @@
+// Internal engine state shared by the C-ABI (allegro_hip.hip), the generic path
+// (generic_engine.h) and the fused MFMA path (fused.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "model_io.h"
+
+namespace ahip {
+
+struct HipError : std::runtime_error {
+  explicit HipError(const std::string &m) : std::runtime_error(m) {}
+};
+struct ArgError : std::runtime_error {
+  explicit ArgError(const std::string &m) : std::runtime_error(m) {}
+};
+struct StateError : std::runtime_error {
+  explicit StateError(const std::string &m) : std::runtime_error(m) {}
+};
+struct UnsupportedError : std::runtime_error {
+  explicit UnsupportedError(const std::string &m) : std::runtime_error(m) {}
+};
+
+#define AHIP_CHECK(expr)                                                                       \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      throw ahip::HipError(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " (" +   \
+                           __FILE__ + ":" + std::to_string(__LINE__) + ")");                   \
+  } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  template <typename T> T *as() const { return (T *)p; }
+  void reserve(size_t bytes) {
+    if (bytes <= cap) return;
+    if (p) AHIP_CHECK(hipFree(p));
+    p = nullptr; cap = 0;
+    size_t want = bytes + bytes / 16 + 256;          // 6 % head-room: shape hysteresis like the
+    AHIP_CHECK(hipMalloc(&p, want));                   // Kokkos path (pair_nequip_allegro_kokkos.cpp:218-229)
+    cap = want;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+// bump allocator over one DevBuf; first pass measures, second pass hands out pointers
+struct Arena {
+  char *base = nullptr;
+  size_t off = 0;
+  bool measuring = true;
+  template <typename T> T *get(size_t n) {
+    size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+    T *r = measuring ? nullptr : (T *)(base + off);
+    off += bytes;
+    return r;
+  }
+};
+
+template <typename T> struct DeviceWeights {
+  std::map<std::string, T *> w;
+  std::vector<void *> owned;
+  bool ready = false;
+  T *get(const std::string &n) const {
+    auto it = w.find(n);
+    if (it == w.end()) throw StateError("device weight '" + n + "' missing");
+    return it->second;
+  }
+};
+
+struct TimingSlot { std::string name; hipEvent_t a = nullptr, b = nullptr; bool used = false; };
+
+struct Model {
+  HostModel hm;
+  int device = 0;
+  int D = 1, Ka = 0;
+  std::vector<double> rcut_model_host;      // [T*T]
+
+  // options
+  std::string opt_path = "auto";            // auto | fused | generic
+  std::string opt_precision = "model";      // model | float64
+  long long chunk_edges = 2000000;
+  bool timing = false;
+
+  // weights
+  DeviceWeights<float> wf;
+  DeviceWeights<double> wd;
+  void *cg_dev = nullptr;                    // AhipCgEntry[ncg_full]
+  int ncg_full = 0, ncg_scalar = 0;
+  double *rcut_model_dev = nullptr;          // [T*T]
+
+  // neighbor list (device)
+  int inum = 0, nall = 0;
+  long long nneigh = 0;
+  bool have_list = false;
+  const int *d_ilist = nullptr, *d_nloff = nullptr, *d_nlj = nullptr;   // current (owned or borrowed)
+  DevBuf b_ilist, b_nloff, b_nlj;
+  std::vector<int> h_flat_j, h_off32, h_ilist;
+
+  // per-call host-path staging
+  DevBuf b_x, b_ftype, b_mtype, b_f, b_eatom, b_engvir, b_cutsq;
+  std::vector<int> h_ftype, h_mtype;
+  std::vector<double> h_f, h_eatom;
+
+  // edge list + workspace
+  DevBuf b_cnt, b_eoff, b_eii, b_ej, b_rvec, b_partial, b_ws, b_misc;
+  long long nedges = 0;
+  int edges_T_size = 0;                      // sizeof(T) of b_rvec contents
+  std::vector<int> h_eoff;
+  int last_max_deg = 0;
+  std::string last_path;
+
+  // timings
+  std::vector<TimingSlot> slots;
+  std::string timing_names;
+  std::vector<double> timing_ms;
+
+  // fused path private state
+  void *fused_state = nullptr;
+
+  // neighbor builder state
+  void *nb_state = nullptr;
+};
+
+// ---- generic path (generic_engine.cpp.inc via allegro_hip.hip) -------------------------------
+struct ComputeArgs {
+  int nlocal, nghost;
+  const double *x;          // device [nall][3]
+  const int *ftype;         // device [nall], index into cutsq
+  const double *cutsq;      // device [nft*nft]
+  int nft;
+  const int *mtype;         // device [nall] model types
+  double *f;                // device [nall][3], accumulated
+  double *eatom;            // device [nall] or null
+  double *engvir;           // device [7]
+  hipStream_t stream;
+};
+
+// ---- fused path entry points (fused.hip; the host-emulation test build links a stub) ---------
+// Returns true when the fused MFMA kernels support this model shape at all.
+bool fused_model_supported(const Model &m, std::string *why);
+// Runs forward+backward for all centres; edges already built (b_eoff/b_eii/b_ej/b_rvec as float).
+// Returns false (and sets *why) if this particular list cannot be handled (e.g. too many edges per atom).
+bool fused_run(Model &m, const ComputeArgs &a, std::string *why);
+void fused_free(Model &m);
+
+// ---- neighbor builder (neigh.hip; stubbed in the host-emulation build) -------------------------
+void neigh_build(Model &m, int nlocal, int nall, const double *x_dev, const double *lo, const double *hi,
+                 double rc_list, hipStream_t s);
+void neigh_free(Model &m);
+void nve_step(int mode, int n, double *x, double *v, const double *f, const int *mtype, const double *mass_dev_or_host,
+              int ntypes, double dt, double ftm2v, hipStream_t s);
+
+}  // namespace ahip

@@ -1,0 +1,37 @@
+// Host-side model description + AHIP blob reader (no HIP, no torch).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+namespace ahip {
+
+struct HostTensor {
+  std::vector<int> shape;
+  std::vector<double> data;
+  long long numel() const { long long n = 1; for (int s : shape) n *= s; return n; }
+};
+
+struct HostModel {
+  std::string model_dtype = "float32";
+  std::vector<std::string> type_names;
+  std::string type_names_joined;            // whitespace separated (reference metadata form)
+  double r_max = 0;
+  std::vector<double> per_edge_type_cutoff; // [T*T] model index, empty = r_max everywhere
+  int num_types = 0, num_bessels = 0, poly_p = 0, l_max = 0, num_layers = 0;
+  int S = 0, U = 0, mlp_depth = 0, mlp_width = 0, readout_depth = 0, readout_width = 0;
+  double avg_num_neighbors = 1;
+  long long seed = 0;
+  std::map<std::string, HostTensor> tensors;
+
+  const HostTensor &get(const std::string &name) const;   // throws std::runtime_error
+};
+
+// Reads `path` (.nequip.pth zip archive with an allegro_hip.bin member, or bare .ahip blob).
+// Throws std::runtime_error with a user-facing message.
+HostModel load_model_file(const std::string &path);
+
+// Parses an in-memory blob.
+HostModel parse_blob(const unsigned char *p, size_t n, const std::string &origin);
+
+}  // namespace ahip

@@ -1,0 +1,34 @@
+// TEST INFRASTRUCTURE ONLY: loop equivalents of prims.hip and a stub of fused.hip for the
+// host-emulation build (see hip/hip_runtime.h).
+#include <hip/hip_runtime.h>
+
+#include "engine.h"
+#include "prims.h"
+
+dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace ahip {
+hipError_t prim_exclusive_scan_i32(const int *in, int *out, int n, hipStream_t) {
+  long long s = 0;
+  for (int i = 0; i < n; ++i) { int v = in[i]; out[i] = (int)s; s += v; }
+  out[n > 0 ? n : 0] = (int)s;
+  return hipSuccess;
+}
+hipError_t prim_sum_columns_f64(const double *in, long long nrow, int ncol, double *out, hipStream_t) {
+  for (int c = 0; c < ncol; ++c) {
+    double s = 0;
+    for (long long r = 0; r < nrow; ++r) s += in[r * ncol + c];
+    out[c] = s;
+  }
+  return hipSuccess;
+}
+hipError_t prim_max_i32(const int *in, int n, int *out, hipStream_t) {
+  int m = 0;
+  for (int i = 0; i < n; ++i) m = std::max(m, in[i]);
+  *out = m;
+  return hipSuccess;
+}
+bool fused_model_supported(const Model &, std::string *why) { if (why) *why = "host emulation has no MFMA"; return false; }
+bool fused_run(Model &, const ComputeArgs &, std::string *why) { if (why) *why = "host emulation has no MFMA"; return false; }
+void fused_free(Model &) {}
+}  // namespace ahip

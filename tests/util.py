@@ -1,0 +1,119 @@
+"""Shared helpers of the parity tests (imports the oracle: tests only)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+
+from oracle import allegro_torch, glue
+from pair_allegro_amd import lmp_like, model_file
+from pair_allegro_amd.pair import PairAllegro, atom_from_rank_system, list_from_rank_system
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN_TAGS = ["Si64_r5", "Cu-cubic_r5", "Cu-cubic_r15", "Cu2AgO4_r5", "aspirin_r5", "aspirin_r15", "CuPd-cubic-big_r5"]
+
+_model_cache = {}
+
+
+def load_golden(tag):
+    z = np.load(os.path.join(GOLDEN, tag + ".npz"))
+    g = {k: z[k] for k in z.files}
+    g["cfg"] = json.loads(str(g["cfg"]))
+    g["symbols"] = [str(s) for s in g["symbols"]]
+    g["lmp_type_names"] = [str(s) for s in g["lmp_type_names"]]
+    g["tag"] = tag
+    return g
+
+
+def golden_model(g, model_dir, dtype):
+    """Exports (once) the golden case's model as <tag>_<dtype>.nequip.pth; checks the weight hash."""
+    key = (g["tag"], dtype)
+    if key not in _model_cache:
+        cfg = dict(g["cfg"])
+        w = model_file.init_weights(cfg)
+        assert hashlib.sha256(model_file.dumps(cfg, w)).hexdigest() == str(g["weights_sha256"]), \
+            "seeded initialiser drifted from the golden fixtures"
+        cfg["model_dtype"] = dtype
+        path = os.path.join(model_dir, f"{g['tag']}_{dtype}.nequip.pth")
+        allegro_torch.export_nequip_pth(path, cfg, w)
+        _model_cache[key] = (path, cfg, w)
+    return _model_cache[key]
+
+
+def lammps_types(g):
+    names = g["lmp_type_names"]
+    return np.array([names.index(s) + 1 for s in g["symbols"]], dtype=np.int32), names
+
+
+def run_pair(lib, model_path, cell, pos, types, lmp_names, skin=1.0, grid=(1, 1, 1), options=None, shuffle_seed=None):
+    """The reference test's `run 0` on a px*py*pz rank grid: every rank builds its LAMMPS view,
+    calls PairAllegro.compute, and the per-rank partial results are reduced the way LAMMPS does
+    (ghost forces reverse-communicated to their owners, eng/virial summed over ranks)."""
+    n = len(pos)
+    forces = np.zeros((n, 3))
+    eatom = np.zeros(n)
+    pe = 0.0
+    virial = np.zeros(6)
+    edges = []
+    info = {}
+    ranks = lmp_like.grid_ranks(grid)
+    for r in ranks:
+        pair = PairAllegro(me=0, nprocs=1, lib=lib, quiet=True)
+        pair.settings([])
+        pair.coeff(["*", "*", model_path] + list(lmp_names), ntypes=len(lmp_names))
+        for k, v in (options or {}).items():
+            pair.model.set_option(k, v)
+        pair.init_style()
+        rs = lmp_like.build_rank_system(cell, pos, types, pair.init_one(1, 1) + skin, grid=grid, rank=r)
+        if shuffle_seed is not None:                      # neighbour order must not matter
+            rng = np.random.RandomState(shuffle_seed)
+            for row in rs.firstneigh[: rs.nlocal]:
+                rng.shuffle(row)
+        atom = atom_from_rank_system(rs, len(lmp_names))
+        pair.compute(atom, list_from_rank_system(rs))
+        np.add.at(forces, rs.tag - 1, atom.f)
+        if rs.nlocal:
+            eatom[rs.tag[: rs.nlocal] - 1] = pair.eatom[: rs.nlocal]
+        pe += pair.eng_vdwl
+        virial += pair.virial
+        if rs.nlocal:
+            ei, rij = pair.model.get_edges()
+            edges.append((rs.tag[ei[0]] - 1, rs.tag[ei[1]] - 1, rij))
+            info["path"] = pair.model.last_path
+        pair.model.close()
+    i = np.concatenate([e[0] for e in edges]); j = np.concatenate([e[1] for e in edges]); d = np.concatenate([e[2] for e in edges])
+    return dict(forces=forces, eatom=eatom, pe=pe, virial=virial, edges=(i, j, d), info=info)
+
+
+def oracle_run(cfg, w, cell, pos, types, lmp_names, skin=1.0):
+    oracle = allegro_torch.build(cfg, w)
+    rs = lmp_like.build_rank_system(cell, pos, types, cfg["r_max"] + skin)
+    model_types = cfg["type_names"]
+    mapper = np.array([model_types.index(s) if s in model_types else -1 for s in lmp_names], dtype=np.int32)
+    T = len(lmp_names)
+    cm = np.full((T, T), cfg["r_max"])
+    if cfg.get("per_edge_type_cutoff") is not None:
+        pc = np.asarray(cfg["per_edge_type_cutoff"])
+        for a in range(T):
+            for b in range(T):
+                cm[a, b] = pc[mapper[a], mapper[b]]
+    f = np.zeros_like(rs.x)
+    ea = np.zeros(rs.nall)
+    eng, vir, inp = glue.compute(oracle, rs.x, rs.type, rs.nlocal, rs.ilist, rs.numneigh, rs.firstneigh, mapper, cm, f, ea)
+    n = len(pos)
+    forces = np.zeros((n, 3))
+    np.add.at(forces, rs.tag - 1, f)
+    eatom = np.zeros(n)
+    eatom[rs.tag[: rs.nlocal] - 1] = ea[: rs.nlocal]
+    return dict(forces=forces, eatom=eatom, pe=eng, virial=vir, inputs=inp, rs=rs)
+
+
+def assert_close_to(res, ref, tol, stress_factor=20.0, what=""):
+    """Reference tolerances: abs+rel tol on F, E_i, PE; x20 on the virial
+    (/root/reference/tests/conftest.py:113, tests/test_python_repro_allegro.py:297-355)."""
+    np.testing.assert_allclose(res["forces"], ref["forces"], atol=tol, rtol=tol, err_msg=f"forces {what}")
+    np.testing.assert_allclose(res["eatom"], ref["eatom"], atol=tol, rtol=tol, err_msg=f"eatom {what}")
+    np.testing.assert_allclose(res["pe"], float(ref["pe"]), atol=tol * max(1, len(ref["eatom"]) ** 0.5), rtol=tol, err_msg=f"pe {what}")
+    np.testing.assert_allclose(res["eatom"].sum(), res["pe"], atol=1e-9 * max(1.0, abs(res["pe"])), rtol=1e-9, err_msg="PE != sum eatom")
+    np.testing.assert_allclose(res["virial"], ref["virial"], atol=tol * stress_factor * max(1, len(ref["eatom"]) ** 0.5),
+                               rtol=tol * stress_factor, err_msg=f"virial {what}")

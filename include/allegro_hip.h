@@ -130,6 +130,10 @@ const char *ahip_last_path(ahip_model *m);
 /* Largest number of edges of any centre atom in the last compute. */
 int ahip_last_max_degree(ahip_model *m);
 
+/* Diagnostic: single-wave self-test of the fused path's register-chain MFMA primitive,
+ * out[32][N] = in[32][K] @ W[K][N] (W row-major f64, in/out f32 host buffers). */
+int ahip_debug_fused_linear(int K, int N, const double *W, const float *in, float *out);
+
 /* ---- mini-MD helpers used by the stand-alone driver / bench (device-resident) ------------- */
 
 /* Build a full neighbor list with cutoff rc_list (= r_max + skin) for nlocal centre atoms among

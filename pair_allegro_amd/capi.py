@@ -22,7 +22,7 @@ SYMBOLS = [
     "ahip_last_error", "ahip_device_count", "ahip_model_load", "ahip_model_free", "ahip_model_meta",
     "ahip_set_option", "ahip_neigh_update", "ahip_neigh_update_csr", "ahip_neigh_update_dev",
     "ahip_compute", "ahip_compute_dev", "ahip_get_edges", "ahip_debug_dump_edges", "ahip_get_timings",
-    "ahip_last_path", "ahip_last_max_degree", "ahip_build_neighbors_dev", "ahip_nve_dev",
+    "ahip_last_path", "ahip_last_max_degree", "ahip_debug_fused_linear", "ahip_build_neighbors_dev", "ahip_nve_dev",
 ]
 
 
@@ -76,6 +76,17 @@ class Library:
                                                C.POINTER(C.c_double), C.c_double, C.c_void_p]
         L.ahip_nve_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_double), C.c_double, C.c_double, C.c_void_p]
+
+        L.ahip_debug_fused_linear.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+
+    def debug_fused_linear(self, W: np.ndarray, x: np.ndarray) -> np.ndarray:
+        W = np.ascontiguousarray(W, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        K, N = W.shape
+        assert x.shape == (32, K)
+        out = np.zeros((32, N), dtype=np.float32)
+        self.check(self.lib.ahip_debug_fused_linear(K, N, _p(W, C.c_double), _p(x, C.c_float), _p(out, C.c_float)))
+        return out
 
     def check(self, rc: int) -> None:
         if rc != 0:

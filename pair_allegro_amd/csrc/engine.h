@@ -127,7 +127,24 @@ struct Model {
   void *nb_state = nullptr;
 };
 
-// ---- generic path (generic_engine.cpp.inc via allegro_hip.hip) -------------------------------
+// ---- stage timing ------------------------------------------------------------------------------
+struct StageTimer {
+  Model &m; hipStream_t s; int idx = -1;
+  StageTimer(Model &m_, const char *name, hipStream_t s_) : m(m_), s(s_) {
+    if (!m.timing) return;
+    for (size_t i = 0; i < m.slots.size(); ++i) if (m.slots[i].name == name) idx = (int)i;
+    if (idx < 0) {
+      TimingSlot t; t.name = name;
+      AHIP_CHECK(hipEventCreate(&t.a)); AHIP_CHECK(hipEventCreate(&t.b));
+      m.slots.push_back(t); idx = (int)m.slots.size() - 1;
+    }
+    m.slots[idx].used = true;
+    AHIP_CHECK(hipEventRecord(m.slots[idx].a, s));
+  }
+  ~StageTimer() { if (idx >= 0) (void)hipEventRecord(m.slots[idx].b, s); }
+};
+
+// ---- generic path (generic_engine.h via allegro_hip.hip) -------------------------------
 struct ComputeArgs {
   int nlocal, nghost;
   const double *x;          // device [nall][3]

@@ -1,8 +1,859 @@
-// Fused MFMA path -- placeholder until the register-chain kernel lands.
+// Fused MFMA path: the whole Allegro model (forward + hand-derived backward) for a tile of centre
+// atoms in ONE kernel launch, float32 compute on the gfx950 matrix cores.
+//
+// Mapping (DESIGN.md "Fused kernel"):
+//  * tile  = consecutive centre atoms whose edges (<= 128) fit the 128 edge slots of a 256-thread
+//            workgroup; wave w owns slots 32w..32w+31; lane = (slot = lane & 31, half h = lane >> 5).
+//  * every per-edge feature vector lives in registers in the v_mfma_f32_32x32x2_f32 C/D layout:
+//            tile t, register r of lane (slot, h)  <->  feature 32 t + (r & 3) + 8 (r >> 2) + 4 h.
+//            With D = W^T-tile (rows = output features) x activations (cols = edges), register r of an
+//            output tile is exactly the B operand of MFMA step r of the next layer: the MLP chains run
+//            register-to-register with no LDS traffic and no shuffles.
+//  * weights are pre-swizzled on the host into A-operand fragment order (one coalesced 1 KiB
+//            dwordx4 load feeds 4 MFMAs); a transposed copy serves the backward pass.
+//  * the only cross-edge coupling -- the per-centre environment sum and its gradient -- goes through
+//            an LDS staging tile [128 slots][128 features] and a deterministic per-atom reduction.
+//  * activations needed by the backward pass are spilled as raw register images to a per-wave
+//            private scratch (written and re-read by the same wave within the same tile, so it lives
+//            in L2 / Infinity Cache, not HBM).
+//
+// Supported model shape (others run the generic path): l_max = 1, 32 tensor features, 64 scalars,
+// MLP 2 x 64, read-out 1 x 32, 8 Bessels, <= 3 layers, <= 4 types.  Reference graph:
+// the TorchScript model executed at /root/reference/pair_nequip_allegro.cpp:409-430.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+
+#include "../../include/allegro_hip.h"
 #include "engine.h"
+#include "prims.h"
 
 namespace ahip {
-bool fused_model_supported(const Model &, std::string *why) { if (why) *why = "fused kernels not built yet"; return false; }
-bool fused_run(Model &, const ComputeArgs &, std::string *why) { if (why) *why = "fused kernels not built yet"; return false; }
-void fused_free(Model &) {}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int TILE_SLOTS = 128;
+static constexpr int MAXA = 16;          // centre atoms per tile
+static constexpr int MAXNL = 3;
+static constexpr int STG_LD = 129;       // staging leading dimension (odd -> conflict-free)
+static constexpr int SEG = 512;          // atoms per sequential packing segment
+static constexpr int ROW = 1024;         // floats per saved register image (16 regs x 64 lanes)
+
+__host__ __device__ inline int feat_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+struct FusedArgs {
+  // edge list
+  const int *eoff, *e_ii, *e_j, *ilist, *mtype;
+  const float *rvec;
+  const double *rcut;            // [T*T]
+  int T, NL, p;
+  float cenv;
+  // tiles
+  const int *tile_a0, *ntiles;
+  // weights (offsets in floats into wbase)
+  const float *wbase;
+  int o_pair, o_tb_wc, o_tb_w1, o_tb_w2, o_emb, o_out0, o_out1, o_scale, o_shift;
+  int o_tb_wcT, o_tb_w1T, o_tb_w2T, o_embT, o_out0T;
+  int o_env[MAXNL], o_lat0[MAXNL], o_lat1[MAXNL], o_lat2[MAXNL], o_mix[MAXNL], o_tp[MAXNL], o_res[MAXNL];
+  int o_envT[MAXNL], o_lat0T[MAXNL], o_lat1T[MAXNL], o_lat2T[MAXNL], o_mixT[MAXNL];
+  // scratch
+  float *scratch;
+  long long wg_scratch, wave_scratch;     // floats
+  // outputs
+  double *f, *eatom, *partial;            // partial [gridDim.x][7]
+};
+
+struct __attribute__((aligned(16))) Lds {
+  float stage[TILE_SLOTS * STG_LD];
+  float env[MAXNL][MAXA * STG_LD];
+  float denv[MAXA * STG_LD];
+  float ea[MAXA];
+  int aoff[MAXA + 2];
+};
+
+// ---------------------------------------------------------------------------- device helpers
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// out[NT] (+)= W-tiles x in[KT].  Fragment layout: [ot][kt][q][lane][4], r = 4 q + c.
+template <int KT, int NT, int KQ_LAST = 4, bool ACC = false>
+__device__ __forceinline__ void linear(const float *__restrict__ Wf, const f32x16 (&in)[KT], f32x16 (&out)[NT], int lane) {
+#pragma unroll
+  for (int ot = 0; ot < NT; ++ot) {
+    f32x16 acc;
+    if (ACC) acc = out[ot];
+    else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const int nq = (kt == KT - 1) ? KQ_LAST : 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < nq) {
+          const f32x4 a = *(const f32x4 *)(Wf + ((((ot * KT + kt) * 4 + q) * 64 + lane) << 2));
+          acc = mfma(a.x, in[kt][4 * q + 0], acc);
+          acc = mfma(a.y, in[kt][4 * q + 1], acc);
+          acc = mfma(a.z, in[kt][4 * q + 2], acc);
+          acc = mfma(a.w, in[kt][4 * q + 3], acc);
+        }
+      }
+    }
+    out[ot] = acc;
+  }
+}
+
+__device__ __forceinline__ float sigmoidf_fast(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
+__device__ __forceinline__ float silu1(float z) { return z * sigmoidf_fast(z); }
+__device__ __forceinline__ float dsilu1(float z) {
+  float s = sigmoidf_fast(z);
+  return s * (1.f + z * (1.f - s));
+}
+
+template <int NT> __device__ __forceinline__ void silu_tiles(const f32x16 (&z)[NT], f32x16 (&h)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h[t][r] = silu1(z[t][r]);
+}
+
+template <int NT> __device__ __forceinline__ void save_rows(float *scr, int row0, const f32x16 (&v)[NT], int lane) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 x = {v[t][4 * q], v[t][4 * q + 1], v[t][4 * q + 2], v[t][4 * q + 3]};
+      *(f32x4 *)(scr + (size_t)(row0 + t) * ROW + ((q * 64 + lane) << 2)) = x;
+    }
+}
+template <int NT> __device__ __forceinline__ void load_rows(const float *scr, int row0, f32x16 (&v)[NT], int lane) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 x = *(const f32x4 *)(scr + (size_t)(row0 + t) * ROW + ((q * 64 + lane) << 2));
+      v[t][4 * q] = x.x; v[t][4 * q + 1] = x.y; v[t][4 * q + 2] = x.z; v[t][4 * q + 3] = x.w;
+    }
+}
+
+// per-half small vectors stored as [q][h][4]
+__device__ __forceinline__ f32x16 load_hvec(const float *__restrict__ p, int h) {
+  f32x16 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 x = *(const f32x4 *)(p + ((q * 2 + h) << 2));
+    v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+  }
+  return v;
+}
+
+__device__ __forceinline__ void cutoff_poly(int p, float x, float &f, float &df) {
+  if (x >= 1.f) { f = 0.f; df = 0.f; return; }
+  float xp1 = 1.f;
+  for (int k = 0; k < p - 1; ++k) xp1 *= x;
+  const float xp = xp1 * x;
+  const float a = 0.5f * (p + 1) * (p + 2), b = (float)p * (p + 2), c = 0.5f * p * (p + 1);
+  f = 1.f - a * xp + b * xp * x - c * xp * x * x;
+  df = -a * p * xp1 + b * (p + 1) * xp - c * (p + 2) * xp * x;
+}
+
+// scratch row map
+__device__ __host__ constexpr int R_Z1TB() { return 0; }
+__device__ __host__ constexpr int R_Z2TB() { return 2; }
+__device__ __host__ constexpr int R_U0() { return 4; }
+__device__ __host__ constexpr int R_W0() { return 6; }
+__device__ __host__ constexpr int R_LAYER(int kk) { return 8 + 14 * kk; }      // OM 2, Z1 2, Z2 2, U 2, VPREV 4, spare 2
+__device__ __host__ constexpr int R_TOTAL(int NL) { return 8 + 14 * NL; }
+
+static constexpr float C_S3 = 1.7320508075688772f;
+static constexpr float C_P1 = 0.5773502691896258f;     // (1,1,0): sqrt(1) * w3j = 1/sqrt(3)
+static constexpr float C_P4 = 0.7071067811865476f;     // (1,1,1): sqrt(3) * w3j = eps_ijk / sqrt(2)
+
+// ---------------------------------------------------------------------------- the kernel
+__global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
+  __shared__ Lds lds;
+  const int tid = threadIdx.x, lane = tid & 63, slot = lane & 31, h = lane >> 5, wave = tid >> 6;
+  float *scr = A.scratch + (size_t)blockIdx.x * A.wg_scratch + (size_t)wave * A.wave_scratch;
+  const float *__restrict__ Wb = A.wbase;
+  const int ntiles = *A.ntiles;
+  const int NL = A.NL;
+  double acc_part = 0.0;       // thread 0: energy; threads 64..69: virial components
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int a0 = A.tile_a0[tile], a1 = A.tile_a0[tile + 1];
+    const int na = a1 - a0;
+    const int e0 = A.eoff[a0], e1 = A.eoff[a1];
+    if (tid <= na) lds.aoff[tid] = A.eoff[a0 + tid] - e0;
+    const int s = wave * 32 + slot;
+    const int e = e0 + s;
+    const bool valid = e < e1;
+
+    // ---------------- geometry ----------------
+    float rx = 1.f, ry = 0.f, rz = 0.f;
+    int aloc = 0, ti = 0, tj = 0, jat = 0;
+    if (valid) {
+      rx = A.rvec[3 * (size_t)e]; ry = A.rvec[3 * (size_t)e + 1]; rz = A.rvec[3 * (size_t)e + 2];
+      const int ii = A.e_ii[e];
+      aloc = ii - a0;
+      ti = A.mtype[A.ilist[ii]];
+      jat = A.e_j[e];
+      tj = A.mtype[jat];
+    }
+    const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+    const float inv = 1.f / d;
+    const float nx = rx * inv, ny = ry * inv, nz = rz * inv;
+    const float rc = (float)A.rcut[ti * A.T + tj];
+    const float xx = d / rc;
+    float fc, dfc_dx;
+    cutoff_poly(A.p, xx, fc, dfc_dx);
+    if (!valid) { fc = 0.f; dfc_dx = 0.f; }
+    const float Y1 = C_S3 * ny, Y2 = C_S3 * nz, Y3 = C_S3 * nx;
+    const float pref = 2.f / rc;
+    const float PI = 3.14159265358979323846f;
+
+    // ---------------- two-body MLP ----------------
+    f32x16 x[2];
+    {
+      f32x16 z[2], hh[2];
+      const float *pt = Wb + A.o_pair + (size_t)(ti * A.T + tj) * 128;
+      z[0] = load_hvec(pt, h);
+      z[1] = load_hvec(pt + 32, h);
+      f32x16 bfin[1];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bfin[0][r] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float n = (float)(r + 4 * h + 1);
+        bfin[0][r] = pref * sinf(PI * n * xx) * inv * fc;
+      }
+      linear<1, 2, 1, true>(Wb + A.o_tb_wc, bfin, z, lane);
+      save_rows<2>(scr, R_Z1TB(), z, lane);
+      silu_tiles<2>(z, hh);
+      linear<2, 2>(Wb + A.o_tb_w1, hh, z, lane);
+      save_rows<2>(scr, R_Z2TB(), z, lane);
+      silu_tiles<2>(z, hh);
+      linear<2, 2>(Wb + A.o_tb_w2, hh, z, lane);
+      save_rows<2>(scr, R_U0(), z, lane);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[t][r] = fc * z[t][r];
+    }
+    // ---------------- tensor embedding ----------------
+    f32x16 V[4];
+    {
+      f32x16 w0[2];
+      linear<2, 2>(Wb + A.o_emb, x, w0, lane);
+      save_rows<2>(scr, R_W0(), w0, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        V[0][r] = w0[0][r];
+        V[1][r] = w0[1][r] * Y1; V[2][r] = w0[1][r] * Y2; V[3][r] = w0[1][r] * Y3;
+      }
+    }
+    __syncthreads();          // aoff visible; previous tile's LDS users done
+
+    // ---------------- layers, forward ----------------
+    for (int kk = 0; kk < NL; ++kk) {
+      const bool last = (kk == NL - 1);
+      const int RL = R_LAYER(kk);
+      f32x16 om[2];
+      linear<2, 2>(Wb + A.o_env[kk], x, om, lane);
+      save_rows<2>(scr, RL + 0, om, lane);
+      {
+        float *st = lds.stage + s * STG_LD;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int fidx = feat_of(r, h);
+          st[fidx] = om[0][r];
+          st[32 + fidx] = om[1][r] * Y1;
+          st[64 + fidx] = om[1][r] * Y2;
+          st[96 + fidx] = om[1][r] * Y3;
+        }
+      }
+      __syncthreads();
+      {
+        const int fidx = tid & 127;
+        for (int a = tid >> 7; a < na; a += 2) {
+          float sum = 0.f;
+          for (int sl = lds.aoff[a]; sl < lds.aoff[a + 1]; ++sl) sum += lds.stage[sl * STG_LD + fidx];
+          lds.env[kk][a * STG_LD + fidx] = A.cenv * sum;
+        }
+      }
+      __syncthreads();
+      if (kk > 0) save_rows<4>(scr, RL + 8, V, lane);
+      // tensor product
+      f32x16 Vp[4];
+      {
+        const float *en = lds.env[kk] + aloc * STG_LD;
+        const float *tp = Wb + A.o_tp[kk];
+        const f32x16 p0 = load_hvec(tp, h), p1 = load_hvec(tp + 32, h);
+        f32x16 p2, p3, p4;
+        if (!last) { p2 = load_hvec(tp + 64, h); p3 = load_hvec(tp + 96, h); p4 = load_hvec(tp + 128, h); }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int fidx = feat_of(r, h);
+          const float e0v = en[fidx], e1v = en[32 + fidx], e2v = en[64 + fidx], e3v = en[96 + fidx];
+          const float v0 = V[0][r], v1 = V[1][r], v2 = V[2][r], v3 = V[3][r];
+          Vp[0][r] = p0[r] * v0 * e0v + p1[r] * C_P1 * (v1 * e1v + v2 * e2v + v3 * e3v);
+          if (!last) {
+            const float c4 = p4[r] * C_P4;
+            Vp[1][r] = p2[r] * v0 * e1v + p3[r] * v1 * e0v + c4 * (v2 * e3v - v3 * e2v);
+            Vp[2][r] = p2[r] * v0 * e2v + p3[r] * v2 * e0v + c4 * (v3 * e1v - v1 * e3v);
+            Vp[3][r] = p2[r] * v0 * e3v + p3[r] * v3 * e0v + c4 * (v1 * e2v - v2 * e1v);
+          }
+        }
+      }
+      // latent MLP
+      {
+        f32x16 cat[3], z[2], hh[2];
+        cat[0] = x[0]; cat[1] = x[1]; cat[2] = Vp[0];
+        linear<3, 2>(Wb + A.o_lat0[kk], cat, z, lane);
+        save_rows<2>(scr, RL + 2, z, lane);
+        silu_tiles<2>(z, hh);
+        linear<2, 2>(Wb + A.o_lat1[kk], hh, z, lane);
+        save_rows<2>(scr, RL + 4, z, lane);
+        silu_tiles<2>(z, hh);
+        linear<2, 2>(Wb + A.o_lat2[kk], hh, z, lane);
+        save_rows<2>(scr, RL + 6, z, lane);
+        const float ra = Wb[A.o_res[kk]], rb = Wb[A.o_res[kk] + 1] * fc;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) x[t][r] = ra * x[t][r] + rb * z[t][r];
+      }
+      if (!last) {
+        const float *mx = Wb + A.o_mix[kk];
+        f32x16 in1[1], out1[1];
+        in1[0] = Vp[0];
+        linear<1, 1>(mx, in1, out1, lane);
+        V[0] = out1[0];
+#pragma unroll
+        for (int lm = 1; lm < 4; ++lm) {
+          in1[0] = Vp[lm];
+          linear<1, 1>(mx + 4096, in1, out1, lane);
+          V[lm] = out1[0];
+        }
+      }
+    }
+
+    // ---------------- read-out ----------------
+    f32x16 zr[1];
+    linear<2, 1>(Wb + A.o_out0, x, zr, lane);
+    const f32x16 wo1 = load_hvec(Wb + A.o_out1, h);
+    float eps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) eps += silu1(zr[0][r]) * wo1[r];
+    eps += __shfl_xor(eps, 32, 64);
+
+    // =========================== backward ===========================
+    const float deps = valid ? Wb[A.o_scale + ti] * A.cenv : 0.f;
+    f32x16 dx[2];
+    {
+      f32x16 dzr[1];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dzr[0][r] = deps * wo1[r] * dsilu1(zr[0][r]);
+      linear<1, 2>(Wb + A.o_out0T, dzr, dx, lane);
+    }
+    float dfc_part = 0.f, dY1 = 0.f, dY2 = 0.f, dY3 = 0.f;
+    f32x16 dV[4];
+#pragma unroll
+    for (int lm = 0; lm < 4; ++lm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dV[lm][r] = 0.f;
+    f32x16 w0s[2];            // w0 (needed for V0 recompute and the embedding backward)
+    load_rows<2>(scr, R_W0(), w0s, lane);
+
+    for (int kk = NL - 1; kk >= 0; --kk) {
+      const bool last = (kk == NL - 1);
+      const int RL = R_LAYER(kk);
+      f32x16 ds[1];
+      {
+        f32x16 u[2], du[2], z[2], dh[2];
+        load_rows<2>(scr, RL + 6, u, lane);
+        const float ra = Wb[A.o_res[kk]], rb = Wb[A.o_res[kk] + 1];
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            acc += u[t][r] * dx[t][r];
+            du[t][r] = rb * fc * dx[t][r];
+            dx[t][r] = ra * dx[t][r];
+          }
+        dfc_part += rb * acc;
+        linear<2, 2>(Wb + A.o_lat2T[kk], du, dh, lane);
+        load_rows<2>(scr, RL + 4, z, lane);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dh[t][r] *= dsilu1(z[t][r]);
+        linear<2, 2>(Wb + A.o_lat1T[kk], dh, du, lane);
+        load_rows<2>(scr, RL + 2, z, lane);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) du[t][r] *= dsilu1(z[t][r]);
+        f32x16 dcat[3];
+        linear<2, 3>(Wb + A.o_lat0T[kk], du, dcat, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dx[0][r] += dcat[0][r]; dx[1][r] += dcat[1][r]; }
+        ds[0] = dcat[2];
+      }
+      // dVp
+      f32x16 dVp[4];
+      if (last) {
+        dVp[0] = ds[0];
+#pragma unroll
+        for (int lm = 1; lm < 4; ++lm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dVp[lm][r] = 0.f;
+      } else {
+        const float *mx = Wb + A.o_mixT[kk];
+        f32x16 in1[1], out1[1];
+        in1[0] = dV[0];
+        linear<1, 1>(mx, in1, out1, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dVp[0][r] = out1[0][r] + ds[0][r];
+#pragma unroll
+        for (int lm = 1; lm < 4; ++lm) {
+          in1[0] = dV[lm];
+          linear<1, 1>(mx + 4096, in1, out1, lane);
+          dVp[lm] = out1[0];
+        }
+      }
+      // V^{kk} (input of this layer's tensor product)
+      f32x16 Vk[4];
+      if (kk > 0) load_rows<4>(scr, RL + 8, Vk, lane);
+      else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          Vk[0][r] = w0s[0][r];
+          Vk[1][r] = w0s[1][r] * Y1; Vk[2][r] = w0s[1][r] * Y2; Vk[3][r] = w0s[1][r] * Y3;
+        }
+      }
+      // tensor-product backward: dV (w.r.t. V^{kk}) and the per-edge environment gradient
+      {
+        const float *en = lds.env[kk] + aloc * STG_LD;
+        const float *tp = Wb + A.o_tp[kk];
+        const f32x16 p0 = load_hvec(tp, h), p1 = load_hvec(tp + 32, h);
+        f32x16 p2, p3, p4;
+        if (!last) { p2 = load_hvec(tp + 64, h); p3 = load_hvec(tp + 96, h); p4 = load_hvec(tp + 128, h); }
+        float *st = lds.stage + s * STG_LD;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int fidx = feat_of(r, h);
+          const float e0v = en[fidx], e1v = en[32 + fidx], e2v = en[64 + fidx], e3v = en[96 + fidx];
+          const float v0 = Vk[0][r], v1 = Vk[1][r], v2 = Vk[2][r], v3 = Vk[3][r];
+          const float g0 = dVp[0][r];
+          const float q0 = p0[r] * g0, q1 = p1[r] * C_P1 * g0;
+          float a0v = q0 * e0v, a1v = q1 * e1v, a2v = q1 * e2v, a3v = q1 * e3v;       // dV
+          float b0v = q0 * v0, b1v = q1 * v1, b2v = q1 * v2, b3v = q1 * v3;           // denv_e
+          if (!last) {
+            const float g1 = dVp[1][r], g2 = dVp[2][r], g3 = dVp[3][r];
+            const float q2 = p2[r], q3 = p3[r], c4 = p4[r] * C_P4;
+            a0v += q2 * (e1v * g1 + e2v * g2 + e3v * g3);
+            b0v += q3 * (v1 * g1 + v2 * g2 + v3 * g3);
+            a1v += q3 * e0v * g1 + c4 * (e2v * g3 - e3v * g2);      // (e x g)_1
+            a2v += q3 * e0v * g2 + c4 * (e3v * g1 - e1v * g3);
+            a3v += q3 * e0v * g3 + c4 * (e1v * g2 - e2v * g1);
+            b1v += q2 * v0 * g1 + c4 * (g2 * v3 - g3 * v2);         // (g x v)_1
+            b2v += q2 * v0 * g2 + c4 * (g3 * v1 - g1 * v3);
+            b3v += q2 * v0 * g3 + c4 * (g1 * v2 - g2 * v1);
+          }
+          dV[0][r] = a0v; dV[1][r] = a1v; dV[2][r] = a2v; dV[3][r] = a3v;
+          st[fidx] = b0v; st[32 + fidx] = b1v; st[64 + fidx] = b2v; st[96 + fidx] = b3v;
+        }
+      }
+      __syncthreads();
+      {
+        const int fidx = tid & 127;
+        for (int a = tid >> 7; a < na; a += 2) {
+          float sum = 0.f;
+          for (int sl = lds.aoff[a]; sl < lds.aoff[a + 1]; ++sl) sum += lds.stage[sl * STG_LD + fidx];
+          lds.denv[a * STG_LD + fidx] = A.cenv * sum;
+        }
+      }
+      __syncthreads();
+      {
+        f32x16 om[2], dom[2];
+        load_rows<2>(scr, RL + 0, om, lane);
+        const float *de = lds.denv + aloc * STG_LD;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int fidx = feat_of(r, h);
+          const float d0 = de[fidx], d1 = de[32 + fidx], d2 = de[64 + fidx], d3 = de[96 + fidx];
+          dom[0][r] = d0;
+          dom[1][r] = d1 * Y1 + d2 * Y2 + d3 * Y3;
+          dY1 += d1 * om[1][r]; dY2 += d2 * om[1][r]; dY3 += d3 * om[1][r];
+        }
+        linear<2, 2, 4, true>(Wb + A.o_envT[kk], dom, dx, lane);
+      }
+      __syncthreads();          // denv / stage free for the next layer
+    }
+    // ---------------- embedding backward ----------------
+    {
+      f32x16 dw0[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        dw0[0][r] = dV[0][r];
+        dw0[1][r] = dV[1][r] * Y1 + dV[2][r] * Y2 + dV[3][r] * Y3;
+        dY1 += dV[1][r] * w0s[1][r]; dY2 += dV[2][r] * w0s[1][r]; dY3 += dV[3][r] * w0s[1][r];
+      }
+      linear<2, 2, 4, true>(Wb + A.o_embT, dw0, dx, lane);
+    }
+    // ---------------- two-body MLP backward ----------------
+    float dd_part = 0.f;
+    {
+      f32x16 u[2], du[2], z[2], dh[2];
+      load_rows<2>(scr, R_U0(), u, lane);
+      float acc = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc += u[t][r] * dx[t][r]; du[t][r] = fc * dx[t][r]; }
+      dfc_part += acc;
+      linear<2, 2>(Wb + A.o_tb_w2T, du, dh, lane);
+      load_rows<2>(scr, R_Z2TB(), z, lane);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[t][r] *= dsilu1(z[t][r]);
+      linear<2, 2>(Wb + A.o_tb_w1T, dh, du, lane);
+      load_rows<2>(scr, R_Z1TB(), z, lane);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) du[t][r] *= dsilu1(z[t][r]);
+      f32x16 dbf[1];
+      linear<2, 1>(Wb + A.o_tb_wcT, du, dbf, lane);
+      const float dfdd = dfc_dx / rc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float n = (float)(r + 4 * h + 1);
+        float sn, cs;
+        sincosf(PI * n * xx, &sn, &cs);
+        const float b = pref * sn * inv;
+        const float db = pref * (cs * PI * n / rc * inv - sn * inv * inv);
+        dd_part += dbf[0][r] * (db * fc + b * dfdd);
+      }
+    }
+    // ---------------- geometry backward, outputs ----------------
+    {
+      const float dfc_tot = dfc_part + __shfl_xor(dfc_part, 32, 64);
+      const float dd = dfc_tot * (dfc_dx / rc) + dd_part + __shfl_xor(dd_part, 32, 64);
+      const float y1 = dY1 + __shfl_xor(dY1, 32, 64), y2 = dY2 + __shfl_xor(dY2, 32, 64), y3 = dY3 + __shfl_xor(dY3, 32, 64);
+      const float Gx = C_S3 * y3, Gy = C_S3 * y1, Gz = C_S3 * y2;
+      const float gn = Gx * nx + Gy * ny + Gz * nz;
+      const float gx = dd * nx + (Gx - gn * nx) * inv;
+      const float gy = dd * ny + (Gy - gn * ny) * inv;
+      const float gz = dd * nz + (Gz - gn * nz) * inv;
+      if (h == 0) {
+        float *st = lds.stage + s * STG_LD;
+        const float m = valid ? 1.f : 0.f;
+        st[0] = m * gx; st[1] = m * gy; st[2] = m * gz; st[3] = m * eps;
+        st[4] = -m * rx * gx; st[5] = -m * ry * gy; st[6] = -m * rz * gz;
+        st[7] = -m * 0.5f * (rx * gy + ry * gx); st[8] = -m * 0.5f * (rx * gz + rz * gx); st[9] = -m * 0.5f * (ry * gz + rz * gy);
+        if (valid) {
+          atomicAdd(&A.f[3 * (size_t)jat], -(double)gx);
+          atomicAdd(&A.f[3 * (size_t)jat + 1], -(double)gy);
+          atomicAdd(&A.f[3 * (size_t)jat + 2], -(double)gz);
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < na) {
+      double sx = 0, sy = 0, sz = 0, se = 0;
+      for (int sl = lds.aoff[tid]; sl < lds.aoff[tid + 1]; ++sl) {
+        const float *st = lds.stage + sl * STG_LD;
+        sx += st[0]; sy += st[1]; sz += st[2]; se += st[3];
+      }
+      const int i = A.ilist[a0 + tid];
+      atomicAdd(&A.f[3 * (size_t)i], sx);
+      atomicAdd(&A.f[3 * (size_t)i + 1], sy);
+      atomicAdd(&A.f[3 * (size_t)i + 2], sz);
+      const int t = A.mtype[i];
+      const float ei = Wb[A.o_scale + t] * ((float)se * A.cenv) + Wb[A.o_shift + t];
+      if (A.eatom) A.eatom[i] = (double)ei;
+      lds.ea[tid] = ei;
+    } else if (tid >= 64 && tid < 70) {
+      const int c = tid - 64 + 4;
+      double sv = 0;
+      const int ne = e1 - e0;
+      for (int sl = 0; sl < ne; ++sl) sv += lds.stage[sl * STG_LD + c];
+      acc_part += sv;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double se = 0;
+      for (int a = 0; a < na; ++a) se += lds.ea[a];
+      acc_part += se;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) A.partial[7 * (size_t)blockIdx.x] = acc_part;
+  if (tid >= 64 && tid < 70) A.partial[7 * (size_t)blockIdx.x + 1 + (tid - 64)] = acc_part;
+}
+
+// ---------------------------------------------------------------------------- tile packing
+// Greedy packing of consecutive centre atoms into tiles (<= 128 edges, <= MAXA atoms), done
+// sequentially inside independent segments of SEG atoms so it parallelises.
+template <bool FILL>
+__global__ void k_pack_tiles(int inum, const int *eoff, int nseg, int *seg_count, const int *seg_base, int *tile_a0) {
+  int sg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sg >= nseg) return;
+  int a = sg * SEG, end = min(inum, a + SEG);
+  int nt = 0, cur_e = 0, cur_a = 0;
+  int base = FILL ? seg_base[sg] : 0;
+  if (FILL && a < end) tile_a0[base] = a;
+  for (int at = a; at < end; ++at) {
+    int deg = eoff[at + 1] - eoff[at];
+    if (cur_a == MAXA || cur_e + deg > TILE_SLOTS) {
+      ++nt; cur_e = 0; cur_a = 0;
+      if (FILL) tile_a0[base + nt] = at;
+    }
+    cur_e += deg; ++cur_a;
+  }
+  if (!FILL) seg_count[sg] = (a < end) ? nt + 1 : 0;
+}
+__global__ void k_pack_finish(int inum, int nseg, const int *seg_base, int *tile_a0, int *ntiles) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int n = seg_base[nseg];
+    tile_a0[n] = inum;
+    *ntiles = n;
+  }
+}
+
+// ---------------------------------------------------------------------------- host side
+struct FusedState {
+  DevBuf wbuf, scratch, seg_count, seg_base, tile_a0, ntiles, partial;
+  FusedArgs args;
+  bool ready = false;
+  int ncu = 256;
+  int grid = 256;
+};
+
+// A-operand fragments of W [K][N] (row-major, x @ W): [ot][kt][q][lane][c], r = 4q+c,
+//   value = W[32 kt + feat(r, lane>>5)][32 ot + (lane & 31)], zero padded.
+static void append_frag(std::vector<float> &out, const double *W, int K, int N, int ldw) {
+  const int KT = (K + 31) / 32, NT = (N + 31) / 32;
+  for (int ot = 0; ot < NT; ++ot)
+    for (int kt = 0; kt < KT; ++kt)
+      for (int q = 0; q < 4; ++q)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int c = 0; c < 4; ++c) {
+            int r = 4 * q + c;
+            int k = 32 * kt + feat_of(r, lane >> 5), n = 32 * ot + (lane & 31);
+            out.push_back((k < K && n < N) ? (float)W[(size_t)k * ldw + n] : 0.f);
+          }
+}
+static std::vector<double> transpose(const double *W, int K, int N) {
+  std::vector<double> t((size_t)K * N);
+  for (int k = 0; k < K; ++k)
+    for (int n = 0; n < N; ++n) t[(size_t)n * K + k] = W[(size_t)k * N + n];
+  return t;
+}
+// per-half vector [q][h][4] of v[0..32)
+static void append_hvec(std::vector<float> &out, const double *v) {
+  for (int q = 0; q < 4; ++q)
+    for (int h = 0; h < 2; ++h)
+      for (int c = 0; c < 4; ++c) out.push_back((float)v[feat_of(4 * q + c, h)]);
+}
+
+bool fused_model_supported(const Model &m, std::string *why) {
+  const HostModel &h = m.hm;
+  auto no = [&](const char *msg) { if (why) *why = msg; return false; };
+  if (h.l_max != 1) return no("fused kernels need l_max = 1");
+  if (h.U != 32 || h.S != 64 || h.mlp_width != 64 || h.readout_width != 32) return no("fused kernels need U=32, S=64, MLP width 64, read-out width 32");
+  if (h.mlp_depth != 2 || h.readout_depth != 1) return no("fused kernels need MLP depth 2 and read-out depth 1");
+  if (h.num_bessels != 8) return no("fused kernels need 8 Bessel functions");
+  if (h.num_layers < 1 || h.num_layers > MAXNL) return no("fused kernels need 1..3 layers");
+  if (h.num_types > 4) return no("fused kernels support at most 4 model types");
+  return true;
+}
+
+static void fused_prepare(Model &m) {
+  if (!m.fused_state) m.fused_state = new FusedState();
+  FusedState &st = *(FusedState *)m.fused_state;
+  if (st.ready) return;
+  const HostModel &h = m.hm;
+  const int T = h.num_types, NL = h.num_layers;
+  std::vector<float> w;
+  FusedArgs &A = st.args;
+  std::memset(&A, 0, sizeof(A));
+  auto mark = [&]() { while (w.size() % 4) w.push_back(0.f); return (int)w.size(); };
+  // two-body: pair table + Bessel block
+  {
+    const HostTensor &w0 = h.get("tb.w0");          // [2T+8][64]
+    A.o_pair = mark();
+    for (int ti = 0; ti < T; ++ti)
+      for (int tj = 0; tj < T; ++tj) {
+        std::vector<double> row(64);
+        for (int n = 0; n < 64; ++n) row[n] = w0.data[(size_t)ti * 64 + n] + w0.data[(size_t)(T + tj) * 64 + n];
+        append_hvec(w, row.data());
+        append_hvec(w, row.data() + 32);
+      }
+    const double *wc = w0.data.data() + (size_t)2 * T * 64;       // [8][64]
+    A.o_tb_wc = mark(); append_frag(w, wc, 8, 64, 64);
+    std::vector<double> wcT = transpose(wc, 8, 64);               // [64][8]
+    A.o_tb_wcT = mark(); append_frag(w, wcT.data(), 64, 8, 8);
+  }
+  auto both = [&](const std::string &name, int K, int N, int &of, int &ofT) {
+    const HostTensor &t = h.get(name);
+    of = mark(); append_frag(w, t.data.data(), K, N, N);
+    std::vector<double> tt = transpose(t.data.data(), K, N);
+    ofT = mark(); append_frag(w, tt.data(), N, K, K);
+  };
+  both("tb.w1", 64, 64, A.o_tb_w1, A.o_tb_w1T);
+  both("tb.w2", 64, 64, A.o_tb_w2, A.o_tb_w2T);
+  both("emb.w", 64, 64, A.o_emb, A.o_embT);
+  for (int k = 0; k < NL; ++k) {
+    const std::string lk = "l" + std::to_string(k + 1);
+    both(lk + ".env", 64, 64, A.o_env[k], A.o_envT[k]);
+    both(lk + ".lat.w0", 96, 64, A.o_lat0[k], A.o_lat0T[k]);
+    both(lk + ".lat.w1", 64, 64, A.o_lat1[k], A.o_lat1T[k]);
+    both(lk + ".lat.w2", 64, 64, A.o_lat2[k], A.o_lat2T[k]);
+    const HostTensor &tp = h.get(lk + ".tp");
+    A.o_tp[k] = mark();
+    for (int p = 0; p < 5; ++p) {
+      std::vector<double> row(32, 0.0);
+      if (p < tp.shape[0]) for (int u = 0; u < 32; ++u) row[u] = tp.data[(size_t)p * 32 + u];
+      append_hvec(w, row.data());
+    }
+    const HostTensor &res = h.get(lk + ".res");
+    A.o_res[k] = mark(); w.push_back((float)res.data[0]); w.push_back((float)res.data[1]);
+    if (k < NL - 1) {
+      const HostTensor &mx = h.get(lk + ".mix");           // [2][32][32]
+      A.o_mix[k] = mark();
+      for (int l = 0; l < 2; ++l) append_frag(w, mx.data.data() + (size_t)l * 1024, 32, 32, 32);
+      A.o_mixT[k] = mark();
+      for (int l = 0; l < 2; ++l) { auto t = transpose(mx.data.data() + (size_t)l * 1024, 32, 32); append_frag(w, t.data(), 32, 32, 32); }
+    }
+  }
+  both("out.w0", 64, 32, A.o_out0, A.o_out0T);
+  A.o_out1 = mark(); append_hvec(w, h.get("out.w1").data.data());
+  A.o_scale = mark(); for (int t = 0; t < T; ++t) w.push_back((float)h.get("scale").data[t]);
+  A.o_shift = mark(); for (int t = 0; t < T; ++t) w.push_back((float)h.get("shift").data[t]);
+  st.wbuf.reserve(w.size() * sizeof(float));
+  AHIP_CHECK(hipMemcpy(st.wbuf.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+  A.wbase = st.wbuf.as<float>();
+  A.T = T; A.NL = NL; A.p = h.poly_p;
+  A.cenv = (float)(1.0 / std::sqrt(h.avg_num_neighbors));
+  hipDeviceProp_t prop;
+  AHIP_CHECK(hipGetDeviceProperties(&prop, m.device));
+  st.ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  st.grid = st.ncu;
+  A.wave_scratch = (long long)R_TOTAL(NL) * ROW;
+  A.wg_scratch = 4 * A.wave_scratch;
+  st.scratch.reserve((size_t)st.grid * A.wg_scratch * sizeof(float));
+  A.scratch = st.scratch.as<float>();
+  st.partial.reserve((size_t)st.grid * 7 * sizeof(double));
+  st.ntiles.reserve(64);
+  st.ready = true;
+}
+
+bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
+  if (m.last_max_deg > TILE_SLOTS) {
+    if (why) *why = "an atom has " + std::to_string(m.last_max_deg) + " edges (> 128 per tile)";
+    return false;
+  }
+  if (m.edges_T_size != 4) { if (why) *why = "edge vectors are not float32"; return false; }
+  fused_prepare(m);
+  FusedState &st = *(FusedState *)m.fused_state;
+  hipStream_t s = a.stream;
+  const int inum = m.inum;
+  const int nseg = (inum + SEG - 1) / SEG;
+  st.seg_count.reserve((size_t)(nseg + 1) * sizeof(int));
+  st.seg_base.reserve((size_t)(nseg + 2) * sizeof(int));
+  st.tile_a0.reserve((size_t)(inum + nseg + 2) * sizeof(int));
+  {
+    StageTimer tm(m, "tile_pack", s);
+    const unsigned B = 64;
+    hipLaunchKernelGGL(k_pack_tiles<false>, dim3((nseg + B - 1) / B), dim3(B), 0, s, inum, m.b_eoff.as<int>(), nseg, st.seg_count.as<int>(), (const int *)nullptr, (int *)nullptr);
+    AHIP_CHECK(prim_exclusive_scan_i32(st.seg_count.as<int>(), st.seg_base.as<int>(), nseg, s));
+    hipLaunchKernelGGL(k_pack_tiles<true>, dim3((nseg + B - 1) / B), dim3(B), 0, s, inum, m.b_eoff.as<int>(), nseg, (int *)nullptr, st.seg_base.as<int>(), st.tile_a0.as<int>());
+    hipLaunchKernelGGL(k_pack_finish, dim3(1), dim3(1), 0, s, inum, nseg, st.seg_base.as<int>(), st.tile_a0.as<int>(), st.ntiles.as<int>());
+  }
+  FusedArgs A = st.args;
+  A.eoff = m.b_eoff.as<int>(); A.e_ii = m.b_eii.as<int>(); A.e_j = m.b_ej.as<int>();
+  A.ilist = m.d_ilist; A.mtype = a.mtype; A.rvec = m.b_rvec.as<float>(); A.rcut = m.rcut_model_dev;
+  A.tile_a0 = st.tile_a0.as<int>(); A.ntiles = st.ntiles.as<int>();
+  A.f = a.f; A.eatom = a.eatom; A.partial = st.partial.as<double>();
+  {
+    StageTimer tm(m, "model_fused", s);
+    hipLaunchKernelGGL(k_fused, dim3(st.grid), dim3(256), 0, s, A);
+  }
+  AHIP_CHECK(hipGetLastError());
+  AHIP_CHECK(prim_sum_columns_f64(st.partial.as<double>(), st.grid, 7, a.engvir, s));
+  return true;
+}
+
+void fused_free(Model &m) {
+  if (!m.fused_state) return;
+  FusedState *st = (FusedState *)m.fused_state;
+  for (DevBuf *b : {&st->wbuf, &st->scratch, &st->seg_count, &st->seg_base, &st->tile_a0, &st->ntiles, &st->partial}) b->release();
+  delete st;
+  m.fused_state = nullptr;
+}
+
+// ---------------------------------------------------------------------------- diagnostic
+// Single-wave self-test of the register-chain linear primitive: out[32][N] = in[32][K] @ W[K][N].
+template <int KT, int NT, int KQ>
+__global__ void __launch_bounds__(64) k_selftest_linear(const float *Wf, const float *in, int K, float *out, int N) {
+  const int lane = threadIdx.x, slot = lane & 31, h = lane >> 5;
+  f32x16 a[KT], o[NT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int k = 32 * t + feat_of(r, h);
+      a[t][r] = k < K ? in[slot * K + k] : 0.f;
+    }
+  linear<KT, NT, KQ>(Wf, a, o, lane);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int n = 32 * t + feat_of(r, h);
+      if (n < N) out[slot * N + n] = o[t][r];
+    }
+}
+
 }  // namespace ahip
+
+using namespace ahip;
+
+extern "C" int ahip_debug_fused_linear(int K, int N, const double *W, const float *in, float *out) {
+  try {
+    std::vector<float> frag;
+    append_frag(frag, W, K, N, N);
+    float *dW = nullptr, *din = nullptr, *dout = nullptr;
+    AHIP_CHECK(hipMalloc((void **)&dW, frag.size() * sizeof(float)));
+    AHIP_CHECK(hipMalloc((void **)&din, (size_t)32 * K * sizeof(float)));
+    AHIP_CHECK(hipMalloc((void **)&dout, (size_t)32 * N * sizeof(float)));
+    AHIP_CHECK(hipMemcpy(dW, frag.data(), frag.size() * sizeof(float), hipMemcpyHostToDevice));
+    AHIP_CHECK(hipMemcpy(din, in, (size_t)32 * K * sizeof(float), hipMemcpyHostToDevice));
+    const int KT = (K + 31) / 32, NT = (N + 31) / 32;
+    bool ok = true;
+#define CASE(kt, nt, kq) hipLaunchKernelGGL((k_selftest_linear<kt, nt, kq>), dim3(1), dim3(64), 0, 0, dW, din, K, dout, N)
+    if (K == 8 && NT == 2) CASE(1, 2, 1);
+    else if (KT == 1 && NT == 1) CASE(1, 1, 4);
+    else if (KT == 1 && NT == 2) CASE(1, 2, 4);
+    else if (KT == 2 && NT == 1) CASE(2, 1, 4);
+    else if (KT == 2 && NT == 2) CASE(2, 2, 4);
+    else if (KT == 3 && NT == 2) CASE(3, 2, 4);
+    else if (KT == 2 && NT == 3) CASE(2, 3, 4);
+    else ok = false;
+#undef CASE
+    if (ok) {
+      AHIP_CHECK(hipDeviceSynchronize());
+      AHIP_CHECK(hipMemcpy(out, dout, (size_t)32 * N * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(dW); (void)hipFree(din); (void)hipFree(dout);
+    return ok ? 0 : AHIP_ERR_UNSUPPORTED;
+  } catch (const std::exception &) { return AHIP_ERR_DEVICE; }
+}

@@ -41,23 +41,6 @@ template <typename T> static void free_weights(DeviceWeights<T> &dw) {
   dw.owned.clear(); dw.w.clear(); dw.ready = false;
 }
 
-// ---- stage timing ------------------------------------------------------------------------------
-struct StageTimer {
-  Model &m; hipStream_t s; int idx = -1;
-  StageTimer(Model &m_, const char *name, hipStream_t s_) : m(m_), s(s_) {
-    if (!m.timing) return;
-    for (size_t i = 0; i < m.slots.size(); ++i) if (m.slots[i].name == name) idx = (int)i;
-    if (idx < 0) {
-      TimingSlot t; t.name = name;
-      AHIP_CHECK(hipEventCreate(&t.a)); AHIP_CHECK(hipEventCreate(&t.b));
-      m.slots.push_back(t); idx = (int)m.slots.size() - 1;
-    }
-    m.slots[idx].used = true;
-    AHIP_CHECK(hipEventRecord(m.slots[idx].a, s));
-  }
-  ~StageTimer() { if (idx >= 0) (void)hipEventRecord(m.slots[idx].b, s); }
-};
-
 // ---- edge build: K1/K2/K5 of the reference's Kokkos path, a2-a4 of SURVEY section 8 -------------
 // After this: m.nedges, m.b_eoff (int[inum+1]), m.b_eii, m.b_ej, m.b_rvec (T[E][3]).
 template <typename T> static void build_edges(Model &m, const ComputeArgs &a) {

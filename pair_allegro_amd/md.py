@@ -235,6 +235,8 @@ class Simulation:
         for sw in reversed(self.swaps):
             buf = self.f[sw.first_recv: sw.first_recv + sw.nrecv]
             rx = self._sendrecv(buf, sw.recvrank, sw.sendrank, sw.nsend)
+            if sw.recvrank == self.rank and sw.sendrank == self.rank:
+                rx = rx.clone()                                  # self-exchange returns a view of f
             self.f.index_add_(0, sw.send_idx, rx)
 
     def needs_rebuild(self) -> bool:

@@ -32,3 +32,5 @@ bool fused_model_supported(const Model &, std::string *why) { if (why) *why = "h
 bool fused_run(Model &, const ComputeArgs &, std::string *why) { if (why) *why = "host emulation has no MFMA"; return false; }
 void fused_free(Model &) {}
 }  // namespace ahip
+
+extern "C" int ahip_debug_fused_linear(int, int, const double *, const float *, float *) { return 5; }

@@ -1,0 +1,53 @@
+"""Worker of tests/test_md_emu.py::test_world_size_2_gloo_matches_single_rank (one process per rank)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from pair_allegro_amd import capi, lmp_like, md, model_file
+
+
+def run(lib, path, cell, pos, vel, cfg, grid, rank, d, nsteps):
+    model = capi.Model(path, 0, lib)
+    sim = md.Simulation(md.HipBackend(model, [28.0855]), np.diag(cell), cfg["r_max"], 1.0, pos, np.zeros(len(pos), np.int32),
+                        vel, torch.device("cpu"), grid=grid, rank=rank, dist=d, dt=0.001)
+    sim.setup()
+    f = sim.gather_forces()
+    for _ in range(nsteps):
+        sim.step()
+    x = torch.zeros((len(pos), 3), dtype=torch.float64)
+    x[sim.tag[: sim.nlocal]] = sim.x[: sim.nlocal]
+    if d is not None and sim.nranks > 1:
+        d.all_reduce(x)
+    e = sim.thermo([28.0855])["pe"]
+    model.close()
+    return f, x.numpy(), e
+
+
+def main():
+    out, libpath, model_dir = sys.argv[1:4]
+    dist.init_process_group(backend="gloo")
+    rank = dist.get_rank()
+    lib = capi.Library(libpath)
+    cfg = model_file.model_S(model_dtype="float64", num_scalar_features=16, num_tensor_features=8, mlp_width=16,
+                             readout_width=8, avg_num_neighbors=28.0)
+    w = model_file.init_weights(cfg)
+    path = os.path.join(model_dir, f"md_small_r{rank}.ahip")
+    model_file.save_ahip(path, cfg, w)
+    cell, pos, _ = lmp_like.diamond_si(3)
+    vel = md.maxwell_boltzmann(len(pos), np.full(len(pos), 28.0855), 300.0, 12345)
+    f2, x2, e2 = run(lib, path, cell, pos, vel, cfg, (2, 1, 1), rank, dist, 3)
+    if rank == 0:
+        f1, x1, e1 = run(lib, path, cell, pos, vel, cfg, (1, 1, 1), 0, None, 3)
+        box = np.diag(cell)
+        x1 = x1 - np.floor(x1 / box) * box
+        x2 = x2 - np.floor(x2 / box) * box
+        np.savez(out, f1=f1, f2=f2, x1=x1, x2=x2, e1=e1, e2=e2)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+"""GPU tests of the fused MFMA path: the register-chain primitive, then the whole kernel against
+the float64 oracle goldens, the float32 generic path and size-independent properties."""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+import util
+from oracle import allegro_torch
+from pair_allegro_amd import cg, lmp_like, model_file
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("K,N", [(8, 64), (32, 32), (32, 64), (64, 32), (64, 64), (96, 64), (64, 96), (64, 8)])
+def test_mfma_linear_primitive(hip_lib, K, N):
+    rng = np.random.RandomState(K * 100 + N)
+    W = rng.normal(size=(K, N))                    # asymmetric: catches transposed fragments
+    x = rng.normal(size=(32, K)).astype(np.float32)
+    out = hip_lib.debug_fused_linear(W, x)
+    ref = x.astype(np.float64) @ W
+    np.testing.assert_allclose(out, ref, atol=2e-5 * np.abs(ref).max(), rtol=1e-5)
+
+
+def test_fused_golden_si64(hip_lib, model_dir):
+    res, g = pc.check_golden(hip_lib, model_dir, "Si64_r5", "float32", options={"path": "fused"})
+    assert res["info"]["path"] == "fused_f32"
+    pc.check_edges_vs_brute_force(res, g)
+
+
+def _model_S_case(model_dir, name, type_names, symbols, cell, pos, nl=2, seed=1):
+    cfg = model_file.model_S(type_names=list(type_names), num_layers=nl, seed=seed,
+                             avg_num_neighbors=float(len(util.glue.brute_force_edges(cell, pos, 5.0)[0])) / len(pos))
+    w = model_file.init_weights(cfg)
+    path = f"{model_dir}/{name}.nequip.pth"
+    allegro_torch.export_nequip_pth(path, cfg, w)
+    names = sorted(set(symbols))
+    types = np.array([names.index(s) + 1 for s in symbols], dtype=np.int32)
+    cfg64 = dict(cfg, model_dtype="float64")
+    ref = util.oracle_run(cfg64, w, cell, pos, types, names)
+    return path, cfg, types, names, ref
+
+
+@pytest.mark.parametrize("nl", [1, 2, 3])
+def test_fused_vs_oracle_two_types(hip_lib, model_dir, nl):
+    """CuPd 256-atom box (reference geometry), model-S shape with 2 types and 1..3 layers."""
+    g = util.load_golden("CuPd-cubic-big_r5")
+    path, cfg, types, names, ref = _model_S_case(model_dir, f"cupd_S_nl{nl}", ["Cu", "Pd"], g["symbols"], g["cell"], g["pos"], nl=nl)
+    fused = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused"})
+    assert fused["info"]["path"] == "fused_f32"
+    gen = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "generic"})
+    util.assert_close_to(fused, ref, 5e-4, what=f"fused vs f64 oracle nl={nl}")
+    assert np.abs(fused["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
+    np.testing.assert_allclose(fused["forces"], gen["forces"], atol=2e-5)
+
+
+def test_fused_multi_rank_and_ragged_tiles(hip_lib, model_dir):
+    """2x2x1 ranks; Cu2AgO4 (7 atoms, ragged degrees, 3 types, triclinic) exercises partial tiles."""
+    g = util.load_golden("Cu2AgO4_r5")
+    path, cfg, types, names, ref = _model_S_case(model_dir, "cu2ago4_S", ["Cu", "Ag", "O"], g["symbols"], g["cell"], g["pos"])
+    fused = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused"})
+    util.assert_close_to(fused, ref, 5e-4, what="Cu2AgO4 fused")
+    g2 = util.load_golden("CuPd-cubic-big_r5")
+    path, cfg, types, names, ref = _model_S_case(model_dir, "cupd_S_mr", ["Cu", "Pd"], g2["symbols"], g2["cell"], g2["pos"])
+    fused = util.run_pair(hip_lib, path, g2["cell"], g2["pos"], types, names, grid=(2, 2, 1), options={"path": "fused"})
+    util.assert_close_to(fused, ref, 5e-4, what="CuPd fused 2x2x1")
+
+
+def test_fused_falls_back_when_degree_exceeds_tile(hip_lib, model_dir):
+    """r_max 15 A on the 4-atom Cu cell: ~1200 edges per atom > 128 slots -> auto picks the generic path,
+    path=fused is a clean error."""
+    g = util.load_golden("Cu-cubic_r15")
+    cfg = model_file.model_S(type_names=["Cu"], r_max=15.0, avg_num_neighbors=1204.0)
+    w = model_file.init_weights(cfg)
+    path = f"{model_dir}/cu15_S.nequip.pth"
+    allegro_torch.export_nequip_pth(path, cfg, w)
+    types = np.ones(4, dtype=np.int32)
+    res = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, ["Cu"])
+    assert res["info"]["path"] == "generic_f32"
+    with pytest.raises(Exception, match="fused path unavailable"):
+        util.run_pair(hip_lib, path, g["cell"], g["pos"], types, ["Cu"], options={"path": "fused"})
+
+
+def test_full_size_properties_10k(hip_lib, model_dir):
+    """BASELINE configs[1] (10 648-atom Si) at full size through size-independent properties:
+    net force = 0 (Newton's third law), PE = sum of per-atom energies, fused == generic,
+    rigid rotation leaves energies invariant and rotates forces, translation invariance."""
+    cfg = model_file.model_S()
+    w = model_file.init_weights(cfg)
+    path = f"{model_dir}/si_S.nequip.pth"
+    allegro_torch.export_nequip_pth(path, cfg, w)
+    cell, pos, types = lmp_like.diamond_si(11)
+    a = util.run_pair(hip_lib, path, cell, pos, types, ["Si"], options={"path": "fused"})
+    b = util.run_pair(hip_lib, path, cell, pos, types, ["Si"], options={"path": "generic"})
+    assert a["info"]["path"] == "fused_f32" and b["info"]["path"] == "generic_f32"
+    assert np.abs(a["forces"].sum(0)).max() < 1e-6 * len(pos) ** 0.5
+    np.testing.assert_allclose(a["eatom"].sum(), a["pe"], rtol=1e-10)
+    assert np.abs(a["forces"] - b["forces"]).max() < 5e-5
+    np.testing.assert_allclose(a["pe"], b["pe"], rtol=1e-6)
+    np.testing.assert_allclose(a["virial"], b["virial"], atol=2e-3 * len(pos) ** 0.5, rtol=1e-4)
+    shifted = lmp_like.wrap(cell, pos + np.array([1.234, -0.77, 3.1]))
+    c = util.run_pair(hip_lib, path, cell, shifted, types, ["Si"], options={"path": "fused"})
+    np.testing.assert_allclose(c["pe"], a["pe"], rtol=1e-6)
+    assert np.abs(c["forces"] - a["forces"]).max() < 5e-5

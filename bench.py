@@ -33,7 +33,7 @@ if ROOT not in sys.path:
 SI_MASS = 28.0855
 
 # Algorithmic work per edge of model S (DESIGN.md "Roofline accounting"): MACs of every dense
-# contraction, forward; the force evaluation costs ~2x forward (input gradients only).
+# contraction, forward; the backward pass needs input gradients only, i.e. the same MAC count again.
 def model_macs_per_edge(cfg):
     T = len(cfg["type_names"]); B = cfg["num_bessels"]; S = cfg["num_scalar_features"]
     U = cfg["num_tensor_features"]; L = cfg["l_max"]; W = cfg["mlp_width"]; R = cfg["readout_width"]
@@ -132,7 +132,7 @@ def main():
         used_path = model.last_path
         # ---- roofline of the dominant kernel -------------------------------------------------
         macs_fwd = model_macs_per_edge(cfg)
-        flops_per_edge = 2.0 * macs_fwd * 3.0          # fwd + input-gradient bwd (2x fwd), 2 flop per MAC
+        flops_per_edge = 2.0 * macs_fwd * 2.0          # 2 flop per MAC x (forward + input-gradient backward)
         import ctypes as C
         ne = C.c_longlong(0)
         lib.check(lib.lib.ahip_get_edges(model.h, C.byref(ne), None, None))

@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
     f32x16 x[2];
     {
       f32x16 z[2], hh[2];
-      const float *pt = Wb + A.o_pair + (size_t)(ti * A.T + tj) * 128;
+      const float *pt = Wb + A.o_pair + (size_t)(ti * A.T + tj) * 64;
       z[0] = load_hvec(pt, h);
       z[1] = load_hvec(pt + 32, h);
       f32x16 bfin[1];
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
 #pragma unroll
         for (int lm = 1; lm < 4; ++lm) {
           in1[0] = Vp[lm];
-          linear<1, 1>(mx + 4096, in1, out1, lane);
+          linear<1, 1>(mx + 1024, in1, out1, lane);
           V[lm] = out1[0];
         }
       }
@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
 #pragma unroll
         for (int lm = 1; lm < 4; ++lm) {
           in1[0] = dV[lm];
-          linear<1, 1>(mx + 4096, in1, out1, lane);
+          linear<1, 1>(mx + 1024, in1, out1, lane);
           dVp[lm] = out1[0];
         }
       }

@@ -37,7 +37,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static constexpr int TILE_SLOTS = 128;
 static constexpr int MAXA = 16;          // centre atoms per tile
 static constexpr int MAXNL = 3;
-static constexpr int STG_LD = 129;       // staging leading dimension (odd -> conflict-free)
+static constexpr int STG_LD = 65;        // staging leading dimension: 64 features per pass (odd -> conflict-free)
+static constexpr int ENV_LD = 129;       // per-atom environment row
 static constexpr int SEG = 512;          // atoms per sequential packing segment
 static constexpr int ROW = 1024;         // floats per saved register image (16 regs x 64 lanes)
 
@@ -54,6 +55,7 @@ struct FusedArgs {
   const int *tile_a0, *ntiles;
   // weights (offsets in floats into wbase)
   const float *wbase;
+  int wbytes;
   int o_pair, o_tb_wc, o_tb_w1, o_tb_w2, o_emb, o_out0, o_out1, o_scale, o_shift;
   int o_tb_wcT, o_tb_w1T, o_tb_w2T, o_embT, o_out0T;
   int o_env[MAXNL], o_lat0[MAXNL], o_lat1[MAXNL], o_lat2[MAXNL], o_mix[MAXNL], o_tp[MAXNL], o_res[MAXNL];
@@ -67,43 +69,63 @@ struct FusedArgs {
 
 struct __attribute__((aligned(16))) Lds {
   float stage[TILE_SLOTS * STG_LD];
-  float env[MAXNL][MAXA * STG_LD];
-  float denv[MAXA * STG_LD];
+  float env[MAXNL][MAXA * ENV_LD];
+  float denv[MAXA * ENV_LD];
   float ea[MAXA];
   int aoff[MAXA + 2];
 };
 
 // ---------------------------------------------------------------------------- device helpers
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// out[NT] (+)= W-tiles x in[KT].  Fragment layout: [ot][kt][q][lane][4], r = 4 q + c.
-template <int KT, int NT, int KQ_LAST = 4, bool ACC = false>
-__device__ __forceinline__ void linear(const float *__restrict__ Wf, const f32x16 (&in)[KT], f32x16 (&out)[NT], int lane) {
+// 16-byte buffer accesses: wave-uniform descriptor + scalar byte offset + per-lane byte offset
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, int voff, int soff, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+
+// out[NT] (+)= W-tiles x in[KT].  Fragment layout: [ot][kt][q][lane][4], r = 4 q + c;
+// wo = offset of the fragment block in floats (wave-uniform), v16 = lane * 16.
+// The MFMA chain is serial (64-cycle issue = latency), so the only thing to hide is the weight
+// fragment latency: a PF-deep register ring keeps PF fragment loads (PF x 256 MFMA cycles) in
+// flight; sched_barrier pins the load -> 4 MFMA order so the compiler cannot sink the loads back
+// next to their use (it did: every load was followed by s_waitcnt vmcnt(0)).
+template <int KT, int NT, int KQ_LAST = 4, bool ACC = false, int PF = 4>
+__device__ __forceinline__ void linear(__amdgpu_buffer_rsrc_t W, int wo, const f32x16 (&in)[KT], f32x16 (&out)[NT], int v16) {
+  constexpr int SPO = (KT - 1) * 4 + KQ_LAST;       // 4-MFMA steps per output tile
+  constexpr int NS = NT * SPO;
+  f32x4 ring[PF];
 #pragma unroll
-  for (int ot = 0; ot < NT; ++ot) {
-    f32x16 acc;
-    if (ACC) acc = out[ot];
-    else {
+  for (int i = 0; i < PF; ++i)
+    if (i < NS) ring[i] = bload(W, v16, (wo + (((i / SPO) * KT + (i % SPO) / 4) * 4 + (i % SPO) % 4) * 256) * 4);
+  f32x16 acc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    }
+  for (int i = 0; i < NS; ++i) {
+    const int ot = i / SPO, j = i % SPO, kt = j / 4, q = j % 4;
+    if (j == 0) {
+      if (ACC) acc = out[ot];
+      else {
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      const int nq = (kt == KT - 1) ? KQ_LAST : 4;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (q < nq) {
-          const f32x4 a = *(const f32x4 *)(Wf + ((((ot * KT + kt) * 4 + q) * 64 + lane) << 2));
-          acc = mfma(a.x, in[kt][4 * q + 0], acc);
-          acc = mfma(a.y, in[kt][4 * q + 1], acc);
-          acc = mfma(a.z, in[kt][4 * q + 2], acc);
-          acc = mfma(a.w, in[kt][4 * q + 3], acc);
-        }
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       }
     }
-    out[ot] = acc;
+    const f32x4 a = ring[i % PF];
+    if (i + PF < NS) {
+      const int n = i + PF;
+      ring[i % PF] = bload(W, v16, (wo + (((n / SPO) * KT + (n % SPO) / 4) * 4 + (n % SPO) % 4) * 256) * 4);
+    }
+    acc = mfma(a.x, in[kt][4 * q + 0], acc);
+    acc = mfma(a.y, in[kt][4 * q + 1], acc);
+    acc = mfma(a.z, in[kt][4 * q + 2], acc);
+    acc = mfma(a.w, in[kt][4 * q + 3], acc);
+    if (j == SPO - 1) out[ot] = acc;
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -114,38 +136,55 @@ __device__ __forceinline__ float dsilu1(float z) {
   return s * (1.f + z * (1.f - s));
 }
 
-template <int NT> __device__ __forceinline__ void silu_tiles(const f32x16 (&z)[NT], f32x16 (&h)[NT]) {
+template <int NT> __device__ __forceinline__ void silu_inplace(f32x16 (&z)[NT]) {
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) h[t][r] = silu1(z[t][r]);
+    for (int r = 0; r < 16; ++r) z[t][r] = silu1(z[t][r]);
 }
 
-template <int NT> __device__ __forceinline__ void save_rows(float *scr, int row0, const f32x16 (&v)[NT], int lane) {
+// saved register images: row = 16 regs x 64 lanes, layout [q][lane][4]
+template <int NT> __device__ __forceinline__ void save_rows(__amdgpu_buffer_rsrc_t S, int row0, const f32x16 (&v)[NT], int v16) {
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       f32x4 x = {v[t][4 * q], v[t][4 * q + 1], v[t][4 * q + 2], v[t][4 * q + 3]};
-      *(f32x4 *)(scr + (size_t)(row0 + t) * ROW + ((q * 64 + lane) << 2)) = x;
+      bstore(S, v16, ((row0 + t) * ROW + q * 256) * 4, x);
     }
 }
-template <int NT> __device__ __forceinline__ void load_rows(const float *scr, int row0, f32x16 (&v)[NT], int lane) {
+template <int NT> __device__ __forceinline__ void load_rows(__amdgpu_buffer_rsrc_t S, int row0, f32x16 (&v)[NT], int v16) {
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      f32x4 x = *(const f32x4 *)(scr + (size_t)(row0 + t) * ROW + ((q * 64 + lane) << 2));
+      f32x4 x = bload(S, v16, ((row0 + t) * ROW + q * 256) * 4);
       v[t][4 * q] = x.x; v[t][4 * q + 1] = x.y; v[t][4 * q + 2] = x.z; v[t][4 * q + 3] = x.w;
     }
 }
+__device__ __forceinline__ f32x4 rowq(__amdgpu_buffer_rsrc_t S, int row, int q, int v16) {
+  return bload(S, v16, (row * ROW + q * 256) * 4);
+}
+__device__ __forceinline__ f32x4 hvecq(__amdgpu_buffer_rsrc_t W, int wo, int q, int h16) {
+  return bload(W, h16, (wo + q * 8) * 4);
+}
+// z *= silu'(saved row)
+template <int NT> __device__ __forceinline__ void mul_dsilu_rows(__amdgpu_buffer_rsrc_t S, int row0, f32x16 (&d)[NT], int v16) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 z = bload(S, v16, ((row0 + t) * ROW + q * 256) * 4);
+      d[t][4 * q] *= dsilu1(z.x); d[t][4 * q + 1] *= dsilu1(z.y); d[t][4 * q + 2] *= dsilu1(z.z); d[t][4 * q + 3] *= dsilu1(z.w);
+    }
+}
 
-// per-half small vectors stored as [q][h][4]
-__device__ __forceinline__ f32x16 load_hvec(const float *__restrict__ p, int h) {
+// per-half small vectors stored as [q][h][4]; h16 = h * 16 bytes
+__device__ __forceinline__ f32x16 load_hvec(__amdgpu_buffer_rsrc_t W, int wo, int h16) {
   f32x16 v;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    f32x4 x = *(const f32x4 *)(p + ((q * 2 + h) << 2));
+    f32x4 x = bload(W, h16, (wo + q * 8) * 4);
     v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
   }
   return v;
@@ -161,23 +200,42 @@ __device__ __forceinline__ void cutoff_poly(int p, float x, float &f, float &df)
   df = -a * p * xp1 + b * (p + 1) * xp - c * (p + 2) * xp * x;
 }
 
-// scratch row map
+// scratch row map (per wave)
 __device__ __host__ constexpr int R_Z1TB() { return 0; }
 __device__ __host__ constexpr int R_Z2TB() { return 2; }
 __device__ __host__ constexpr int R_U0() { return 4; }
 __device__ __host__ constexpr int R_W0() { return 6; }
-__device__ __host__ constexpr int R_LAYER(int kk) { return 8 + 14 * kk; }      // OM 2, Z1 2, Z2 2, U 2, VPREV 4, spare 2
-__device__ __host__ constexpr int R_TOTAL(int NL) { return 8 + 14 * NL; }
+__device__ __host__ constexpr int R_DV() { return 8; }                          // parked dV (4 rows)
+__device__ __host__ constexpr int R_LAYER(int kk) { return 12 + 12 * kk; }      // OM 2, Z1 2, Z2 2, U 2, VIN 4
+__device__ __host__ constexpr int R_TOTAL(int NL) { return 12 + 12 * NL; }
 
 static constexpr float C_S3 = 1.7320508075688772f;
 static constexpr float C_P1 = 0.5773502691896258f;     // (1,1,0): sqrt(1) * w3j = 1/sqrt(3)
 static constexpr float C_P4 = 0.7071067811865476f;     // (1,1,1): sqrt(3) * w3j = eps_ijk / sqrt(2)
 
+// Per-centre sum of the staged half (64 features) into dst[a][half*64 + f], scaled.
+__device__ __forceinline__ void reduce_half(const Lds &lds, float *dst, int half, int na, float scale, int tid) {
+  const int fidx = tid & 63;
+  for (int a = tid >> 6; a < na; a += 4) {
+    float sum = 0.f;
+    for (int sl = lds.aoff[a]; sl < lds.aoff[a + 1]; ++sl) sum += lds.stage[sl * STG_LD + fidx];
+    dst[a * ENV_LD + half * 64 + fidx] = scale * sum;
+  }
+}
+
 // ---------------------------------------------------------------------------- the kernel
-__global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
+__global__ void __launch_bounds__(256, 2) k_fused(FusedArgs A) {
   __shared__ Lds lds;
   const int tid = threadIdx.x, lane = tid & 63, slot = lane & 31, h = lane >> 5, wave = tid >> 6;
-  float *scr = A.scratch + (size_t)blockIdx.x * A.wg_scratch + (size_t)wave * A.wave_scratch;
+  const int v16 = lane * 16, h16 = h * 16;
+  // wave-uniform buffer descriptors (made provably uniform with readfirstlane)
+  __amdgpu_buffer_rsrc_t SB, WB;
+  {
+    unsigned long long b = (unsigned long long)(A.scratch + (size_t)blockIdx.x * A.wg_scratch + (size_t)wave * A.wave_scratch);
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    SB = __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, (int)(A.wave_scratch * 4), 0x00020000);
+    WB = __builtin_amdgcn_make_buffer_rsrc((void *)A.wbase, 0, A.wbytes, 0x00020000);
+  }
   const float *__restrict__ Wb = A.wbase;
   const int ntiles = *A.ntiles;
   const int NL = A.NL;
@@ -191,6 +249,7 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
     const int s = wave * 32 + slot;
     const int e = e0 + s;
     const bool valid = e < e1;
+    float *const st = lds.stage + s * STG_LD;
 
     // ---------------- geometry ----------------
     float rx = 1.f, ry = 0.f, rz = 0.f;
@@ -214,14 +273,24 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
     const float Y1 = C_S3 * ny, Y2 = C_S3 * nz, Y3 = C_S3 * nx;
     const float pref = 2.f / rc;
     const float PI = 3.14159265358979323846f;
+    const float *const envrow = lds.env[0] + aloc * ENV_LD;        // + kk * MAXA*ENV_LD
+    const float *const denvrow = lds.denv + aloc * ENV_LD;
 
     // ---------------- two-body MLP ----------------
     f32x16 x[2];
     {
-      f32x16 z[2], hh[2];
-      const float *pt = Wb + A.o_pair + (size_t)(ti * A.T + tj) * 64;
-      z[0] = load_hvec(pt, h);
-      z[1] = load_hvec(pt + 32, h);
+      f32x16 z[2];
+      {
+        // per-type-pair rows: the fragment block is wave-uniform only per pair, so use per-lane offsets
+        const float *pt = Wb + A.o_pair + (size_t)(ti * A.T + tj) * 64;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v = *(const f32x4 *)(pt + t * 32 + (q * 2 + h) * 4);
+            z[t][4 * q] = v.x; z[t][4 * q + 1] = v.y; z[t][4 * q + 2] = v.z; z[t][4 * q + 3] = v.w;
+          }
+      }
       f32x16 bfin[1];
 #pragma unroll
       for (int r = 0; r < 16; ++r) bfin[0][r] = 0.f;
@@ -230,30 +299,25 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
         const float n = (float)(r + 4 * h + 1);
         bfin[0][r] = pref * sinf(PI * n * xx) * inv * fc;
       }
-      linear<1, 2, 1, true>(Wb + A.o_tb_wc, bfin, z, lane);
-      save_rows<2>(scr, R_Z1TB(), z, lane);
-      silu_tiles<2>(z, hh);
-      linear<2, 2>(Wb + A.o_tb_w1, hh, z, lane);
-      save_rows<2>(scr, R_Z2TB(), z, lane);
-      silu_tiles<2>(z, hh);
-      linear<2, 2>(Wb + A.o_tb_w2, hh, z, lane);
-      save_rows<2>(scr, R_U0(), z, lane);
+      linear<1, 2, 1, true>(WB, A.o_tb_wc, bfin, z, v16);
+      save_rows<2>(SB, R_Z1TB(), z, v16);
+      silu_inplace<2>(z);
+      f32x16 z2[2];
+      linear<2, 2>(WB, A.o_tb_w1, z, z2, v16);
+      save_rows<2>(SB, R_Z2TB(), z2, v16);
+      silu_inplace<2>(z2);
+      linear<2, 2>(WB, A.o_tb_w2, z2, z, v16);
+      save_rows<2>(SB, R_U0(), z, v16);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[t][r] = fc * z[t][r];
     }
-    // ---------------- tensor embedding ----------------
-    f32x16 V[4];
+    // ---------------- tensor embedding weights (V^0 = w0 (x) Y is rebuilt where needed) -------------
     {
       f32x16 w0[2];
-      linear<2, 2>(Wb + A.o_emb, x, w0, lane);
-      save_rows<2>(scr, R_W0(), w0, lane);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        V[0][r] = w0[0][r];
-        V[1][r] = w0[1][r] * Y1; V[2][r] = w0[1][r] * Y2; V[3][r] = w0[1][r] * Y3;
-      }
+      linear<2, 2>(WB, A.o_emb, x, w0, v16);
+      save_rows<2>(SB, R_W0(), w0, v16);
     }
     __syncthreads();          // aoff visible; previous tile's LDS users done
 
@@ -261,90 +325,100 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
     for (int kk = 0; kk < NL; ++kk) {
       const bool last = (kk == NL - 1);
       const int RL = R_LAYER(kk);
-      f32x16 om[2];
-      linear<2, 2>(Wb + A.o_env[kk], x, om, lane);
-      save_rows<2>(scr, RL + 0, om, lane);
+      float *const envk = lds.env[0] + kk * (MAXA * ENV_LD);
       {
-        float *st = lds.stage + s * STG_LD;
+        f32x16 om[2];
+        linear<2, 2>(WB, A.o_env[kk], x, om, v16);
+        save_rows<2>(SB, RL + 0, om, v16);
+        // environment sum, two staged halves of 64 features
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int fidx = feat_of(r, h);
           st[fidx] = om[0][r];
           st[32 + fidx] = om[1][r] * Y1;
-          st[64 + fidx] = om[1][r] * Y2;
-          st[96 + fidx] = om[1][r] * Y3;
         }
-      }
-      __syncthreads();
-      {
-        const int fidx = tid & 127;
-        for (int a = tid >> 7; a < na; a += 2) {
-          float sum = 0.f;
-          for (int sl = lds.aoff[a]; sl < lds.aoff[a + 1]; ++sl) sum += lds.stage[sl * STG_LD + fidx];
-          lds.env[kk][a * STG_LD + fidx] = A.cenv * sum;
-        }
-      }
-      __syncthreads();
-      if (kk > 0) save_rows<4>(scr, RL + 8, V, lane);
-      // tensor product
-      f32x16 Vp[4];
-      {
-        const float *en = lds.env[kk] + aloc * STG_LD;
-        const float *tp = Wb + A.o_tp[kk];
-        const f32x16 p0 = load_hvec(tp, h), p1 = load_hvec(tp + 32, h);
-        f32x16 p2, p3, p4;
-        if (!last) { p2 = load_hvec(tp + 64, h); p3 = load_hvec(tp + 96, h); p4 = load_hvec(tp + 128, h); }
+        __syncthreads();
+        reduce_half(lds, envk, 0, na, A.cenv, tid);
+        __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int fidx = feat_of(r, h);
-          const float e0v = en[fidx], e1v = en[32 + fidx], e2v = en[64 + fidx], e3v = en[96 + fidx];
-          const float v0 = V[0][r], v1 = V[1][r], v2 = V[2][r], v3 = V[3][r];
-          Vp[0][r] = p0[r] * v0 * e0v + p1[r] * C_P1 * (v1 * e1v + v2 * e2v + v3 * e3v);
-          if (!last) {
-            const float c4 = p4[r] * C_P4;
-            Vp[1][r] = p2[r] * v0 * e1v + p3[r] * v1 * e0v + c4 * (v2 * e3v - v3 * e2v);
-            Vp[2][r] = p2[r] * v0 * e2v + p3[r] * v2 * e0v + c4 * (v3 * e1v - v1 * e3v);
-            Vp[3][r] = p2[r] * v0 * e3v + p3[r] * v3 * e0v + c4 * (v1 * e2v - v2 * e1v);
+          st[fidx] = om[1][r] * Y2;
+          st[32 + fidx] = om[1][r] * Y3;
+        }
+        __syncthreads();
+        reduce_half(lds, envk, 1, na, A.cenv, tid);
+        __syncthreads();
+      }
+      // tensor product (V^{kk} and the path weights are streamed 4 registers at a time)
+      f32x16 Vp[4];
+      {
+        const float *en = envrow + kk * (MAXA * ENV_LD);
+        const int tpo = A.o_tp[kk];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 V0, V1, V2, V3;
+          if (kk > 0) {
+            V0 = rowq(SB, RL + 8, q, v16); V1 = rowq(SB, RL + 9, q, v16); V2 = rowq(SB, RL + 10, q, v16); V3 = rowq(SB, RL + 11, q, v16);
+          } else {
+            V0 = rowq(SB, R_W0(), q, v16);
+            const f32x4 w1 = rowq(SB, R_W0() + 1, q, v16);
+            V1 = w1 * Y1; V2 = w1 * Y2; V3 = w1 * Y3;
           }
+          const f32x4 p0 = hvecq(WB, tpo, q, h16), p1 = hvecq(WB, tpo + 32, q, h16);
+          f32x4 p2, p3, p4;
+          if (!last) { p2 = hvecq(WB, tpo + 64, q, h16); p3 = hvecq(WB, tpo + 96, q, h16); p4 = hvecq(WB, tpo + 128, q, h16); }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int r = 4 * q + c;
+            const int fidx = feat_of(r, h);
+            const float e0v = en[fidx], e1v = en[32 + fidx], e2v = en[64 + fidx], e3v = en[96 + fidx];
+            const float v0 = V0[c], v1 = V1[c], v2 = V2[c], v3 = V3[c];
+            Vp[0][r] = p0[c] * v0 * e0v + p1[c] * C_P1 * (v1 * e1v + v2 * e2v + v3 * e3v);
+            if (!last) {
+              const float c4 = p4[c] * C_P4;
+              Vp[1][r] = p2[c] * v0 * e1v + p3[c] * v1 * e0v + c4 * (v2 * e3v - v3 * e2v);
+              Vp[2][r] = p2[c] * v0 * e2v + p3[c] * v2 * e0v + c4 * (v3 * e1v - v1 * e3v);
+              Vp[3][r] = p2[c] * v0 * e3v + p3[c] * v3 * e0v + c4 * (v1 * e2v - v2 * e1v);
+            }
+          }
+        }
+      }
+      // channel mixing -> V^{kk+1}, parked in the next layer's VIN rows
+      if (!last) {
+        const int mx = A.o_mix[kk];
+        f32x16 in1[1], out1[1];
+#pragma unroll
+        for (int lm = 0; lm < 4; ++lm) {
+          in1[0] = Vp[lm];
+          linear<1, 1>(WB, lm == 0 ? mx : mx + 1024, in1, out1, v16);
+          save_rows<1>(SB, R_LAYER(kk + 1) + 8 + lm, out1, v16);
         }
       }
       // latent MLP
       {
-        f32x16 cat[3], z[2], hh[2];
+        f32x16 cat[3], z[2], z2[2];
         cat[0] = x[0]; cat[1] = x[1]; cat[2] = Vp[0];
-        linear<3, 2>(Wb + A.o_lat0[kk], cat, z, lane);
-        save_rows<2>(scr, RL + 2, z, lane);
-        silu_tiles<2>(z, hh);
-        linear<2, 2>(Wb + A.o_lat1[kk], hh, z, lane);
-        save_rows<2>(scr, RL + 4, z, lane);
-        silu_tiles<2>(z, hh);
-        linear<2, 2>(Wb + A.o_lat2[kk], hh, z, lane);
-        save_rows<2>(scr, RL + 6, z, lane);
+        linear<3, 2>(WB, A.o_lat0[kk], cat, z, v16);
+        save_rows<2>(SB, RL + 2, z, v16);
+        silu_inplace<2>(z);
+        linear<2, 2>(WB, A.o_lat1[kk], z, z2, v16);
+        save_rows<2>(SB, RL + 4, z2, v16);
+        silu_inplace<2>(z2);
+        linear<2, 2>(WB, A.o_lat2[kk], z2, z, v16);
+        save_rows<2>(SB, RL + 6, z, v16);
         const float ra = Wb[A.o_res[kk]], rb = Wb[A.o_res[kk] + 1] * fc;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r) x[t][r] = ra * x[t][r] + rb * z[t][r];
       }
-      if (!last) {
-        const float *mx = Wb + A.o_mix[kk];
-        f32x16 in1[1], out1[1];
-        in1[0] = Vp[0];
-        linear<1, 1>(mx, in1, out1, lane);
-        V[0] = out1[0];
-#pragma unroll
-        for (int lm = 1; lm < 4; ++lm) {
-          in1[0] = Vp[lm];
-          linear<1, 1>(mx + 1024, in1, out1, lane);
-          V[lm] = out1[0];
-        }
-      }
     }
 
     // ---------------- read-out ----------------
     f32x16 zr[1];
-    linear<2, 1>(Wb + A.o_out0, x, zr, lane);
-    const f32x16 wo1 = load_hvec(Wb + A.o_out1, h);
+    linear<2, 1>(WB, A.o_out0, x, zr, v16);
+    const f32x16 wo1 = load_hvec(WB, A.o_out1, h16);
     float eps = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) eps += silu1(zr[0][r]) * wo1[r];
@@ -357,180 +431,168 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
       f32x16 dzr[1];
 #pragma unroll
       for (int r = 0; r < 16; ++r) dzr[0][r] = deps * wo1[r] * dsilu1(zr[0][r]);
-      linear<1, 2>(Wb + A.o_out0T, dzr, dx, lane);
+      linear<1, 2>(WB, A.o_out0T, dzr, dx, v16);
     }
     float dfc_part = 0.f, dY1 = 0.f, dY2 = 0.f, dY3 = 0.f;
-    f32x16 dV[4];
-#pragma unroll
-    for (int lm = 0; lm < 4; ++lm)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dV[lm][r] = 0.f;
-    f32x16 w0s[2];            // w0 (needed for V0 recompute and the embedding backward)
-    load_rows<2>(scr, R_W0(), w0s, lane);
 
     for (int kk = NL - 1; kk >= 0; --kk) {
       const bool last = (kk == NL - 1);
       const int RL = R_LAYER(kk);
-      f32x16 ds[1];
+      f32x16 dVp[4];
       {
-        f32x16 u[2], du[2], z[2], dh[2];
-        load_rows<2>(scr, RL + 6, u, lane);
-        const float ra = Wb[A.o_res[kk]], rb = Wb[A.o_res[kk] + 1];
-        float acc = 0.f;
+        f32x16 du[2], dh[2];
+        {
+          const float ra = Wb[A.o_res[kk]], rb = Wb[A.o_res[kk] + 1];
+          float acc = 0.f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+          for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            acc += u[t][r] * dx[t][r];
-            du[t][r] = rb * fc * dx[t][r];
-            dx[t][r] = ra * dx[t][r];
-          }
-        dfc_part += rb * acc;
-        linear<2, 2>(Wb + A.o_lat2T[kk], du, dh, lane);
-        load_rows<2>(scr, RL + 4, z, lane);
+            for (int q = 0; q < 4; ++q) {
+              f32x4 u = bload(SB, v16, ((RL + 6 + t) * ROW + q * 256) * 4);
+              const float uu[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) dh[t][r] *= dsilu1(z[t][r]);
-        linear<2, 2>(Wb + A.o_lat1T[kk], dh, du, lane);
-        load_rows<2>(scr, RL + 2, z, lane);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) du[t][r] *= dsilu1(z[t][r]);
+              for (int c = 0; c < 4; ++c) {
+                const int r = 4 * q + c;
+                acc += uu[c] * dx[t][r];
+                du[t][r] = rb * fc * dx[t][r];
+                dx[t][r] = ra * dx[t][r];
+              }
+            }
+          dfc_part += rb * acc;
+        }
+        linear<2, 2>(WB, A.o_lat2T[kk], du, dh, v16);
+        mul_dsilu_rows<2>(SB, RL + 4, dh, v16);
+        linear<2, 2>(WB, A.o_lat1T[kk], dh, du, v16);
+        mul_dsilu_rows<2>(SB, RL + 2, du, v16);
         f32x16 dcat[3];
-        linear<2, 3>(Wb + A.o_lat0T[kk], du, dcat, lane);
+        linear<2, 3>(WB, A.o_lat0T[kk], du, dcat, v16);
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dx[0][r] += dcat[0][r]; dx[1][r] += dcat[1][r]; }
-        ds[0] = dcat[2];
+        dVp[0] = dcat[2];                                   // ds
       }
-      // dVp
-      f32x16 dVp[4];
-      if (last) {
-        dVp[0] = ds[0];
-#pragma unroll
-        for (int lm = 1; lm < 4; ++lm)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) dVp[lm][r] = 0.f;
-      } else {
-        const float *mx = Wb + A.o_mixT[kk];
+      if (!last) {
+        const int mx = A.o_mixT[kk];
         f32x16 in1[1], out1[1];
-        in1[0] = dV[0];
-        linear<1, 1>(mx, in1, out1, lane);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dVp[0][r] = out1[0][r] + ds[0][r];
+        for (int lm = 0; lm < 4; ++lm) {
+          load_rows<1>(SB, R_DV() + lm, in1, v16);
+          linear<1, 1>(WB, lm == 0 ? mx : mx + 1024, in1, out1, v16);
+          if (lm == 0) {
 #pragma unroll
-        for (int lm = 1; lm < 4; ++lm) {
-          in1[0] = dV[lm];
-          linear<1, 1>(mx + 1024, in1, out1, lane);
-          dVp[lm] = out1[0];
+            for (int r = 0; r < 16; ++r) dVp[0][r] += out1[0][r];
+          } else dVp[lm] = out1[0];
         }
       }
-      // V^{kk} (input of this layer's tensor product)
-      f32x16 Vk[4];
-      if (kk > 0) load_rows<4>(scr, RL + 8, Vk, lane);
-      else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          Vk[0][r] = w0s[0][r];
-          Vk[1][r] = w0s[1][r] * Y1; Vk[2][r] = w0s[1][r] * Y2; Vk[3][r] = w0s[1][r] * Y3;
-        }
-      }
-      // tensor-product backward: dV (w.r.t. V^{kk}) and the per-edge environment gradient
+      // tensor-product backward: dV (w.r.t. V^{kk}, parked) and the per-edge environment gradient
       {
-        const float *en = lds.env[kk] + aloc * STG_LD;
-        const float *tp = Wb + A.o_tp[kk];
-        const f32x16 p0 = load_hvec(tp, h), p1 = load_hvec(tp + 32, h);
-        f32x16 p2, p3, p4;
-        if (!last) { p2 = load_hvec(tp + 64, h); p3 = load_hvec(tp + 96, h); p4 = load_hvec(tp + 128, h); }
-        float *st = lds.stage + s * STG_LD;
+        const float *en = envrow + kk * (MAXA * ENV_LD);
+        const int tpo = A.o_tp[kk];
+        f32x16 b2s, b3s;                 // second staged half
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 V0, V1, V2, V3;
+          if (kk > 0) {
+            V0 = rowq(SB, RL + 8, q, v16); V1 = rowq(SB, RL + 9, q, v16); V2 = rowq(SB, RL + 10, q, v16); V3 = rowq(SB, RL + 11, q, v16);
+          } else {
+            V0 = rowq(SB, R_W0(), q, v16);
+            const f32x4 w1 = rowq(SB, R_W0() + 1, q, v16);
+            V1 = w1 * Y1; V2 = w1 * Y2; V3 = w1 * Y3;
+          }
+          const f32x4 p0 = hvecq(WB, tpo, q, h16), p1 = hvecq(WB, tpo + 32, q, h16);
+          f32x4 p2, p3, p4;
+          if (!last) { p2 = hvecq(WB, tpo + 64, q, h16); p3 = hvecq(WB, tpo + 96, q, h16); p4 = hvecq(WB, tpo + 128, q, h16); }
+          f32x4 o0, o1, o2, o3;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int r = 4 * q + c;
+            const int fidx = feat_of(r, h);
+            const float e0v = en[fidx], e1v = en[32 + fidx], e2v = en[64 + fidx], e3v = en[96 + fidx];
+            const float v0 = V0[c], v1 = V1[c], v2 = V2[c], v3 = V3[c];
+            const float g0 = dVp[0][r];
+            const float q0 = p0[c] * g0, q1 = p1[c] * C_P1 * g0;
+            float a0v = q0 * e0v, a1v = q1 * e1v, a2v = q1 * e2v, a3v = q1 * e3v;       // dV
+            float b0v = q0 * v0, b1v = q1 * v1, b2v = q1 * v2, b3v = q1 * v3;           // denv_e
+            if (!last) {
+              const float g1 = dVp[1][r], g2 = dVp[2][r], g3 = dVp[3][r];
+              const float q2 = p2[c], q3 = p3[c], c4 = p4[c] * C_P4;
+              a0v += q2 * (e1v * g1 + e2v * g2 + e3v * g3);
+              b0v += q3 * (v1 * g1 + v2 * g2 + v3 * g3);
+              a1v += q3 * e0v * g1 + c4 * (e2v * g3 - e3v * g2);      // (e x g)_1
+              a2v += q3 * e0v * g2 + c4 * (e3v * g1 - e1v * g3);
+              a3v += q3 * e0v * g3 + c4 * (e1v * g2 - e2v * g1);
+              b1v += q2 * v0 * g1 + c4 * (g2 * v3 - g3 * v2);         // (g x v)_1
+              b2v += q2 * v0 * g2 + c4 * (g3 * v1 - g1 * v3);
+              b3v += q2 * v0 * g3 + c4 * (g1 * v2 - g2 * v1);
+            }
+            o0[c] = a0v; o1[c] = a1v; o2[c] = a2v; o3[c] = a3v;
+            st[fidx] = b0v; st[32 + fidx] = b1v;
+            b2s[r] = b2v; b3s[r] = b3v;
+          }
+          bstore(SB, v16, ((R_DV() + 0) * ROW + q * 256) * 4, o0);
+          bstore(SB, v16, ((R_DV() + 1) * ROW + q * 256) * 4, o1);
+          bstore(SB, v16, ((R_DV() + 2) * ROW + q * 256) * 4, o2);
+          bstore(SB, v16, ((R_DV() + 3) * ROW + q * 256) * 4, o3);
+        }
+        __syncthreads();
+        reduce_half(lds, lds.denv, 0, na, A.cenv, tid);
+        __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int fidx = feat_of(r, h);
-          const float e0v = en[fidx], e1v = en[32 + fidx], e2v = en[64 + fidx], e3v = en[96 + fidx];
-          const float v0 = Vk[0][r], v1 = Vk[1][r], v2 = Vk[2][r], v3 = Vk[3][r];
-          const float g0 = dVp[0][r];
-          const float q0 = p0[r] * g0, q1 = p1[r] * C_P1 * g0;
-          float a0v = q0 * e0v, a1v = q1 * e1v, a2v = q1 * e2v, a3v = q1 * e3v;       // dV
-          float b0v = q0 * v0, b1v = q1 * v1, b2v = q1 * v2, b3v = q1 * v3;           // denv_e
-          if (!last) {
-            const float g1 = dVp[1][r], g2 = dVp[2][r], g3 = dVp[3][r];
-            const float q2 = p2[r], q3 = p3[r], c4 = p4[r] * C_P4;
-            a0v += q2 * (e1v * g1 + e2v * g2 + e3v * g3);
-            b0v += q3 * (v1 * g1 + v2 * g2 + v3 * g3);
-            a1v += q3 * e0v * g1 + c4 * (e2v * g3 - e3v * g2);      // (e x g)_1
-            a2v += q3 * e0v * g2 + c4 * (e3v * g1 - e1v * g3);
-            a3v += q3 * e0v * g3 + c4 * (e1v * g2 - e2v * g1);
-            b1v += q2 * v0 * g1 + c4 * (g2 * v3 - g3 * v2);         // (g x v)_1
-            b2v += q2 * v0 * g2 + c4 * (g3 * v1 - g1 * v3);
-            b3v += q2 * v0 * g3 + c4 * (g1 * v2 - g2 * v1);
-          }
-          dV[0][r] = a0v; dV[1][r] = a1v; dV[2][r] = a2v; dV[3][r] = a3v;
-          st[fidx] = b0v; st[32 + fidx] = b1v; st[64 + fidx] = b2v; st[96 + fidx] = b3v;
+          st[fidx] = b2s[r]; st[32 + fidx] = b3s[r];
         }
+        __syncthreads();
+        reduce_half(lds, lds.denv, 1, na, A.cenv, tid);
+        __syncthreads();
       }
-      __syncthreads();
-      {
-        const int fidx = tid & 127;
-        for (int a = tid >> 7; a < na; a += 2) {
-          float sum = 0.f;
-          for (int sl = lds.aoff[a]; sl < lds.aoff[a + 1]; ++sl) sum += lds.stage[sl * STG_LD + fidx];
-          lds.denv[a * STG_LD + fidx] = A.cenv * sum;
-        }
-      }
-      __syncthreads();
       {
         f32x16 om[2], dom[2];
-        load_rows<2>(scr, RL + 0, om, lane);
-        const float *de = lds.denv + aloc * STG_LD;
+        load_rows<2>(SB, RL + 0, om, v16);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int fidx = feat_of(r, h);
-          const float d0 = de[fidx], d1 = de[32 + fidx], d2 = de[64 + fidx], d3 = de[96 + fidx];
+          const float d0 = denvrow[fidx], d1 = denvrow[32 + fidx], d2 = denvrow[64 + fidx], d3 = denvrow[96 + fidx];
           dom[0][r] = d0;
           dom[1][r] = d1 * Y1 + d2 * Y2 + d3 * Y3;
           dY1 += d1 * om[1][r]; dY2 += d2 * om[1][r]; dY3 += d3 * om[1][r];
         }
-        linear<2, 2, 4, true>(Wb + A.o_envT[kk], dom, dx, lane);
+        linear<2, 2, 4, true>(WB, A.o_envT[kk], dom, dx, v16);
       }
-      __syncthreads();          // denv / stage free for the next layer
     }
     // ---------------- embedding backward ----------------
     {
-      f32x16 dw0[2];
+      f32x16 dV[4], w0[2], dw0[2];
+      load_rows<4>(SB, R_DV(), dV, v16);
+      load_rows<2>(SB, R_W0(), w0, v16);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         dw0[0][r] = dV[0][r];
         dw0[1][r] = dV[1][r] * Y1 + dV[2][r] * Y2 + dV[3][r] * Y3;
-        dY1 += dV[1][r] * w0s[1][r]; dY2 += dV[2][r] * w0s[1][r]; dY3 += dV[3][r] * w0s[1][r];
+        dY1 += dV[1][r] * w0[1][r]; dY2 += dV[2][r] * w0[1][r]; dY3 += dV[3][r] * w0[1][r];
       }
-      linear<2, 2, 4, true>(Wb + A.o_embT, dw0, dx, lane);
+      linear<2, 2, 4, true>(WB, A.o_embT, dw0, dx, v16);
     }
     // ---------------- two-body MLP backward ----------------
     float dd_part = 0.f;
     {
-      f32x16 u[2], du[2], z[2], dh[2];
-      load_rows<2>(scr, R_U0(), u, lane);
+      f32x16 du[2], dh[2];
       float acc = 0.f;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc += u[t][r] * dx[t][r]; du[t][r] = fc * dx[t][r]; }
+        for (int q = 0; q < 4; ++q) {
+          f32x4 u = bload(SB, v16, ((R_U0() + t) * ROW + q * 256) * 4);
+          const float uu[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { acc += uu[c] * dx[t][4 * q + c]; du[t][4 * q + c] = fc * dx[t][4 * q + c]; }
+        }
       dfc_part += acc;
-      linear<2, 2>(Wb + A.o_tb_w2T, du, dh, lane);
-      load_rows<2>(scr, R_Z2TB(), z, lane);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dh[t][r] *= dsilu1(z[t][r]);
-      linear<2, 2>(Wb + A.o_tb_w1T, dh, du, lane);
-      load_rows<2>(scr, R_Z1TB(), z, lane);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) du[t][r] *= dsilu1(z[t][r]);
+      linear<2, 2>(WB, A.o_tb_w2T, du, dh, v16);
+      mul_dsilu_rows<2>(SB, R_Z2TB(), dh, v16);
+      linear<2, 2>(WB, A.o_tb_w1T, dh, du, v16);
+      mul_dsilu_rows<2>(SB, R_Z1TB(), du, v16);
       f32x16 dbf[1];
-      linear<2, 1>(Wb + A.o_tb_wcT, du, dbf, lane);
+      linear<2, 1>(WB, A.o_tb_wcT, du, dbf, v16);
       const float dfdd = dfc_dx / rc;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -553,7 +615,6 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
       const float gy = dd * ny + (Gy - gn * ny) * inv;
       const float gz = dd * nz + (Gz - gn * nz) * inv;
       if (h == 0) {
-        float *st = lds.stage + s * STG_LD;
         const float m = valid ? 1.f : 0.f;
         st[0] = m * gx; st[1] = m * gy; st[2] = m * gz; st[3] = m * eps;
         st[4] = -m * rx * gx; st[5] = -m * ry * gy; st[6] = -m * rz * gz;
@@ -569,8 +630,8 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
     if (tid < na) {
       double sx = 0, sy = 0, sz = 0, se = 0;
       for (int sl = lds.aoff[tid]; sl < lds.aoff[tid + 1]; ++sl) {
-        const float *st = lds.stage + sl * STG_LD;
-        sx += st[0]; sy += st[1]; sz += st[2]; se += st[3];
+        const float *sp = lds.stage + sl * STG_LD;
+        sx += sp[0]; sy += sp[1]; sz += sp[2]; se += sp[3];
       }
       const int i = A.ilist[a0 + tid];
       atomicAdd(&A.f[3 * (size_t)i], sx);
@@ -741,12 +802,13 @@ static void fused_prepare(Model &m) {
   st.wbuf.reserve(w.size() * sizeof(float));
   AHIP_CHECK(hipMemcpy(st.wbuf.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
   A.wbase = st.wbuf.as<float>();
+  A.wbytes = (int)(w.size() * sizeof(float));
   A.T = T; A.NL = NL; A.p = h.poly_p;
   A.cenv = (float)(1.0 / std::sqrt(h.avg_num_neighbors));
   hipDeviceProp_t prop;
   AHIP_CHECK(hipGetDeviceProperties(&prop, m.device));
   st.ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  st.grid = st.ncu;
+  st.grid = 2 * st.ncu;                     // two resident workgroups per CU (LDS 66 KB, <= 256 registers)
   A.wave_scratch = (long long)R_TOTAL(NL) * ROW;
   A.wg_scratch = 4 * A.wave_scratch;
   st.scratch.reserve((size_t)st.grid * A.wg_scratch * sizeof(float));
@@ -813,7 +875,8 @@ __global__ void __launch_bounds__(64) k_selftest_linear(const float *Wf, const f
       int k = 32 * t + feat_of(r, h);
       a[t][r] = k < K ? in[slot * K + k] : 0.f;
     }
-  linear<KT, NT, KQ>(Wf, a, o, lane);
+  __amdgpu_buffer_rsrc_t WB = __builtin_amdgcn_make_buffer_rsrc((void *)Wf, 0, KT * NT * 4096, 0x00020000);
+  linear<KT, NT, KQ>(WB, 0, a, o, lane * 16);
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll

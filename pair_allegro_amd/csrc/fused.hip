@@ -23,6 +23,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/allegro_hip.h"
@@ -37,7 +40,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static constexpr int TILE_SLOTS = 128;
 static constexpr int MAXA = 16;          // centre atoms per tile
 static constexpr int MAXNL = 3;
-static constexpr int STG_LD = 65;        // staging leading dimension: 64 features per pass (odd -> conflict-free)
+static constexpr int STG_LD = 129;       // staging leading dimension: all 128 features of a slot (odd -> conflict-free)
 static constexpr int ENV_LD = 129;       // per-atom environment row
 static constexpr int SEG = 512;          // atoms per sequential packing segment
 static constexpr int ROW = 1024;         // floats per saved register image (16 regs x 64 lanes)
@@ -56,7 +59,7 @@ struct FusedArgs {
   // weights (offsets in floats into wbase)
   const float *wbase;
   int wbytes;
-  int o_pair, o_tb_wc, o_tb_w1, o_tb_w2, o_emb, o_out0, o_out1, o_scale, o_shift;
+  int o_tpl, o_pair, o_tb_wc, o_tb_w1, o_tb_w2, o_emb, o_out0, o_out1, o_scale, o_shift;
   int o_tb_wcT, o_tb_w1T, o_tb_w2T, o_embT, o_out0T;
   int o_env[MAXNL], o_lat0[MAXNL], o_lat1[MAXNL], o_lat2[MAXNL], o_mix[MAXNL], o_tp[MAXNL], o_res[MAXNL];
   int o_envT[MAXNL], o_lat0T[MAXNL], o_lat1T[MAXNL], o_lat2T[MAXNL], o_mixT[MAXNL];
@@ -65,12 +68,16 @@ struct FusedArgs {
   long long wg_scratch, wave_scratch;     // floats
   // outputs
   double *f, *eatom, *partial;            // partial [gridDim.x][7]
+  long long *prof;                        // [PH_N] or unused
+  float *dbg;                             // [E][8] per-edge diagnostics or null
 };
 
 struct __attribute__((aligned(16))) Lds {
   float stage[TILE_SLOTS * STG_LD];
   float env[MAXNL][MAXA * ENV_LD];
   float denv[MAXA * ENV_LD];
+  float tp[MAXNL][5 * 32];                // tensor-product path weights [layer][path][u]
+  float vir[4][8];                        // per-wave virial partials
   float ea[MAXA];
   int aoff[MAXA + 2];
 };
@@ -96,7 +103,7 @@ __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, int voff, int s
 // fragment latency: a PF-deep register ring keeps PF fragment loads (PF x 256 MFMA cycles) in
 // flight; sched_barrier pins the load -> 4 MFMA order so the compiler cannot sink the loads back
 // next to their use (it did: every load was followed by s_waitcnt vmcnt(0)).
-template <int KT, int NT, int KQ_LAST = 4, bool ACC = false, int PF = 4>
+template <int KT, int NT, int KQ_LAST = 4, bool ACC = false, int PF = 8>
 __device__ __forceinline__ void linear(__amdgpu_buffer_rsrc_t W, int wo, const f32x16 (&in)[KT], f32x16 (&out)[NT], int v16) {
   constexpr int SPO = (KT - 1) * 4 + KQ_LAST;       // 4-MFMA steps per output tile
   constexpr int NS = NT * SPO;
@@ -168,6 +175,12 @@ __device__ __forceinline__ f32x4 rowq(__amdgpu_buffer_rsrc_t S, int row, int q, 
 __device__ __forceinline__ f32x4 hvecq(__amdgpu_buffer_rsrc_t W, int wo, int q, int h16) {
   return bload(W, h16, (wo + q * 8) * 4);
 }
+template <int NT> __device__ __forceinline__ void mul_dsilu(f32x16 (&d)[NT], const f32x16 (&z)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[t][r] *= dsilu1(z[t][r]);
+}
 // z *= silu'(saved row)
 template <int NT> __device__ __forceinline__ void mul_dsilu_rows(__amdgpu_buffer_rsrc_t S, int row0, f32x16 (&d)[NT], int v16) {
 #pragma unroll
@@ -213,18 +226,32 @@ static constexpr float C_S3 = 1.7320508075688772f;
 static constexpr float C_P1 = 0.5773502691896258f;     // (1,1,0): sqrt(1) * w3j = 1/sqrt(3)
 static constexpr float C_P4 = 0.7071067811865476f;     // (1,1,1): sqrt(3) * w3j = eps_ijk / sqrt(2)
 
-// Per-centre sum of the staged half (64 features) into dst[a][half*64 + f], scaled.
-__device__ __forceinline__ void reduce_half(const Lds &lds, float *dst, int half, int na, float scale, int tid) {
-  const int fidx = tid & 63;
-  for (int a = tid >> 6; a < na; a += 4) {
-    float sum = 0.f;
-    for (int sl = lds.aoff[a]; sl < lds.aoff[a + 1]; ++sl) sum += lds.stage[sl * STG_LD + fidx];
-    dst[a * ENV_LD + half * 64 + fidx] = scale * sum;
+// Per-centre sum of the staged tile: dst[a][f] = scale * sum_{slots of a} stage[slot][f], f < 128.
+// 256 threads = 2 atoms x 128 features per pass; 4 independent accumulators keep 4 LDS reads in flight.
+__device__ __forceinline__ void reduce_stage(const Lds &lds, float *dst, int na, float scale, int tid) {
+  const int fidx = tid & 127;
+  for (int a = tid >> 7; a < na; a += 2) {
+    const int s0 = lds.aoff[a], s1 = lds.aoff[a + 1];
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    int sl = s0;
+    for (; sl + 4 <= s1; sl += 4) {
+      acc0 += lds.stage[sl * STG_LD + fidx];
+      acc1 += lds.stage[(sl + 1) * STG_LD + fidx];
+      acc2 += lds.stage[(sl + 2) * STG_LD + fidx];
+      acc3 += lds.stage[(sl + 3) * STG_LD + fidx];
+    }
+    for (; sl < s1; ++sl) acc0 += lds.stage[sl * STG_LD + fidx];
+    dst[a * ENV_LD + fidx] = scale * ((acc0 + acc1) + (acc2 + acc3));
   }
 }
 
 // ---------------------------------------------------------------------------- the kernel
-__global__ void __launch_bounds__(256, 2) k_fused(FusedArgs A) {
+// PROF: opt-in phase timing (s_memtime stamps per wave, summed into A.prof[phase]); AHIP_FUSED_PROF=1.
+enum { PH_GEOM = 0, PH_TB, PH_EMB, PH_ENV, PH_TP, PH_MIX, PH_LAT, PH_OUT, PH_BLAT, PH_BMIX, PH_BTP, PH_BENV, PH_BEMB, PH_BTB, PH_FIN, PH_N };
+#define PHASE(id) do { if (PROF) { long long _t = clock64(); pacc[id] += _t - tprev; tprev = _t; } } while (0)
+
+template <bool PROF>
+__global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
   __shared__ Lds lds;
   const int tid = threadIdx.x, lane = tid & 63, slot = lane & 31, h = lane >> 5, wave = tid >> 6;
   const int v16 = lane * 16, h16 = h * 16;
@@ -237,9 +264,17 @@ __global__ void __launch_bounds__(256, 2) k_fused(FusedArgs A) {
     WB = __builtin_amdgcn_make_buffer_rsrc((void *)A.wbase, 0, A.wbytes, 0x00020000);
   }
   const float *__restrict__ Wb = A.wbase;
+  for (int k = tid; k < A.NL * 160; k += 256) lds.tp[k / 160][k % 160] = Wb[A.o_tpl + k];
   const int ntiles = *A.ntiles;
   const int NL = A.NL;
   double acc_part = 0.0;       // thread 0: energy; threads 64..69: virial components
+  long long pacc[PH_N];
+  long long tprev = 0;
+  if (PROF) {
+#pragma unroll
+    for (int k = 0; k < PH_N; ++k) pacc[k] = 0;
+    tprev = clock64();
+  }
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int a0 = A.tile_a0[tile], a1 = A.tile_a0[tile + 1];
@@ -276,6 +311,7 @@ __global__ void __launch_bounds__(256, 2) k_fused(FusedArgs A) {
     const float *const envrow = lds.env[0] + aloc * ENV_LD;        // + kk * MAXA*ENV_LD
     const float *const denvrow = lds.denv + aloc * ENV_LD;
 
+    PHASE(PH_GEOM);
     // ---------------- two-body MLP ----------------
     f32x16 x[2];
     {
@@ -297,7 +333,11 @@ __global__ void __launch_bounds__(256, 2) k_fused(FusedArgs A) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float n = (float)(r + 4 * h + 1);
+#ifdef AHIP_PRECISE_SIN
         bfin[0][r] = pref * sinf(PI * n * xx) * inv * fc;
+#else
+        bfin[0][r] = pref * __builtin_amdgcn_sinf(0.5f * n * xx) * inv * fc;
+#endif
       }
       linear<1, 2, 1, true>(WB, A.o_tb_wc, bfin, z, v16);
       save_rows<2>(SB, R_Z1TB(), z, v16);
@@ -313,77 +353,84 @@ __global__ void __launch_bounds__(256, 2) k_fused(FusedArgs A) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[t][r] = fc * z[t][r];
     }
+    PHASE(PH_TB);
     // ---------------- tensor embedding weights (V^0 = w0 (x) Y is rebuilt where needed) -------------
     {
       f32x16 w0[2];
       linear<2, 2>(WB, A.o_emb, x, w0, v16);
       save_rows<2>(SB, R_W0(), w0, v16);
     }
-    __syncthreads();          // aoff visible; previous tile's LDS users done
+    __syncthreads();          // aoff visible; previous tile's LDS users done    PHASE(PH_EMB);
+
 
     // ---------------- layers, forward ----------------
     for (int kk = 0; kk < NL; ++kk) {
       const bool last = (kk == NL - 1);
       const int RL = R_LAYER(kk);
       float *const envk = lds.env[0] + kk * (MAXA * ENV_LD);
+      f32x16 V[4], V0a[1], V1a[1];
       {
         f32x16 om[2];
         linear<2, 2>(WB, A.o_env[kk], x, om, v16);
         save_rows<2>(SB, RL + 0, om, v16);
-        // environment sum, two staged halves of 64 features
+        // prefetch V^{kk} (or w0 for the first layer) now: it lands while the environment is reduced
+#ifndef AHIP_NO_PF1
+        if (kk > 0) load_rows<4>(SB, RL + 8, V, v16);
+        else { load_rows<1>(SB, R_W0(), V0a, v16); load_rows<1>(SB, R_W0() + 1, V1a, v16); }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        // environment sum over the centre's edges
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int fidx = feat_of(r, h);
           st[fidx] = om[0][r];
           st[32 + fidx] = om[1][r] * Y1;
+          st[64 + fidx] = om[1][r] * Y2;
+          st[96 + fidx] = om[1][r] * Y3;
         }
         __syncthreads();
-        reduce_half(lds, envk, 0, na, A.cenv, tid);
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int fidx = feat_of(r, h);
-          st[fidx] = om[1][r] * Y2;
-          st[32 + fidx] = om[1][r] * Y3;
-        }
-        __syncthreads();
-        reduce_half(lds, envk, 1, na, A.cenv, tid);
+        reduce_stage(lds, envk, na, A.cenv, tid);
         __syncthreads();
       }
-      // tensor product (V^{kk} and the path weights are streamed 4 registers at a time)
+#ifdef AHIP_NO_PF1
+      if (kk > 0) load_rows<4>(SB, RL + 8, V, v16);
+      else { load_rows<1>(SB, R_W0(), V0a, v16); load_rows<1>(SB, R_W0() + 1, V1a, v16); }
+#endif
+      if (kk == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float w1 = V1a[0][r];
+          V[0][r] = V0a[0][r]; V[1][r] = w1 * Y1; V[2][r] = w1 * Y2; V[3][r] = w1 * Y3;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      PHASE(PH_ENV);
+      // tensor product (4 registers per scheduling group: keeps the LDS reads from being hoisted en bloc)
       f32x16 Vp[4];
       {
         const float *en = envrow + kk * (MAXA * ENV_LD);
-        const int tpo = A.o_tp[kk];
+        const float *tp = lds.tp[kk];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          f32x4 V0, V1, V2, V3;
-          if (kk > 0) {
-            V0 = rowq(SB, RL + 8, q, v16); V1 = rowq(SB, RL + 9, q, v16); V2 = rowq(SB, RL + 10, q, v16); V3 = rowq(SB, RL + 11, q, v16);
-          } else {
-            V0 = rowq(SB, R_W0(), q, v16);
-            const f32x4 w1 = rowq(SB, R_W0() + 1, q, v16);
-            V1 = w1 * Y1; V2 = w1 * Y2; V3 = w1 * Y3;
-          }
-          const f32x4 p0 = hvecq(WB, tpo, q, h16), p1 = hvecq(WB, tpo + 32, q, h16);
-          f32x4 p2, p3, p4;
-          if (!last) { p2 = hvecq(WB, tpo + 64, q, h16); p3 = hvecq(WB, tpo + 96, q, h16); p4 = hvecq(WB, tpo + 128, q, h16); }
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const int r = 4 * q + c;
             const int fidx = feat_of(r, h);
             const float e0v = en[fidx], e1v = en[32 + fidx], e2v = en[64 + fidx], e3v = en[96 + fidx];
-            const float v0 = V0[c], v1 = V1[c], v2 = V2[c], v3 = V3[c];
-            Vp[0][r] = p0[c] * v0 * e0v + p1[c] * C_P1 * (v1 * e1v + v2 * e2v + v3 * e3v);
+            const float v0 = V[0][r], v1 = V[1][r], v2 = V[2][r], v3 = V[3][r];
+            Vp[0][r] = tp[fidx] * v0 * e0v + tp[32 + fidx] * C_P1 * (v1 * e1v + v2 * e2v + v3 * e3v);
             if (!last) {
-              const float c4 = p4[c] * C_P4;
-              Vp[1][r] = p2[c] * v0 * e1v + p3[c] * v1 * e0v + c4 * (v2 * e3v - v3 * e2v);
-              Vp[2][r] = p2[c] * v0 * e2v + p3[c] * v2 * e0v + c4 * (v3 * e1v - v1 * e3v);
-              Vp[3][r] = p2[c] * v0 * e3v + p3[c] * v3 * e0v + c4 * (v1 * e2v - v2 * e1v);
+              const float p2 = tp[64 + fidx], p3 = tp[96 + fidx], c4 = tp[128 + fidx] * C_P4;
+              Vp[1][r] = p2 * v0 * e1v + p3 * v1 * e0v + c4 * (v2 * e3v - v3 * e2v);
+              Vp[2][r] = p2 * v0 * e2v + p3 * v2 * e0v + c4 * (v3 * e1v - v1 * e3v);
+              Vp[3][r] = p2 * v0 * e3v + p3 * v3 * e0v + c4 * (v1 * e2v - v2 * e1v);
             }
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      PHASE(PH_TP);
       // channel mixing -> V^{kk+1}, parked in the next layer's VIN rows
       if (!last) {
         const int mx = A.o_mix[kk];
@@ -395,6 +442,8 @@ __global__ void __launch_bounds__(256, 2) k_fused(FusedArgs A) {
           save_rows<1>(SB, R_LAYER(kk + 1) + 8 + lm, out1, v16);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      PHASE(PH_MIX);
       // latent MLP
       {
         f32x16 cat[3], z[2], z2[2];
@@ -413,8 +462,10 @@ __global__ void __launch_bounds__(256, 2) k_fused(FusedArgs A) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) x[t][r] = ra * x[t][r] + rb * z[t][r];
       }
+      PHASE(PH_LAT);
     }
 
+    PHASE(PH_LAT);
     // ---------------- read-out ----------------
     f32x16 zr[1];
     linear<2, 1>(WB, A.o_out0, x, zr, v16);
@@ -435,10 +486,11 @@ __global__ void __launch_bounds__(256, 2) k_fused(FusedArgs A) {
     }
     float dfc_part = 0.f, dY1 = 0.f, dY2 = 0.f, dY3 = 0.f;
 
+    PHASE(PH_OUT);
     for (int kk = NL - 1; kk >= 0; --kk) {
       const bool last = (kk == NL - 1);
       const int RL = R_LAYER(kk);
-      f32x16 dVp[4];
+      f32x16 dVp[4], Vk[4], V0b[1], V1b[1];
       {
         f32x16 du[2], dh[2];
         {
@@ -460,16 +512,47 @@ __global__ void __launch_bounds__(256, 2) k_fused(FusedArgs A) {
             }
           dfc_part += rb * acc;
         }
+#ifdef AHIP_OLD_ZT
         linear<2, 2>(WB, A.o_lat2T[kk], du, dh, v16);
         mul_dsilu_rows<2>(SB, RL + 4, dh, v16);
         linear<2, 2>(WB, A.o_lat1T[kk], dh, du, v16);
         mul_dsilu_rows<2>(SB, RL + 2, du, v16);
+#else
+        f32x16 zt[2];
+        load_rows<2>(SB, RL + 4, zt, v16);                   // z2, lands under the next 64 MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        linear<2, 2>(WB, A.o_lat2T[kk], du, dh, v16);
+        mul_dsilu<2>(dh, zt);
+        load_rows<2>(SB, RL + 2, zt, v16);                   // z1
+        __builtin_amdgcn_sched_barrier(0);
+        linear<2, 2>(WB, A.o_lat1T[kk], dh, du, v16);
+        mul_dsilu<2>(du, zt);
+#endif
+        // prefetch V^{kk} (input of this layer's tensor product) under the 96 MFMAs of lat0^T
+#ifndef AHIP_NO_PF2
+        if (kk > 0) load_rows<4>(SB, RL + 8, Vk, v16);
+        else { load_rows<1>(SB, R_W0(), V0b, v16); load_rows<1>(SB, R_W0() + 1, V1b, v16); }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         f32x16 dcat[3];
         linear<2, 3>(WB, A.o_lat0T[kk], du, dcat, v16);
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dx[0][r] += dcat[0][r]; dx[1][r] += dcat[1][r]; }
         dVp[0] = dcat[2];                                   // ds
       }
+#ifdef AHIP_NO_PF2
+      if (kk > 0) load_rows<4>(SB, RL + 8, Vk, v16);
+      else { load_rows<1>(SB, R_W0(), V0b, v16); load_rows<1>(SB, R_W0() + 1, V1b, v16); }
+#endif
+      if (kk == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float w1 = V1b[0][r];
+          Vk[0][r] = V0b[0][r]; Vk[1][r] = w1 * Y1; Vk[2][r] = w1 * Y2; Vk[3][r] = w1 * Y3;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      PHASE(PH_BLAT);
       if (!last) {
         const int mx = A.o_mixT[kk];
         f32x16 in1[1], out1[1];
@@ -483,38 +566,29 @@ __global__ void __launch_bounds__(256, 2) k_fused(FusedArgs A) {
           } else dVp[lm] = out1[0];
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      PHASE(PH_BMIX);
       // tensor-product backward: dV (w.r.t. V^{kk}, parked) and the per-edge environment gradient
+      f32x16 om[2];
       {
         const float *en = envrow + kk * (MAXA * ENV_LD);
-        const int tpo = A.o_tp[kk];
-        f32x16 b2s, b3s;                 // second staged half
+        const float *tp = lds.tp[kk];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          f32x4 V0, V1, V2, V3;
-          if (kk > 0) {
-            V0 = rowq(SB, RL + 8, q, v16); V1 = rowq(SB, RL + 9, q, v16); V2 = rowq(SB, RL + 10, q, v16); V3 = rowq(SB, RL + 11, q, v16);
-          } else {
-            V0 = rowq(SB, R_W0(), q, v16);
-            const f32x4 w1 = rowq(SB, R_W0() + 1, q, v16);
-            V1 = w1 * Y1; V2 = w1 * Y2; V3 = w1 * Y3;
-          }
-          const f32x4 p0 = hvecq(WB, tpo, q, h16), p1 = hvecq(WB, tpo + 32, q, h16);
-          f32x4 p2, p3, p4;
-          if (!last) { p2 = hvecq(WB, tpo + 64, q, h16); p3 = hvecq(WB, tpo + 96, q, h16); p4 = hvecq(WB, tpo + 128, q, h16); }
           f32x4 o0, o1, o2, o3;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const int r = 4 * q + c;
             const int fidx = feat_of(r, h);
             const float e0v = en[fidx], e1v = en[32 + fidx], e2v = en[64 + fidx], e3v = en[96 + fidx];
-            const float v0 = V0[c], v1 = V1[c], v2 = V2[c], v3 = V3[c];
+            const float v0 = Vk[0][r], v1 = Vk[1][r], v2 = Vk[2][r], v3 = Vk[3][r];
             const float g0 = dVp[0][r];
-            const float q0 = p0[c] * g0, q1 = p1[c] * C_P1 * g0;
+            const float q0 = tp[fidx] * g0, q1 = tp[32 + fidx] * C_P1 * g0;
             float a0v = q0 * e0v, a1v = q1 * e1v, a2v = q1 * e2v, a3v = q1 * e3v;       // dV
             float b0v = q0 * v0, b1v = q1 * v1, b2v = q1 * v2, b3v = q1 * v3;           // denv_e
             if (!last) {
               const float g1 = dVp[1][r], g2 = dVp[2][r], g3 = dVp[3][r];
-              const float q2 = p2[c], q3 = p3[c], c4 = p4[c] * C_P4;
+              const float q2 = tp[64 + fidx], q3 = tp[96 + fidx], c4 = tp[128 + fidx] * C_P4;
               a0v += q2 * (e1v * g1 + e2v * g2 + e3v * g3);
               b0v += q3 * (v1 * g1 + v2 * g2 + v3 * g3);
               a1v += q3 * e0v * g1 + c4 * (e2v * g3 - e3v * g2);      // (e x g)_1
@@ -525,40 +599,42 @@ __global__ void __launch_bounds__(256, 2) k_fused(FusedArgs A) {
               b3v += q2 * v0 * g3 + c4 * (g1 * v2 - g2 * v1);
             }
             o0[c] = a0v; o1[c] = a1v; o2[c] = a2v; o3[c] = a3v;
-            st[fidx] = b0v; st[32 + fidx] = b1v;
-            b2s[r] = b2v; b3s[r] = b3v;
+            st[fidx] = b0v; st[32 + fidx] = b1v; st[64 + fidx] = b2v; st[96 + fidx] = b3v;
           }
           bstore(SB, v16, ((R_DV() + 0) * ROW + q * 256) * 4, o0);
           bstore(SB, v16, ((R_DV() + 1) * ROW + q * 256) * 4, o1);
           bstore(SB, v16, ((R_DV() + 2) * ROW + q * 256) * 4, o2);
           bstore(SB, v16, ((R_DV() + 3) * ROW + q * 256) * 4, o3);
+          __builtin_amdgcn_sched_barrier(0);
         }
+        load_rows<2>(SB, RL + 0, om, v16);                   // omega of this layer, lands during the reduction
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
-        reduce_half(lds, lds.denv, 0, na, A.cenv, tid);
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int fidx = feat_of(r, h);
-          st[fidx] = b2s[r]; st[32 + fidx] = b3s[r];
-        }
-        __syncthreads();
-        reduce_half(lds, lds.denv, 1, na, A.cenv, tid);
+        reduce_stage(lds, lds.denv, na, A.cenv, tid);
         __syncthreads();
       }
+      __builtin_amdgcn_sched_barrier(0);
+      PHASE(PH_BTP);
       {
-        f32x16 om[2], dom[2];
-        load_rows<2>(SB, RL + 0, om, v16);
+        f32x16 dom[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int fidx = feat_of(r, h);
-          const float d0 = denvrow[fidx], d1 = denvrow[32 + fidx], d2 = denvrow[64 + fidx], d3 = denvrow[96 + fidx];
-          dom[0][r] = d0;
-          dom[1][r] = d1 * Y1 + d2 * Y2 + d3 * Y3;
-          dY1 += d1 * om[1][r]; dY2 += d2 * om[1][r]; dY3 += d3 * om[1][r];
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int r = 4 * q + c;
+            const int fidx = feat_of(r, h);
+            const float d0 = denvrow[fidx], d1 = denvrow[32 + fidx], d2 = denvrow[64 + fidx], d3 = denvrow[96 + fidx];
+            dom[0][r] = d0;
+            dom[1][r] = d1 * Y1 + d2 * Y2 + d3 * Y3;
+            dY1 += d1 * om[1][r]; dY2 += d2 * om[1][r]; dY3 += d3 * om[1][r];
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
         linear<2, 2, 4, true>(WB, A.o_envT[kk], dom, dx, v16);
       }
+      PHASE(PH_BENV);
     }
+    PHASE(PH_BENV);
     // ---------------- embedding backward ----------------
     {
       f32x16 dV[4], w0[2], dw0[2];
@@ -572,6 +648,7 @@ __global__ void __launch_bounds__(256, 2) k_fused(FusedArgs A) {
       }
       linear<2, 2, 4, true>(WB, A.o_embT, dw0, dx, v16);
     }
+    PHASE(PH_BEMB);
     // ---------------- two-body MLP backward ----------------
     float dd_part = 0.f;
     {
@@ -587,23 +664,40 @@ __global__ void __launch_bounds__(256, 2) k_fused(FusedArgs A) {
           for (int c = 0; c < 4; ++c) { acc += uu[c] * dx[t][4 * q + c]; du[t][4 * q + c] = fc * dx[t][4 * q + c]; }
         }
       dfc_part += acc;
+#ifdef AHIP_OLD_ZT
       linear<2, 2>(WB, A.o_tb_w2T, du, dh, v16);
       mul_dsilu_rows<2>(SB, R_Z2TB(), dh, v16);
       linear<2, 2>(WB, A.o_tb_w1T, dh, du, v16);
       mul_dsilu_rows<2>(SB, R_Z1TB(), du, v16);
+#else
+      f32x16 zt[2];
+      load_rows<2>(SB, R_Z2TB(), zt, v16);
+      __builtin_amdgcn_sched_barrier(0);
+      linear<2, 2>(WB, A.o_tb_w2T, du, dh, v16);
+      mul_dsilu<2>(dh, zt);
+      load_rows<2>(SB, R_Z1TB(), zt, v16);
+      __builtin_amdgcn_sched_barrier(0);
+      linear<2, 2>(WB, A.o_tb_w1T, dh, du, v16);
+      mul_dsilu<2>(du, zt);
+#endif
       f32x16 dbf[1];
       linear<2, 1>(WB, A.o_tb_wcT, du, dbf, v16);
       const float dfdd = dfc_dx / rc;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float n = (float)(r + 4 * h + 1);
-        float sn, cs;
-        sincosf(PI * n * xx, &sn, &cs);
+        // argument in revolutions for v_sin/v_cos (|arg| <= 4): abs error ~1e-6, far inside the force budget
+#ifdef AHIP_PRECISE_SIN
+        float sn, cs; sincosf(PI * n * xx, &sn, &cs);
+#else
+        const float sn = __builtin_amdgcn_sinf(0.5f * n * xx), cs = __builtin_amdgcn_cosf(0.5f * n * xx);
+#endif
         const float b = pref * sn * inv;
         const float db = pref * (cs * PI * n / rc * inv - sn * inv * inv);
         dd_part += dbf[0][r] * (db * fc + b * dfdd);
       }
     }
+    PHASE(PH_BTB);
     // ---------------- geometry backward, outputs ----------------
     {
       const float dfc_tot = dfc_part + __shfl_xor(dfc_part, 32, 64);
@@ -614,47 +708,67 @@ __global__ void __launch_bounds__(256, 2) k_fused(FusedArgs A) {
       const float gx = dd * nx + (Gx - gn * nx) * inv;
       const float gy = dd * ny + (Gy - gn * ny) * inv;
       const float gz = dd * nz + (Gz - gn * nz) * inv;
+      if (A.dbg && valid && h == 0) {
+        float *dp = A.dbg + 8 * (size_t)e;
+        dp[0] = gx; dp[1] = gy; dp[2] = gz; dp[3] = dd; dp[4] = dfc_tot; dp[5] = y1; dp[6] = y2; dp[7] = y3;
+      }
+      const float m = valid ? 1.f : 0.f;
       if (h == 0) {
-        const float m = valid ? 1.f : 0.f;
         st[0] = m * gx; st[1] = m * gy; st[2] = m * gz; st[3] = m * eps;
-        st[4] = -m * rx * gx; st[5] = -m * ry * gy; st[6] = -m * rz * gz;
-        st[7] = -m * 0.5f * (rx * gy + ry * gx); st[8] = -m * 0.5f * (rx * gz + rz * gx); st[9] = -m * 0.5f * (ry * gz + rz * gy);
         if (valid) {
           atomicAdd(&A.f[3 * (size_t)jat], -(double)gx);
           atomicAdd(&A.f[3 * (size_t)jat + 1], -(double)gy);
           atomicAdd(&A.f[3 * (size_t)jat + 2], -(double)gz);
         }
       }
+      // virial of this wave's 32 edges: butterfly over the slot lanes, lane 0 publishes 6 partials
+      float w6[6] = {-m * rx * gx, -m * ry * gy, -m * rz * gz, -m * 0.5f * (rx * gy + ry * gx),
+                     -m * 0.5f * (rx * gz + rz * gx), -m * 0.5f * (ry * gz + rz * gy)};
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) w6[c] += __shfl_xor(w6[c], off, 64);
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) lds.vir[wave][c] = w6[c];
+      }
     }
     __syncthreads();
-    if (tid < na) {
-      double sx = 0, sy = 0, sz = 0, se = 0;
-      for (int sl = lds.aoff[tid]; sl < lds.aoff[tid + 1]; ++sl) {
-        const float *sp = lds.stage + sl * STG_LD;
-        sx += sp[0]; sy += sp[1]; sz += sp[2]; se += sp[3];
+    {
+      // per-centre sums of (g, eps): 16 lanes per atom = 4 columns x 4 row-parts
+      const int a = tid >> 4, col = tid & 3, part = (tid >> 2) & 3;
+      float sum = 0.f;
+      if (a < na)
+        for (int sl = lds.aoff[a] + part; sl < lds.aoff[a + 1]; sl += 4) sum += lds.stage[sl * STG_LD + col];
+      sum += __shfl_xor(sum, 4, 64);
+      sum += __shfl_xor(sum, 8, 64);
+      if (a < na && part == 0) {
+        const int i = A.ilist[a0 + a];
+        if (col < 3) atomicAdd(&A.f[3 * (size_t)i + col], (double)sum);
+        else {
+          const int t = A.mtype[i];
+          const float ei = Wb[A.o_scale + t] * (sum * A.cenv) + Wb[A.o_shift + t];
+          if (A.eatom) A.eatom[i] = (double)ei;
+          lds.ea[a] = ei;
+        }
       }
-      const int i = A.ilist[a0 + tid];
-      atomicAdd(&A.f[3 * (size_t)i], sx);
-      atomicAdd(&A.f[3 * (size_t)i + 1], sy);
-      atomicAdd(&A.f[3 * (size_t)i + 2], sz);
-      const int t = A.mtype[i];
-      const float ei = Wb[A.o_scale + t] * ((float)se * A.cenv) + Wb[A.o_shift + t];
-      if (A.eatom) A.eatom[i] = (double)ei;
-      lds.ea[tid] = ei;
-    } else if (tid >= 64 && tid < 70) {
-      const int c = tid - 64 + 4;
-      double sv = 0;
-      const int ne = e1 - e0;
-      for (int sl = 0; sl < ne; ++sl) sv += lds.stage[sl * STG_LD + c];
-      acc_part += sv;
     }
     __syncthreads();
     if (tid == 0) {
       double se = 0;
       for (int a = 0; a < na; ++a) se += lds.ea[a];
       acc_part += se;
+    } else if (tid >= 64 && tid < 70) {
+      const int c = tid - 64;
+      acc_part += (double)((lds.vir[0][c] + lds.vir[1][c]) + (lds.vir[2][c] + lds.vir[3][c]));
     }
     __syncthreads();
+    PHASE(PH_FIN);
+  }
+  if (PROF && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < PH_N; ++k) atomicAdd((unsigned long long *)&A.prof[k], (unsigned long long)pacc[k]);
   }
   if (tid == 0) A.partial[7 * (size_t)blockIdx.x] = acc_part;
   if (tid >= 64 && tid < 70) A.partial[7 * (size_t)blockIdx.x + 1 + (tid - 64)] = acc_part;
@@ -693,9 +807,11 @@ __global__ void k_pack_finish(int inum, int nseg, const int *seg_base, int *tile
 struct FusedState {
   DevBuf wbuf, scratch, seg_count, seg_base, tile_a0, ntiles, partial;
   FusedArgs args;
-  bool ready = false;
+  bool ready = false, prof_on = false, dbg_on = false;
+  DevBuf prof, dbg;
   int ncu = 256;
   int grid = 256;
+  int occ = 2;                 // resident workgroups per CU (AHIP_FUSED_OCC=1|2)
 };
 
 // A-operand fragments of W [K][N] (row-major, x @ W): [ot][kt][q][lane][c], r = 4q+c,
@@ -795,6 +911,12 @@ static void fused_prepare(Model &m) {
       for (int l = 0; l < 2; ++l) { auto t = transpose(mx.data.data() + (size_t)l * 1024, 32, 32); append_frag(w, t.data(), 32, 32, 32); }
     }
   }
+  A.o_tpl = mark();
+  for (int k = 0; k < NL; ++k) {
+    const HostTensor &tp = h.get("l" + std::to_string(k + 1) + ".tp");
+    for (int p = 0; p < 5; ++p)
+      for (int u = 0; u < 32; ++u) w.push_back(p < tp.shape[0] ? (float)tp.data[(size_t)p * 32 + u] : 0.f);
+  }
   both("out.w0", 64, 32, A.o_out0, A.o_out0T);
   A.o_out1 = mark(); append_hvec(w, h.get("out.w1").data.data());
   A.o_scale = mark(); for (int t = 0; t < T; ++t) w.push_back((float)h.get("scale").data[t]);
@@ -808,13 +930,22 @@ static void fused_prepare(Model &m) {
   hipDeviceProp_t prop;
   AHIP_CHECK(hipGetDeviceProperties(&prop, m.device));
   st.ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  st.grid = 2 * st.ncu;                     // two resident workgroups per CU (LDS 66 KB, <= 256 registers)
+  // One persistent workgroup per CU = one wave per SIMD with the whole 512-entry register file.
+  // (Two workgroups per CU at <= 256 registers was measured: the tensor-product phases spill and
+  //  the kernel is 1.7x slower -- profiles/r01_b.)
+  st.occ = 1;
+  st.grid = st.ncu;
   A.wave_scratch = (long long)R_TOTAL(NL) * ROW;
   A.wg_scratch = 4 * A.wave_scratch;
   st.scratch.reserve((size_t)st.grid * A.wg_scratch * sizeof(float));
   A.scratch = st.scratch.as<float>();
   st.partial.reserve((size_t)st.grid * 7 * sizeof(double));
   st.ntiles.reserve(64);
+  st.prof.reserve(64 * sizeof(long long));
+  const char *pe = std::getenv("AHIP_FUSED_PROF");
+  st.prof_on = pe && pe[0] == '1';
+  const char *de = std::getenv("AHIP_FUSED_DBG");
+  st.dbg_on = de && de[0] == '1';
   st.ready = true;
 }
 
@@ -847,17 +978,39 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
   A.f = a.f; A.eatom = a.eatom; A.partial = st.partial.as<double>();
   {
     StageTimer tm(m, "model_fused", s);
-    hipLaunchKernelGGL(k_fused, dim3(st.grid), dim3(256), 0, s, A);
+    if (st.dbg_on) {
+      st.dbg.reserve((size_t)std::max<long long>(m.nedges, 1) * 8 * sizeof(float));
+      AHIP_CHECK(hipMemsetAsync(st.dbg.p, 0, (size_t)m.nedges * 8 * sizeof(float), s));
+      A.dbg = st.dbg.as<float>();
+    }
+    if (st.prof_on) {
+      AHIP_CHECK(hipMemsetAsync(st.prof.p, 0, 64 * sizeof(long long), s));
+      A.prof = st.prof.as<long long>();
+      hipLaunchKernelGGL(k_fused<true>, dim3(st.grid), dim3(256), 0, s, A);
+    } else {
+      hipLaunchKernelGGL(k_fused<false>, dim3(st.grid), dim3(256), 0, s, A);
+    }
   }
   AHIP_CHECK(hipGetLastError());
   AHIP_CHECK(prim_sum_columns_f64(st.partial.as<double>(), st.grid, 7, a.engvir, s));
+  if (st.prof_on) {
+    long long hp[PH_N];
+    AHIP_CHECK(hipMemcpyAsync(hp, st.prof.p, sizeof(hp), hipMemcpyDeviceToHost, s));
+    AHIP_CHECK(hipStreamSynchronize(s));
+    static const char *names[PH_N] = {"geom", "tb_mlp", "embed", "env+reduce", "tp", "mix", "latent_mlp", "readout", "b_latent", "b_mix", "b_tp+reduce", "b_env", "b_embed", "b_tb", "finish"};
+    double tot = 0;
+    for (int k = 0; k < PH_N; ++k) tot += (double)hp[k];
+    std::fprintf(stderr, "[ahip fused prof] wave-cycles by phase (sum over %d waves):", st.grid * 4);
+    for (int k = 0; k < PH_N; ++k) std::fprintf(stderr, " %s=%.1f%%", names[k], 100.0 * hp[k] / tot);
+    std::fprintf(stderr, " | total=%.3g cycles\n", tot);
+  }
   return true;
 }
 
 void fused_free(Model &m) {
   if (!m.fused_state) return;
   FusedState *st = (FusedState *)m.fused_state;
-  for (DevBuf *b : {&st->wbuf, &st->scratch, &st->seg_count, &st->seg_base, &st->tile_a0, &st->ntiles, &st->partial}) b->release();
+  for (DevBuf *b : {&st->wbuf, &st->scratch, &st->seg_count, &st->seg_base, &st->tile_a0, &st->ntiles, &st->partial, &st->prof}) b->release();
   delete st;
   m.fused_state = nullptr;
 }
@@ -889,6 +1042,15 @@ __global__ void __launch_bounds__(64) k_selftest_linear(const float *Wf, const f
 }  // namespace ahip
 
 using namespace ahip;
+
+// Diagnostic (AHIP_FUSED_DBG=1): per-edge {g[3], dd, dfc, dY[3]} of the last fused compute.
+extern "C" int ahip_debug_fused_edges(ahip::Model *m, float *out, long long nedges) {
+  if (!m || !m->fused_state) return AHIP_ERR_STATE;
+  FusedState &st = *(FusedState *)m->fused_state;
+  if (!st.dbg_on || !st.dbg.p || nedges != m->nedges) return AHIP_ERR_STATE;
+  if (hipDeviceSynchronize() != hipSuccess) return AHIP_ERR_DEVICE;
+  return hipMemcpy(out, st.dbg.p, (size_t)nedges * 8 * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess ? 0 : AHIP_ERR_DEVICE;
+}
 
 extern "C" int ahip_debug_fused_linear(int K, int N, const double *W, const float *in, float *out) {
   try {

@@ -134,6 +134,10 @@ int ahip_last_max_degree(ahip_model *m);
  * out[32][N] = in[32][K] @ W[K][N] (W row-major f64, in/out f32 host buffers). */
 int ahip_debug_fused_linear(int K, int N, const double *W, const float *in, float *out);
 
+/* Diagnostic (environment AHIP_FUSED_DBG=1): per-edge {g[3], dE/dd, dE/dfc, dE/dY1..3} of the last fused
+ * compute, [nedges][8] floats, edge order = ahip_get_edges. */
+int ahip_debug_fused_edges(ahip_model *m, float *out, long long nedges);
+
 /* ---- mini-MD helpers used by the stand-alone driver / bench (device-resident) ------------- */
 
 /* Build a full neighbor list with cutoff rc_list (= r_max + skin) for nlocal centre atoms among

@@ -22,7 +22,7 @@ SYMBOLS = [
     "ahip_last_error", "ahip_device_count", "ahip_model_load", "ahip_model_free", "ahip_model_meta",
     "ahip_set_option", "ahip_neigh_update", "ahip_neigh_update_csr", "ahip_neigh_update_dev",
     "ahip_compute", "ahip_compute_dev", "ahip_get_edges", "ahip_debug_dump_edges", "ahip_get_timings",
-    "ahip_last_path", "ahip_last_max_degree", "ahip_debug_fused_linear", "ahip_build_neighbors_dev", "ahip_nve_dev",
+    "ahip_last_path", "ahip_last_max_degree", "ahip_debug_fused_linear", "ahip_debug_fused_edges", "ahip_build_neighbors_dev", "ahip_nve_dev",
 ]
 
 

@@ -1044,7 +1044,8 @@ __global__ void __launch_bounds__(64) k_selftest_linear(const float *Wf, const f
 using namespace ahip;
 
 // Diagnostic (AHIP_FUSED_DBG=1): per-edge {g[3], dd, dfc, dY[3]} of the last fused compute.
-extern "C" int ahip_debug_fused_edges(ahip::Model *m, float *out, long long nedges) {
+extern "C" int ahip_debug_fused_edges(ahip_model *mh, float *out, long long nedges) {
+  ahip::Model *m = (ahip::Model *)mh;
   if (!m || !m->fused_state) return AHIP_ERR_STATE;
   FusedState &st = *(FusedState *)m->fused_state;
   if (!st.dbg_on || !st.dbg.p || nedges != m->nedges) return AHIP_ERR_STATE;

@@ -1,0 +1,61 @@
+/* -*- c++ -*- ----------------------------------------------------------
+   pair_style allegro -- MI355X-native implementation over liballegro_hip (C-ABI, include/allegro_hip.h).
+
+   Drop-in for `pair_style allegro` of mir-group/pair_allegro: same command surface
+   (`pair_style allegro`, `pair_coeff * * <model>.nequip.pth <type names...>`), same neighbor request
+   (full + ghost), same newton/atom-ID requirements, same outputs.  The class only marshals LAMMPS
+   pointers into the library; there is no libtorch and no Kokkos dependency.
+   Reference interface replaced: /root/reference/pair_nequip_allegro.h:43-50,80-82.
+------------------------------------------------------------------------- */
+
+#ifdef PAIR_CLASS
+// clang-format off
+PairStyle(allegro,PairAllegroHIP)
+// clang-format on
+#else
+
+#ifndef LMP_PAIR_ALLEGRO_HIP_H
+#define LMP_PAIR_ALLEGRO_HIP_H
+
+#include "pair.h"
+
+#include <map>
+#include <string>
+#include <vector>
+
+struct ahip_model;
+
+namespace LAMMPS_NS {
+
+class PairAllegroHIP : public Pair {
+ public:
+  PairAllegroHIP(class LAMMPS *);
+  ~PairAllegroHIP() override;
+  void compute(int, int) override;
+  void settings(int, char **) override;
+  void coeff(int, char **) override;
+  double init_one(int, int) override;
+  void init_style() override;
+  void allocate();
+
+  double cutoff;
+  int device = 0;
+  std::vector<int> type_mapper;    // LAMMPS type-1 -> model type, -1 = unmapped
+  std::string model_path;
+
+  // `compute allegro` hooks of the reference (pair_nequip_allegro.h:80-82); the HIP model has no
+  // extra outputs yet, so a registered name is an error at compute time like the reference's "missing {}".
+  std::vector<std::string> custom_output_names;
+  void add_custom_output(std::string);
+
+ protected:
+  int debug_mode = 0;
+  double **cutoff_matrix = nullptr;    // [ntypes][ntypes], LAMMPS type index
+  ahip_model *model = nullptr;
+  bigint last_list_build = -1;         // neighbor->lastcall of the list currently installed in the library
+};
+
+}    // namespace LAMMPS_NS
+
+#endif
+#endif

@@ -226,6 +226,97 @@ static constexpr float C_S3 = 1.7320508075688772f;
 static constexpr float C_P1 = 0.5773502691896258f;     // (1,1,0): sqrt(1) * w3j = 1/sqrt(3)
 static constexpr float C_P4 = 0.7071067811865476f;     // (1,1,1): sqrt(3) * w3j = eps_ijk / sqrt(2)
 
+// ---- streamed linear: continuous weight-fragment ring + epilogue under the next tile's MFMAs ----
+// The sequence of linears of a tile is static, so the 4-deep fragment ring never drains: while the last
+// 4 steps of one linear issue their MFMAs the ring is refilled with the FIRST 4 fragments of the next
+// linear (wo_next; they always sit at wo_next + j*256 because every streamed shape has >= 4 steps per
+// output tile).  Every streamed linear has a step count that is a multiple of 4, so the ring phase is 0 at
+// every call boundary (also across the runtime layer loop).  The element-wise epilogue of output tile t
+// (SiLU, save, scaling, SiLU') is executed in small chunks between the MFMA groups of tile t+1.
+struct EpiNone {
+  __device__ __forceinline__ void tile_done(int, const f32x16 &) const {}
+  __device__ __forceinline__ float apply(int, int, float v) const { return v; }
+};
+struct EpiSave {             // raw rows to scratch, value unchanged
+  __amdgpu_buffer_rsrc_t S; int row0, v16;
+  __device__ __forceinline__ void tile_done(int ot, const f32x16 &acc) const {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 x = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+      bstore(S, v16, ((row0 + ot) * ROW + q * 256) * 4, x);
+    }
+  }
+  __device__ __forceinline__ float apply(int, int, float v) const { return v; }
+};
+struct EpiSiluSave : EpiSave {   // raw rows to scratch, out = silu
+  __device__ __forceinline__ float apply(int, int, float v) const { return silu1(v); }
+};
+struct EpiSaveScale : EpiSave {  // raw rows to scratch, out = c * v
+  float c;
+  __device__ __forceinline__ float apply(int, int, float v) const { return c * v; }
+};
+template <int NT> struct EpiMulDsilu {       // out = v * silu'(z)
+  const f32x16 (&z)[NT];
+  __device__ __forceinline__ void tile_done(int, const f32x16 &) const {}
+  __device__ __forceinline__ float apply(int ot, int r, float v) const { return v * dsilu1(z[ot][r]); }
+};
+template <int NT> struct EpiResidual : EpiSave {   // raw u rows to scratch, out = ra * xold + rbf * u
+  const f32x16 (&xold)[NT]; float ra, rbf;
+  __device__ __forceinline__ float apply(int ot, int r, float v) const { return ra * xold[ot][r] + rbf * v; }
+};
+
+template <int KT, int NT, bool ACC, bool HAS_NEXT, class Epi>
+__device__ __forceinline__ void linear_s(__amdgpu_buffer_rsrc_t W, int wo, int wo_next, const f32x16 (&in)[KT],
+                                         f32x16 (&out)[NT], int v16, f32x4 (&ring)[4], const Epi &epi) {
+  constexpr int SPO = KT * 4, NS = NT * SPO;
+  f32x16 acc, prev;
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int ot = i / SPO, j = i % SPO, kt = j / 4, q = j % 4;
+    if (j == 0) {
+      if (ACC) acc = out[ot];
+      else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      }
+    }
+    const f32x4 a = ring[i % 4];
+    {
+      const int n = i + 4;
+      if (n < NS) ring[i % 4] = bload(W, v16, (wo + (((n / SPO) * KT + (n % SPO) / 4) * 4 + (n % SPO) % 4) * 256) * 4);
+      else if (HAS_NEXT) ring[i % 4] = bload(W, v16, (wo_next + (n - NS) * 256) * 4);
+    }
+    // The 4 MFMAs of a step form a dependent chain (64 cycles each): the wave stalls on each one, so the
+    // epilogue of the previous output tile is fed one register at a time INTO the gaps of the chain
+    // (one element every KT MFMAs), where it executes in the shadow of the MFMA just issued.
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      acc = mfma(a[c], in[kt][4 * q + c], acc);
+      if (ot > 0) {
+        const int idx = j * 4 + c;                 // MFMA index inside this output tile
+        if (idx % KT == 0) {
+          const int r = idx / KT;
+          out[ot - 1][r] = epi.apply(ot - 1, r, prev[r]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (j == SPO - 1) {
+      epi.tile_done(ot, acc);
+      if (ot == NT - 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[ot][r] = epi.apply(ot, r, acc[r]);
+      } else prev = acc;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// first 4 fragments of the linear at wo into the ring
+__device__ __forceinline__ void ring_prime(__amdgpu_buffer_rsrc_t W, int wo, int v16, f32x4 (&ring)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ring[j] = bload(W, v16, (wo + j * 256) * 4);
+}
+
 // Per-centre sum of the staged tile: dst[a][f] = scale * sum_{slots of a} stage[slot][f], f < 128.
 // 256 threads = 2 atoms x 128 features per pass; 4 independent accumulators keep 4 LDS reads in flight.
 __device__ __forceinline__ void reduce_stage(const Lds &lds, float *dst, int na, float scale, int tid) {
@@ -254,7 +345,7 @@ template <bool PROF>
 __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
   __shared__ Lds lds;
   const int tid = threadIdx.x, lane = tid & 63, slot = lane & 31, h = lane >> 5, wave = tid >> 6;
-  const int v16 = lane * 16, h16 = h * 16;
+  const int v16 = lane * 16;
   // wave-uniform buffer descriptors (made provably uniform with readfirstlane)
   __amdgpu_buffer_rsrc_t SB, WB;
   {
@@ -275,6 +366,8 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
     for (int k = 0; k < PH_N; ++k) pacc[k] = 0;
     tprev = clock64();
   }
+  f32x4 ring[4];                               // the weight-fragment stream (see linear_s)
+  ring_prime(WB, A.o_tb_w1, v16, ring);
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int a0 = A.tile_a0[tile], a1 = A.tile_a0[tile + 1];
@@ -310,14 +403,13 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
     const float PI = 3.14159265358979323846f;
     const float *const envrow = lds.env[0] + aloc * ENV_LD;        // + kk * MAXA*ENV_LD
     const float *const denvrow = lds.denv + aloc * ENV_LD;
-
     PHASE(PH_GEOM);
+
     // ---------------- two-body MLP ----------------
     f32x16 x[2];
     {
-      f32x16 z[2];
+      f32x16 z[2], z2[2];
       {
-        // per-type-pair rows: the fragment block is wave-uniform only per pair, so use per-lane offsets
         const float *pt = Wb + A.o_pair + (size_t)(ti * A.T + tj) * 64;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -333,35 +425,22 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float n = (float)(r + 4 * h + 1);
-#ifdef AHIP_PRECISE_SIN
-        bfin[0][r] = pref * sinf(PI * n * xx) * inv * fc;
-#else
-        bfin[0][r] = pref * __builtin_amdgcn_sinf(0.5f * n * xx) * inv * fc;
-#endif
+        bfin[0][r] = pref * __builtin_amdgcn_sinf(0.5f * n * xx) * inv * fc;    // revolutions: sin(pi n x)
       }
-      linear<1, 2, 1, true>(WB, A.o_tb_wc, bfin, z, v16);
+      linear<1, 2, 1, true, 2>(WB, A.o_tb_wc, bfin, z, v16);          // 2 steps only: own loads, not streamed
       save_rows<2>(SB, R_Z1TB(), z, v16);
       silu_inplace<2>(z);
-      f32x16 z2[2];
-      linear<2, 2>(WB, A.o_tb_w1, z, z2, v16);
-      save_rows<2>(SB, R_Z2TB(), z2, v16);
-      silu_inplace<2>(z2);
-      linear<2, 2>(WB, A.o_tb_w2, z2, z, v16);
-      save_rows<2>(SB, R_U0(), z, v16);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[t][r] = fc * z[t][r];
+      linear_s<2, 2, false, true>(WB, A.o_tb_w1, A.o_tb_w2, z, z2, v16, ring, EpiSiluSave{{SB, R_Z2TB(), v16}});
+      linear_s<2, 2, false, true>(WB, A.o_tb_w2, A.o_emb, z2, x, v16, ring, EpiSaveScale{{SB, R_U0(), v16}, fc});
     }
     PHASE(PH_TB);
     // ---------------- tensor embedding weights (V^0 = w0 (x) Y is rebuilt where needed) -------------
     {
       f32x16 w0[2];
-      linear<2, 2>(WB, A.o_emb, x, w0, v16);
-      save_rows<2>(SB, R_W0(), w0, v16);
+      linear_s<2, 2, false, true>(WB, A.o_emb, A.o_env[0], x, w0, v16, ring, EpiSave{SB, R_W0(), v16});
     }
-    __syncthreads();          // aoff visible; previous tile's LDS users done    PHASE(PH_EMB);
-
+    __syncthreads();          // aoff visible; previous tile's LDS users done
+    PHASE(PH_EMB);
 
     // ---------------- layers, forward ----------------
     for (int kk = 0; kk < NL; ++kk) {
@@ -371,14 +450,12 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
       f32x16 V[4], V0a[1], V1a[1];
       {
         f32x16 om[2];
-        linear<2, 2>(WB, A.o_env[kk], x, om, v16);
-        save_rows<2>(SB, RL + 0, om, v16);
+        linear_s<2, 2, false, true>(WB, A.o_env[kk], last ? A.o_lat0[kk] : A.o_mix[kk], x, om, v16, ring,
+                                    EpiSave{SB, RL + 0, v16});
         // prefetch V^{kk} (or w0 for the first layer) now: it lands while the environment is reduced
-#ifndef AHIP_NO_PF1
         if (kk > 0) load_rows<4>(SB, RL + 8, V, v16);
         else { load_rows<1>(SB, R_W0(), V0a, v16); load_rows<1>(SB, R_W0() + 1, V1a, v16); }
         __builtin_amdgcn_sched_barrier(0);
-#endif
         // environment sum over the centre's edges
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -392,10 +469,6 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
         reduce_stage(lds, envk, na, A.cenv, tid);
         __syncthreads();
       }
-#ifdef AHIP_NO_PF1
-      if (kk > 0) load_rows<4>(SB, RL + 8, V, v16);
-      else { load_rows<1>(SB, R_W0(), V0a, v16); load_rows<1>(SB, R_W0() + 1, V1a, v16); }
-#endif
       if (kk == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -405,7 +478,7 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
       }
       __builtin_amdgcn_sched_barrier(0);
       PHASE(PH_ENV);
-      // tensor product (4 registers per scheduling group: keeps the LDS reads from being hoisted en bloc)
+      // tensor product (4 registers per scheduling group)
       f32x16 Vp[4];
       {
         const float *en = envrow + kk * (MAXA * ENV_LD);
@@ -429,7 +502,6 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
       PHASE(PH_TP);
       // channel mixing -> V^{kk+1}, parked in the next layer's VIN rows
       if (!last) {
@@ -438,38 +510,30 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
 #pragma unroll
         for (int lm = 0; lm < 4; ++lm) {
           in1[0] = Vp[lm];
-          linear<1, 1>(WB, lm == 0 ? mx : mx + 1024, in1, out1, v16);
-          save_rows<1>(SB, R_LAYER(kk + 1) + 8 + lm, out1, v16);
+          linear_s<1, 1, false, true>(WB, lm == 0 ? mx : mx + 1024, lm == 3 ? A.o_lat0[kk] : mx + 1024, in1, out1, v16, ring,
+                                      EpiSave{SB, R_LAYER(kk + 1) + 8 + lm, v16});
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
       PHASE(PH_MIX);
       // latent MLP
       {
         f32x16 cat[3], z[2], z2[2];
         cat[0] = x[0]; cat[1] = x[1]; cat[2] = Vp[0];
-        linear<3, 2>(WB, A.o_lat0[kk], cat, z, v16);
-        save_rows<2>(SB, RL + 2, z, v16);
-        silu_inplace<2>(z);
-        linear<2, 2>(WB, A.o_lat1[kk], z, z2, v16);
-        save_rows<2>(SB, RL + 4, z2, v16);
-        silu_inplace<2>(z2);
-        linear<2, 2>(WB, A.o_lat2[kk], z2, z, v16);
-        save_rows<2>(SB, RL + 6, z, v16);
-        const float ra = Wb[A.o_res[kk]], rb = Wb[A.o_res[kk] + 1] * fc;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) x[t][r] = ra * x[t][r] + rb * z[t][r];
+        linear_s<3, 2, false, true>(WB, A.o_lat0[kk], A.o_lat1[kk], cat, z, v16, ring, EpiSiluSave{{SB, RL + 2, v16}});
+        linear_s<2, 2, false, true>(WB, A.o_lat1[kk], A.o_lat2[kk], z, z2, v16, ring, EpiSiluSave{{SB, RL + 4, v16}});
+        const float ra = Wb[A.o_res[kk]], rbf = Wb[A.o_res[kk] + 1] * fc;
+        f32x16 xn[2];
+        linear_s<2, 2, false, true>(WB, A.o_lat2[kk], last ? A.o_out0 : A.o_env[last ? kk : kk + 1], z2, xn, v16, ring,
+                                    EpiResidual<2>{{SB, RL + 6, v16}, x, ra, rbf});
+        x[0] = xn[0]; x[1] = xn[1];
       }
       PHASE(PH_LAT);
     }
 
-    PHASE(PH_LAT);
     // ---------------- read-out ----------------
     f32x16 zr[1];
-    linear<2, 1>(WB, A.o_out0, x, zr, v16);
-    const f32x16 wo1 = load_hvec(WB, A.o_out1, h16);
+    linear_s<2, 1, false, true>(WB, A.o_out0, A.o_out0T, x, zr, v16, ring, EpiNone{});
+    const f32x16 wo1 = load_hvec(WB, A.o_out1, h * 16);
     float eps = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) eps += silu1(zr[0][r]) * wo1[r];
@@ -477,16 +541,18 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
 
     // =========================== backward ===========================
     const float deps = valid ? Wb[A.o_scale + ti] * A.cenv : 0.f;
-    f32x16 dx[2];
+    f32x16 dx[2], upre[2];
+    load_rows<2>(SB, R_LAYER(NL - 1) + 6, upre, v16);     // u of the last layer, lands under the out0^T MFMAs
+    __builtin_amdgcn_sched_barrier(0);
     {
       f32x16 dzr[1];
 #pragma unroll
       for (int r = 0; r < 16; ++r) dzr[0][r] = deps * wo1[r] * dsilu1(zr[0][r]);
-      linear<1, 2>(WB, A.o_out0T, dzr, dx, v16);
+      linear_s<1, 2, false, true>(WB, A.o_out0T, A.o_lat2T[NL - 1], dzr, dx, v16, ring, EpiNone{});
     }
     float dfc_part = 0.f, dY1 = 0.f, dY2 = 0.f, dY3 = 0.f;
-
     PHASE(PH_OUT);
+
     for (int kk = NL - 1; kk >= 0; --kk) {
       const bool last = (kk == NL - 1);
       const int RL = R_LAYER(kk);
@@ -499,51 +565,29 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
 #pragma unroll
           for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              f32x4 u = bload(SB, v16, ((RL + 6 + t) * ROW + q * 256) * 4);
-              const float uu[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                const int r = 4 * q + c;
-                acc += uu[c] * dx[t][r];
-                du[t][r] = rb * fc * dx[t][r];
-                dx[t][r] = ra * dx[t][r];
-              }
+            for (int r = 0; r < 16; ++r) {
+              acc += upre[t][r] * dx[t][r];
+              du[t][r] = rb * fc * dx[t][r];
+              dx[t][r] = ra * dx[t][r];
             }
           dfc_part += rb * acc;
         }
-#ifdef AHIP_OLD_ZT
-        linear<2, 2>(WB, A.o_lat2T[kk], du, dh, v16);
-        mul_dsilu_rows<2>(SB, RL + 4, dh, v16);
-        linear<2, 2>(WB, A.o_lat1T[kk], dh, du, v16);
-        mul_dsilu_rows<2>(SB, RL + 2, du, v16);
-#else
-        f32x16 zt[2];
+        f32x16 zt[2], zt1[2];
         load_rows<2>(SB, RL + 4, zt, v16);                   // z2, lands under the next 64 MFMAs
+        load_rows<2>(SB, RL + 2, zt1, v16);                  // z1
         __builtin_amdgcn_sched_barrier(0);
-        linear<2, 2>(WB, A.o_lat2T[kk], du, dh, v16);
-        mul_dsilu<2>(dh, zt);
-        load_rows<2>(SB, RL + 2, zt, v16);                   // z1
-        __builtin_amdgcn_sched_barrier(0);
-        linear<2, 2>(WB, A.o_lat1T[kk], dh, du, v16);
-        mul_dsilu<2>(du, zt);
-#endif
-        // prefetch V^{kk} (input of this layer's tensor product) under the 96 MFMAs of lat0^T
-#ifndef AHIP_NO_PF2
+        linear_s<2, 2, false, true>(WB, A.o_lat2T[kk], A.o_lat1T[kk], du, dh, v16, ring, EpiMulDsilu<2>{zt});
+        // prefetch V^{kk} (input of this layer's tensor product) under the MFMAs that follow
         if (kk > 0) load_rows<4>(SB, RL + 8, Vk, v16);
         else { load_rows<1>(SB, R_W0(), V0b, v16); load_rows<1>(SB, R_W0() + 1, V1b, v16); }
         __builtin_amdgcn_sched_barrier(0);
-#endif
+        linear_s<2, 2, false, true>(WB, A.o_lat1T[kk], A.o_lat0T[kk], dh, du, v16, ring, EpiMulDsilu<2>{zt1});
         f32x16 dcat[3];
-        linear<2, 3>(WB, A.o_lat0T[kk], du, dcat, v16);
+        linear_s<2, 3, false, true>(WB, A.o_lat0T[kk], last ? A.o_envT[kk] : A.o_mixT[kk], du, dcat, v16, ring, EpiNone{});
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dx[0][r] += dcat[0][r]; dx[1][r] += dcat[1][r]; }
         dVp[0] = dcat[2];                                   // ds
       }
-#ifdef AHIP_NO_PF2
-      if (kk > 0) load_rows<4>(SB, RL + 8, Vk, v16);
-      else { load_rows<1>(SB, R_W0(), V0b, v16); load_rows<1>(SB, R_W0() + 1, V1b, v16); }
-#endif
       if (kk == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -559,7 +603,7 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
 #pragma unroll
         for (int lm = 0; lm < 4; ++lm) {
           load_rows<1>(SB, R_DV() + lm, in1, v16);
-          linear<1, 1>(WB, lm == 0 ? mx : mx + 1024, in1, out1, v16);
+          linear_s<1, 1, false, true>(WB, lm == 0 ? mx : mx + 1024, lm == 3 ? A.o_envT[kk] : mx + 1024, in1, out1, v16, ring, EpiNone{});
           if (lm == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) dVp[0][r] += out1[0][r];
@@ -630,11 +674,12 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        linear<2, 2, 4, true>(WB, A.o_envT[kk], dom, dx, v16);
+        if (kk > 0) load_rows<2>(SB, R_LAYER(kk - 1) + 6, upre, v16);     // next iteration's u rows
+        __builtin_amdgcn_sched_barrier(0);
+        linear_s<2, 2, true, true>(WB, A.o_envT[kk], kk > 0 ? A.o_lat2T[kk > 0 ? kk - 1 : 0] : A.o_embT, dom, dx, v16, ring, EpiNone{});
       }
       PHASE(PH_BENV);
     }
-    PHASE(PH_BENV);
     // ---------------- embedding backward ----------------
     {
       f32x16 dV[4], w0[2], dw0[2];
@@ -646,7 +691,7 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
         dw0[1][r] = dV[1][r] * Y1 + dV[2][r] * Y2 + dV[3][r] * Y3;
         dY1 += dV[1][r] * w0[1][r]; dY2 += dV[2][r] * w0[1][r]; dY3 += dV[3][r] * w0[1][r];
       }
-      linear<2, 2, 4, true>(WB, A.o_embT, dw0, dx, v16);
+      linear_s<2, 2, true, true>(WB, A.o_embT, A.o_tb_w2T, dw0, dx, v16, ring, EpiNone{});
     }
     PHASE(PH_BEMB);
     // ---------------- two-body MLP backward ----------------
@@ -664,34 +709,20 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
           for (int c = 0; c < 4; ++c) { acc += uu[c] * dx[t][4 * q + c]; du[t][4 * q + c] = fc * dx[t][4 * q + c]; }
         }
       dfc_part += acc;
-#ifdef AHIP_OLD_ZT
-      linear<2, 2>(WB, A.o_tb_w2T, du, dh, v16);
-      mul_dsilu_rows<2>(SB, R_Z2TB(), dh, v16);
-      linear<2, 2>(WB, A.o_tb_w1T, dh, du, v16);
-      mul_dsilu_rows<2>(SB, R_Z1TB(), du, v16);
-#else
-      f32x16 zt[2];
+      f32x16 zt[2], zt1[2];
       load_rows<2>(SB, R_Z2TB(), zt, v16);
+      load_rows<2>(SB, R_Z1TB(), zt1, v16);
       __builtin_amdgcn_sched_barrier(0);
-      linear<2, 2>(WB, A.o_tb_w2T, du, dh, v16);
-      mul_dsilu<2>(dh, zt);
-      load_rows<2>(SB, R_Z1TB(), zt, v16);
-      __builtin_amdgcn_sched_barrier(0);
-      linear<2, 2>(WB, A.o_tb_w1T, dh, du, v16);
-      mul_dsilu<2>(du, zt);
-#endif
+      linear_s<2, 2, false, true>(WB, A.o_tb_w2T, A.o_tb_w1T, du, dh, v16, ring, EpiMulDsilu<2>{zt});
+      linear_s<2, 2, false, true>(WB, A.o_tb_w1T, A.o_tb_wcT, dh, du, v16, ring, EpiMulDsilu<2>{zt1});
       f32x16 dbf[1];
-      linear<2, 1>(WB, A.o_tb_wcT, du, dbf, v16);
+      linear_s<2, 1, false, true>(WB, A.o_tb_wcT, A.o_tb_w1, du, dbf, v16, ring, EpiNone{});   // next = next tile's first linear
       const float dfdd = dfc_dx / rc;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float n = (float)(r + 4 * h + 1);
         // argument in revolutions for v_sin/v_cos (|arg| <= 4): abs error ~1e-6, far inside the force budget
-#ifdef AHIP_PRECISE_SIN
-        float sn, cs; sincosf(PI * n * xx, &sn, &cs);
-#else
         const float sn = __builtin_amdgcn_sinf(0.5f * n * xx), cs = __builtin_amdgcn_cosf(0.5f * n * xx);
-#endif
         const float b = pref * sn * inv;
         const float db = pref * (cs * PI * n / rc * inv - sn * inv * inv);
         dd_part += dbf[0][r] * (db * fc + b * dfdd);

@@ -140,10 +140,14 @@ def main():
         stage_avg = {k: float(np.mean(v)) for k, v in stage_ms.items()}
         dom = max((k for k in stage_avg if k.startswith("model")), key=lambda k: stage_avg[k], default=None)
         roof = None
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")      # measured in a separate PMC run (cannot be collected live)
+        if os.path.exists(tj) and used_path == "fused_f32" and natoms == 1000000 and world == 1:
+            traffic = json.load(open(tj))["traffic_bytes_per_launch"]
         if dom is not None:
             ach = flops_per_edge * edges_rank0 / (stage_avg[dom] * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": 157.3, "unit": "TFLOP/s",
-                    "frac": round(ach / 157.3, 4), "traffic": None, "kernel": dom,
+                    "frac": round(ach / 157.3, 4), "traffic": traffic, "kernel": dom,
                     "avg_ms": round(stage_avg[dom], 3), "edges_per_launch": edges_rank0,
                     "flops_per_edge": flops_per_edge}
         # ---- CPU baseline + max|dF| on a bounded sample --------------------------------------

@@ -38,7 +38,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int TILE_SLOTS = 128;
-static constexpr int MAXA = 16;          // centre atoms per tile
+static constexpr int MAXA = 12;          // centre atoms per tile (LDS budget: env rows + the 64 KiB park region)
 static constexpr int MAXNL = 3;
 static constexpr int STG_LD = 129;       // staging leading dimension: all 128 features of a slot (odd -> conflict-free)
 static constexpr int ENV_LD = 129;       // per-atom environment row
@@ -77,6 +77,7 @@ struct __attribute__((aligned(16))) Lds {
   float env[MAXNL][MAXA * ENV_LD];
   float denv[MAXA * ENV_LD];
   float tp[MAXNL][5 * 32];                // tensor-product path weights [layer][path][u]
+  float park[4][4 * ROW];                 // per-wave private park: 4 register images (V^{k+1} forward, dE/dV backward)
   float vir[4][8];                        // per-wave virial partials
   float ea[MAXA];
   int aoff[MAXA + 2];
@@ -192,6 +193,22 @@ template <int NT> __device__ __forceinline__ void mul_dsilu_rows(__amdgpu_buffer
     }
 }
 
+// wave-private LDS park rows, same [q][lane][4] image as the scratch rows (16 B per lane, conflict-free)
+__device__ __forceinline__ void park_store(float *pk, int row, const f32x16 &v, int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 x = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    *(f32x4 *)(pk + row * ROW + q * 256 + lane * 4) = x;
+  }
+}
+__device__ __forceinline__ void park_load(const float *pk, int row, f32x16 &v, int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 x = *(const f32x4 *)(pk + row * ROW + q * 256 + lane * 4);
+    v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+  }
+}
+
 // per-half small vectors stored as [q][h][4]; h16 = h * 16 bytes
 __device__ __forceinline__ f32x16 load_hvec(__amdgpu_buffer_rsrc_t W, int wo, int h16) {
   f32x16 v;
@@ -247,6 +264,13 @@ struct EpiSave {             // raw rows to scratch, value unchanged
     }
   }
   __device__ __forceinline__ float apply(int, int, float v) const { return v; }
+};
+struct EpiSavePark : EpiSave {  // raw rows to scratch (for the backward pass) and to the LDS park (next layer's forward)
+  float *pk; int prow, lane;
+  __device__ __forceinline__ void tile_done(int ot, const f32x16 &acc) const {
+    EpiSave::tile_done(ot, acc);
+    park_store(pk, prow + ot, acc, lane);
+  }
 };
 struct EpiSiluSave : EpiSave {   // raw rows to scratch, out = silu
   __device__ __forceinline__ float apply(int, int, float v) const { return silu1(v); }
@@ -366,6 +390,7 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
     for (int k = 0; k < PH_N; ++k) pacc[k] = 0;
     tprev = clock64();
   }
+  float *const pk = lds.park[wave];
   f32x4 ring[4];                               // the weight-fragment stream (see linear_s)
   ring_prime(WB, A.o_tb_w1, v16, ring);
 
@@ -453,8 +478,7 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
         linear_s<2, 2, false, true>(WB, A.o_env[kk], last ? A.o_lat0[kk] : A.o_mix[kk], x, om, v16, ring,
                                     EpiSave{SB, RL + 0, v16});
         // prefetch V^{kk} (or w0 for the first layer) now: it lands while the environment is reduced
-        if (kk > 0) load_rows<4>(SB, RL + 8, V, v16);
-        else { load_rows<1>(SB, R_W0(), V0a, v16); load_rows<1>(SB, R_W0() + 1, V1a, v16); }
+        if (kk == 0) { load_rows<1>(SB, R_W0(), V0a, v16); load_rows<1>(SB, R_W0() + 1, V1a, v16); }
         __builtin_amdgcn_sched_barrier(0);
         // environment sum over the centre's edges
 #pragma unroll
@@ -475,6 +499,9 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
           const float w1 = V1a[0][r];
           V[0][r] = V0a[0][r]; V[1][r] = w1 * Y1; V[2][r] = w1 * Y2; V[3][r] = w1 * Y3;
         }
+      } else {
+#pragma unroll
+        for (int lm = 0; lm < 4; ++lm) park_load(pk, lm, V[lm], lane);      // V^{kk} parked by the previous layer's mix
       }
       __builtin_amdgcn_sched_barrier(0);
       PHASE(PH_ENV);
@@ -511,7 +538,7 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
         for (int lm = 0; lm < 4; ++lm) {
           in1[0] = Vp[lm];
           linear_s<1, 1, false, true>(WB, lm == 0 ? mx : mx + 1024, lm == 3 ? A.o_lat0[kk] : mx + 1024, in1, out1, v16, ring,
-                                      EpiSave{SB, R_LAYER(kk + 1) + 8 + lm, v16});
+                                      EpiSavePark{{SB, R_LAYER(kk + 1) + 8 + lm, v16}, pk, lm, lane});
         }
       }
       PHASE(PH_MIX);
@@ -602,7 +629,7 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
         f32x16 in1[1], out1[1];
 #pragma unroll
         for (int lm = 0; lm < 4; ++lm) {
-          load_rows<1>(SB, R_DV() + lm, in1, v16);
+          park_load(pk, lm, in1[0], lane);
           linear_s<1, 1, false, true>(WB, lm == 0 ? mx : mx + 1024, lm == 3 ? A.o_envT[kk] : mx + 1024, in1, out1, v16, ring, EpiNone{});
           if (lm == 0) {
 #pragma unroll
@@ -645,10 +672,10 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
             o0[c] = a0v; o1[c] = a1v; o2[c] = a2v; o3[c] = a3v;
             st[fidx] = b0v; st[32 + fidx] = b1v; st[64 + fidx] = b2v; st[96 + fidx] = b3v;
           }
-          bstore(SB, v16, ((R_DV() + 0) * ROW + q * 256) * 4, o0);
-          bstore(SB, v16, ((R_DV() + 1) * ROW + q * 256) * 4, o1);
-          bstore(SB, v16, ((R_DV() + 2) * ROW + q * 256) * 4, o2);
-          bstore(SB, v16, ((R_DV() + 3) * ROW + q * 256) * 4, o3);
+          *(f32x4 *)(pk + 0 * ROW + q * 256 + lane * 4) = o0;
+          *(f32x4 *)(pk + 1 * ROW + q * 256 + lane * 4) = o1;
+          *(f32x4 *)(pk + 2 * ROW + q * 256 + lane * 4) = o2;
+          *(f32x4 *)(pk + 3 * ROW + q * 256 + lane * 4) = o3;
           __builtin_amdgcn_sched_barrier(0);
         }
         load_rows<2>(SB, RL + 0, om, v16);                   // omega of this layer, lands during the reduction
@@ -683,8 +710,9 @@ __global__ void __launch_bounds__(256, 1) k_fused(FusedArgs A) {
     // ---------------- embedding backward ----------------
     {
       f32x16 dV[4], w0[2], dw0[2];
-      load_rows<4>(SB, R_DV(), dV, v16);
       load_rows<2>(SB, R_W0(), w0, v16);
+#pragma unroll
+      for (int lm = 0; lm < 4; ++lm) park_load(pk, lm, dV[lm], lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         dw0[0][r] = dV[0][r];

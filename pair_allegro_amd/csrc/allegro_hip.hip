@@ -349,6 +349,7 @@ int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const i
     AHIP_CHECK(hipMemcpyAsync(m->b_ftype.p, m->h_ftype.data(), (size_t)nall * sizeof(int), hipMemcpyHostToDevice, s));
     AHIP_CHECK(hipMemcpyAsync(m->b_mtype.p, m->h_mtype.data(), (size_t)nall * sizeof(int), hipMemcpyHostToDevice, s));
     AHIP_CHECK(hipMemcpyAsync(m->b_cutsq.p, cutsq.data(), cutsq.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    m->h_cutsq_dev.clear();
     AHIP_CHECK(hipMemsetAsync(m->b_f.p, 0, (size_t)nall * 3 * sizeof(double), s));
     if (eatom) AHIP_CHECK(hipMemsetAsync(m->b_eatom.p, 0, (size_t)nall * sizeof(double), s));
 
@@ -393,9 +394,12 @@ int ahip_compute_dev(ahip_model *m, int nlocal, int nghost, const double *x_dev,
       double c = cutoff_matrix_model ? cutoff_matrix_model[k] : m->rcut_model_host[k];
       cutsq[k] = c * c;
     }
-    m->b_cutsq.reserve(cutsq.size() * sizeof(double));
-    AHIP_CHECK(hipMemcpyAsync(m->b_cutsq.p, cutsq.data(), cutsq.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    AHIP_CHECK(hipStreamSynchronize(s));                     // cutsq is a stack vector
+    if (cutsq != m->h_cutsq_dev) {                           // upload (and synchronise) only when the matrix changes
+      m->b_cutsq.reserve(cutsq.size() * sizeof(double));
+      AHIP_CHECK(hipMemcpyAsync(m->b_cutsq.p, cutsq.data(), cutsq.size() * sizeof(double), hipMemcpyHostToDevice, s));
+      AHIP_CHECK(hipStreamSynchronize(s));                   // cutsq is a stack vector
+      m->h_cutsq_dev = cutsq;
+    }
     ComputeArgs a{nlocal, nghost, x_dev, mtype_dev, m->b_cutsq.as<double>(), T, mtype_dev, f_dev, eatom_dev, eng_vir_dev, s};
     run_model(m, a);
     collect_timings(m);

@@ -105,7 +105,7 @@ struct Model {
   // per-call host-path staging
   DevBuf b_x, b_ftype, b_mtype, b_f, b_eatom, b_engvir, b_cutsq;
   std::vector<int> h_ftype, h_mtype;
-  std::vector<double> h_f, h_eatom;
+  std::vector<double> h_f, h_eatom, h_cutsq_dev;      // h_cutsq_dev: what b_cutsq currently holds (device path)
 
   // edge list + workspace
   DevBuf b_cnt, b_eoff, b_eii, b_ej, b_rvec, b_partial, b_ws, b_misc;

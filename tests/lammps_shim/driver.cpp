@@ -1,0 +1,67 @@
+// TEST INFRASTRUCTURE ONLY: drives PairAllegroHIP through the LAMMPS call sequence
+// (settings -> coeff -> init_style -> init_one -> compute) on a system read from a flat binary file
+// written by tests/test_lammps_cpp.py, and writes forces / energy / virial back.
+#include "pair_allegro_hip.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace LAMMPS_NS;
+
+template <typename T> static std::vector<T> rd(FILE *f, size_t n) { std::vector<T> v(n); if (n && fread(v.data(), sizeof(T), n, f) != n) { perror("read"); exit(3); } return v; }
+
+int main(int argc, char **argv) {
+  if (argc < 5) { fprintf(stderr, "usage: driver system.bin out.bin model names...\n"); return 2; }
+  FILE *f = fopen(argv[1], "rb");
+  int hdr[4];
+  if (!f || fread(hdr, sizeof(int), 4, f) != 4) return 3;
+  const int nlocal = hdr[0], nghost = hdr[1], ntypes = hdr[2], nneigh = hdr[3], nall = nlocal + nghost;
+  auto x = rd<double>(f, (size_t)nall * 3);
+  auto type = rd<int>(f, nall);
+  auto tag = rd<int>(f, nall);
+  auto numneigh = rd<int>(f, nall);
+  auto flat = rd<int>(f, nneigh);
+  fclose(f);
+  std::vector<double> fr((size_t)nall * 3, 0.0), eatom(nall, 0.0);
+  std::vector<double *> xp(nall), fp(nall);
+  std::vector<int *> first(nall);
+  std::vector<int> ilist(nlocal);
+  size_t off = 0;
+  for (int i = 0; i < nall; i++) { xp[i] = &x[3 * (size_t)i]; fp[i] = &fr[3 * (size_t)i]; first[i] = flat.data() + off; off += numneigh[i]; }
+  for (int i = 0; i < nlocal; i++) ilist[i] = i;
+
+  Atom atom; Comm comm; Force force; Neighbor neighbor; Error error; Memory memory; NeighList list;
+  LAMMPS lmp{&atom, &comm, &force, &neighbor, &error, &memory};
+  atom.ntypes = ntypes; atom.nlocal = nlocal; atom.nghost = nghost; atom.x = xp.data(); atom.f = fp.data(); atom.type = type.data(); atom.tag = tag.data();
+  list.inum = nlocal; list.gnum = nghost; list.ilist = ilist.data(); list.numneigh = numneigh.data(); list.firstneigh = first.data();
+  int rc = 0;
+  try {
+    PairAllegroHIP pair(&lmp);
+    pair.list = &list;
+    pair.eatom = eatom.data();
+    pair.settings(0, nullptr);
+    std::vector<char *> args;
+    char star[] = "*";
+    args.push_back(star); args.push_back(star);
+    for (int k = 3; k < argc; k++) args.push_back(argv[k]);
+    pair.coeff((int)args.size(), args.data());
+    pair.init_style();
+    if (neighbor.requested != (NeighConst::REQ_FULL | NeighConst::REQ_GHOST)) { fprintf(stderr, "bad neighbor request\n"); return 4; }
+    const double cut = pair.init_one(1, 1);
+    neighbor.lastcall = 1;
+    pair.compute(3, 2);                     // eflag global+atom, vflag global
+    pair.compute(3, 2);                     // second step on the same list: forces must be ADDED again
+    FILE *o = fopen(argv[2], "wb");
+    fwrite(&cut, sizeof(double), 1, o);
+    fwrite(&pair.eng_vdwl, sizeof(double), 1, o);
+    fwrite(pair.virial, sizeof(double), 6, o);
+    fwrite(fr.data(), sizeof(double), fr.size(), o);
+    fwrite(eatom.data(), sizeof(double), eatom.size(), o);
+    fclose(o);
+    printf("restartinfo=%d manybody=%d no_fdotr=%d setflag11=%d\n", pair.restartinfo, pair.manybody_flag, pair.no_virial_fdotr_compute, pair.setflag[1][1]);
+  } catch (const LammpsAbort &e) { printf("LAMMPS error->all: %s\n", e.what()); rc = 10; }
+  catch (const std::exception &e) { printf("exception: %s\n", e.what()); rc = 11; }
+  return rc;
+}

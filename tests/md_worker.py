@@ -9,9 +9,9 @@ import torch.distributed as dist
 from pair_allegro_amd import capi, lmp_like, md, model_file
 
 
-def run(lib, path, cell, pos, vel, cfg, grid, rank, d, nsteps):
+def run(lib, path, cell, pos, vel, cfg, grid, rank, d, nsteps, skin=1.0):
     model = capi.Model(path, 0, lib)
-    sim = md.Simulation(md.HipBackend(model, [28.0855]), np.diag(cell), cfg["r_max"], 1.0, pos, np.zeros(len(pos), np.int32),
+    sim = md.Simulation(md.HipBackend(model, [28.0855]), np.diag(cell), cfg["r_max"], skin, pos, np.zeros(len(pos), np.int32),
                         vel, torch.device("cpu"), grid=grid, rank=rank, dist=d, dt=0.001)
     sim.setup()
     f = sim.gather_forces()
@@ -22,14 +22,21 @@ def run(lib, path, cell, pos, vel, cfg, grid, rank, d, nsteps):
     if d is not None and sim.nranks > 1:
         d.all_reduce(x)
     e = sim.thermo([28.0855])["pe"]
+    nreb = sim.nrebuild
+    nloc = sim.nlocal
     model.close()
-    return f, x.numpy(), e
+    return f, x.numpy(), e, nreb, nloc
 
 
 def main():
     out, libpath, model_dir = sys.argv[1:4]
+    temperature = float(sys.argv[4]) if len(sys.argv) > 4 else 300.0
+    nsteps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+    skin = float(sys.argv[6]) if len(sys.argv) > 6 else 1.0
     dist.init_process_group(backend="gloo")
     rank = dist.get_rank()
+    world = dist.get_world_size()
+    grid = md.choose_grid(world)
     lib = capi.Library(libpath)
     cfg = model_file.model_S(model_dtype="float64", num_scalar_features=16, num_tensor_features=8, mlp_width=16,
                              readout_width=8, avg_num_neighbors=28.0)
@@ -37,14 +44,16 @@ def main():
     path = os.path.join(model_dir, f"md_small_r{rank}.ahip")
     model_file.save_ahip(path, cfg, w)
     cell, pos, _ = lmp_like.diamond_si(3)
-    vel = md.maxwell_boltzmann(len(pos), np.full(len(pos), 28.0855), 300.0, 12345)
-    f2, x2, e2 = run(lib, path, cell, pos, vel, cfg, (2, 1, 1), rank, dist, 3)
+    vel = md.maxwell_boltzmann(len(pos), np.full(len(pos), 28.0855), temperature, 12345)
+    f2, x2, e2, nreb, nloc = run(lib, path, cell, pos, vel, cfg, grid, rank, dist, nsteps, skin)
+    nl = torch.tensor([nloc]); dist.all_reduce(nl)
+    assert int(nl.item()) == len(pos), "atoms lost or duplicated in migration"
     if rank == 0:
-        f1, x1, e1 = run(lib, path, cell, pos, vel, cfg, (1, 1, 1), 0, None, 3)
+        f1, x1, e1, nreb1, _ = run(lib, path, cell, pos, vel, cfg, (1, 1, 1), 0, None, nsteps, skin)
         box = np.diag(cell)
         x1 = x1 - np.floor(x1 / box) * box
         x2 = x2 - np.floor(x2 / box) * box
-        np.savez(out, f1=f1, f2=f2, x1=x1, x2=x2, e1=e1, e2=e2)
+        np.savez(out, f1=f1, f2=f2, x1=x1, x2=x2, e1=e1, e2=e2, nreb=nreb, nreb1=nreb1)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -46,17 +46,32 @@ def test_single_rank_forces_and_energy_conservation(emu_lib, model_dir):
     model.close()
 
 
-def test_world_size_2_gloo_matches_single_rank(emu_lib, model_dir, tmp_path):
-    """Two processes (gloo), 2x1x1 bricks: forces after setup and positions after 3 steps equal the
-    single-rank run; exercises borders, forward and reverse comm across ranks."""
-    out = tmp_path / "mr.npz"
+def _run_workers(emu_lib, model_dir, tmp_path, world, port, extra=()):
+    out = tmp_path / f"mr{world}.npz"
     worker = os.path.join(ROOT, "tests", "md_worker.py")
-    env = dict(os.environ, PYTHONPATH=ROOT + ":" + os.path.join(ROOT, "tests"), MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29731", worker, str(out), emu_lib.path, model_dir]
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    env = dict(os.environ, PYTHONPATH=ROOT + ":" + os.path.join(ROOT, "tests"), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), worker, str(out), emu_lib.path, model_dir] + [str(e) for e in extra]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
-    z = np.load(out)
+    return np.load(out)
+
+
+@pytest.mark.parametrize("world,port", [(2, 29731), (4, 29733), (8, 29735)])
+def test_gloo_ranks_match_single_rank(emu_lib, model_dir, tmp_path, world, port):
+    """2 / 4 / 8 processes (gloo) on 2x1x1 / 2x2x1 / 2x2x2 bricks -- the grids bench.py uses on 2 / 4 / 8 GPUs:
+    forces after setup, positions and energy after 3 steps equal the single-rank run (borders, forward and
+    reverse communication across ranks and across periodic self-images)."""
+    z = _run_workers(emu_lib, model_dir, tmp_path, world, port)
     np.testing.assert_allclose(z["f2"], z["f1"], atol=1e-10)
     np.testing.assert_allclose(z["x2"], z["x1"], atol=1e-12)
     np.testing.assert_allclose(z["e2"], z["e1"], rtol=1e-12)
+
+
+def test_gloo_rebuild_and_migration(emu_lib, model_dir, tmp_path):
+    """Hot system (6000 K), skin 0.2 A, 40 steps on 2x2x1 bricks: several re-neighborings, atoms cross brick
+    faces (migration) -- no atom lost, trajectory equals the single-rank run."""
+    z = _run_workers(emu_lib, model_dir, tmp_path, 4, 29737, extra=(6000.0, 40, 0.2))
+    assert int(z["nreb"]) >= 3 and int(z["nreb1"]) >= 3
+    np.testing.assert_allclose(z["x2"], z["x1"], atol=1e-8)
+    np.testing.assert_allclose(z["e2"], z["e1"], rtol=1e-9)

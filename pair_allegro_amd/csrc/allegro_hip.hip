@@ -127,6 +127,7 @@ void ahip_model_free(ahip_model *m) {
   (void)hipDeviceSynchronize();
   fused_free(*m);
   neigh_free(*m);
+  edges_free(*m);
   free_weights(m->wf);
   free_weights(m->wd);
   if (m->cg_dev) (void)hipFree(m->cg_dev);
@@ -297,7 +298,7 @@ static void run_model(ahip_model *m, const ComputeArgs &a) {
     m->last_path = "generic_f64";
     return;
   }
-  build_edges<float>(*m, a);
+  if (!edges_build_f32(*m, a)) build_edges<float>(*m, a);
   std::string why;
   bool fused_ok = false;
   if (m->opt_path != "generic") {

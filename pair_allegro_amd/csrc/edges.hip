@@ -1,0 +1,189 @@
+// Single-pass edge build for the float32 production path: cutoff filter of the skin-inflated full
+// neighbor list + CSR->COO expansion (reference: preprocess() passes 1+2, /root/reference/
+// pair_nequip_allegro.cpp:488-512,566-629; Kokkos K1,K2,K5, pair_nequip_allegro_kokkos.cpp:165-258).
+//
+//  * one wave per centre row: the row's neighbour indices are read coalesced (64 per instruction), the
+//    gathered x_j / type_j are the only random traffic; `rsq <= cut^2` in float64 (host-path semantics);
+//  * survivors are compacted with ballot/mbcnt and kept in registers (8 centres per wave);
+//  * the global edge offsets come from a decoupled look-back scan over 32-centre blocks (block order taken
+//    from an atomic ticket, so a block's predecessors have always started), so the neighbour data is
+//    gathered ONCE -- the two-pass version (generic_kernels.h) gathers it twice;
+//  * every block then writes its edges to one contiguous range of e_ii / e_j / rvec.
+// Output layout is identical to k_count_edges + scan + k_fill_edges: edges grouped by centre, list order.
+// Rows longer than 128 entries raise the overflow flag and the caller re-runs the two-pass kernels.
+#include <hip/hip_runtime.h>
+
+#include "engine.h"
+
+namespace ahip {
+
+static constexpr int EB_ATOMS = 32;      // centres per block
+static constexpr int EB_PER_WAVE = 8;    // centres per wave
+static constexpr int EB_CHUNKS = 2;      // 64-entry chunks per row held in registers
+
+__device__ __forceinline__ unsigned long long pack_state(unsigned long long state, unsigned long long v) { return (state << 62) | v; }
+
+__global__ void __launch_bounds__(256) k_build_edges(int inum, const int *__restrict__ ilist, const int *__restrict__ nl_off,
+                                                       const int *__restrict__ nl_j, const double *__restrict__ x,
+                                                       const int *__restrict__ ftype, const double *__restrict__ cutsq, int nft,
+                                                       unsigned int *ticket, unsigned long long *status, int *eoff, int *e_ii,
+                                                       int *e_j, float *rvec, int *maxdeg, int *overflow) {
+  __shared__ int s_cnt[EB_ATOMS];
+  __shared__ int s_base[EB_ATOMS + 1];
+  __shared__ int s_blk;
+  __shared__ long long s_prefix;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_blk = (int)atomicAdd(ticket, 1u);
+  __syncthreads();
+  const int b = s_blk;
+  const int a_begin = b * EB_ATOMS;
+
+  // ---- gather + filter: results stay in registers -------------------------------------------------
+  int jj[EB_PER_WAVE][EB_CHUNKS];
+  float dxs[EB_PER_WAVE][EB_CHUNKS], dys[EB_PER_WAVE][EB_CHUNKS], dzs[EB_PER_WAVE][EB_CHUNKS];
+  int rank[EB_PER_WAVE][EB_CHUNKS];      // -1 = dropped, else position inside the centre's edge range
+  int kept_k[EB_PER_WAVE];
+#pragma unroll
+  for (int k = 0; k < EB_PER_WAVE; ++k) {
+    const int la = wave * EB_PER_WAVE + k;
+    const int ii = a_begin + la;
+    int kept = 0;
+    if (ii < inum) {
+      const int i = ilist[ii];
+      const double xi = x[3 * (size_t)i], yi = x[3 * (size_t)i + 1], zi = x[3 * (size_t)i + 2];
+      const double *crow = cutsq + (size_t)ftype[i] * nft;
+      const int p0 = nl_off[ii], p1 = nl_off[ii + 1];
+      if (p1 - p0 > 64 * EB_CHUNKS && lane == 0) atomicOr(overflow, 1);
+#pragma unroll
+      for (int c = 0; c < EB_CHUNKS; ++c) {
+        const int p = p0 + c * 64 + lane;
+        const bool valid = p < p1;
+        int j = 0;
+        bool keep = false;
+        float fx = 0.f, fy = 0.f, fz = 0.f;
+        if (valid) {
+          j = nl_j[p];
+          const double ddx = x[3 * (size_t)j] - xi, ddy = x[3 * (size_t)j + 1] - yi, ddz = x[3 * (size_t)j + 2] - zi;
+          const double rsq = ddx * ddx + ddy * ddy + ddz * ddz;
+          keep = rsq <= crow[ftype[j]];
+          fx = (float)ddx; fy = (float)ddy; fz = (float)ddz;       // neighbour - centre, f64 difference cast to f32
+        }
+        const unsigned long long mask = __ballot(keep);
+        const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+        jj[k][c] = j; dxs[k][c] = fx; dys[k][c] = fy; dzs[k][c] = fz;
+        rank[k][c] = keep ? kept + below : -1;
+        kept += __popcll(mask);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < EB_CHUNKS; ++c) { jj[k][c] = 0; dxs[k][c] = dys[k][c] = dzs[k][c] = 0.f; rank[k][c] = -1; }
+    }
+    kept_k[k] = kept;
+    if (lane == 0) s_cnt[la] = kept;
+  }
+  __syncthreads();
+
+  // ---- block scan of the 32 counts, then decoupled look-back for the block's global offset ----------
+  if (tid < 64) {
+    int v = tid < EB_ATOMS ? s_cnt[tid] : 0;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      int t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    if (tid < EB_ATOMS) s_base[tid + 1] = inc;
+    if (tid == 0) s_base[0] = 0;
+    int mx = v;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+    if (tid == 0 && mx > 0) atomicMax(maxdeg, mx);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned long long agg = (unsigned long long)s_base[EB_ATOMS];
+    unsigned long long prefix = 0;
+    if (b == 0) {
+      __hip_atomic_store(&status[0], pack_state(2, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __hip_atomic_store(&status[b], pack_state(1, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int k = b - 1;; --k) {
+        unsigned long long v;
+        do {
+          v = __hip_atomic_load(&status[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((v >> 62) == 0) __builtin_amdgcn_s_sleep(1);
+        } while ((v >> 62) == 0);
+        prefix += v & ((1ull << 62) - 1);
+        if ((v >> 62) == 2) break;
+      }
+      __hip_atomic_store(&status[b], pack_state(2, prefix + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_prefix = (long long)prefix;
+  }
+  __syncthreads();
+  const long long gbase = s_prefix;
+
+  // ---- offsets + edges -------------------------------------------------------------------------------
+  if (tid < EB_ATOMS && a_begin + tid < inum) eoff[a_begin + tid] = (int)(gbase + s_base[tid]);
+  if (tid == 0 && a_begin + EB_ATOMS >= inum) eoff[inum] = (int)(gbase + s_base[min(EB_ATOMS, inum - a_begin)]);
+#pragma unroll
+  for (int k = 0; k < EB_PER_WAVE; ++k) {
+    const int la = wave * EB_PER_WAVE + k;
+    const int ii = a_begin + la;
+    const long long ebase = gbase + s_base[la];
+#pragma unroll
+    for (int c = 0; c < EB_CHUNKS; ++c) {
+      const int r = rank[k][c];
+      if (r >= 0) {
+        const long long e = ebase + r;
+        e_ii[e] = ii;
+        e_j[e] = jj[k][c];
+        rvec[3 * e] = dxs[k][c]; rvec[3 * e + 1] = dys[k][c]; rvec[3 * e + 2] = dzs[k][c];
+      }
+    }
+  }
+}
+
+struct EdgeState { DevBuf flags; };
+
+bool edges_build_f32(Model &m, const ComputeArgs &a) {
+  StageTimer tm(m, "edge_build", a.stream);
+  const int inum = m.inum;
+  const int nblocks = (inum + EB_ATOMS - 1) / EB_ATOMS;
+  if (!m.edge_state) m.edge_state = new EdgeState();
+  EdgeState &st = *(EdgeState *)m.edge_state;
+  // header: [0] ticket (u32), [1] maxdeg, [2] overflow; status array starts at byte 64
+  const size_t bytes = 64 + (size_t)nblocks * sizeof(unsigned long long);
+  st.flags.reserve(bytes);
+  AHIP_CHECK(hipMemsetAsync(st.flags.p, 0, bytes, a.stream));
+  const size_t cap = (size_t)std::max<long long>(m.nneigh, 1);            // upper bound: every list entry survives
+  m.b_eoff.reserve((size_t)(inum + 2) * sizeof(int));
+  m.b_eii.reserve(cap * sizeof(int));
+  m.b_ej.reserve(cap * sizeof(int));
+  m.b_rvec.reserve(cap * 3 * sizeof(float));
+  m.edges_T_size = 4;
+  int *hdr = st.flags.as<int>();
+  hipLaunchKernelGGL(k_build_edges, dim3(nblocks), dim3(256), 0, a.stream, inum, m.d_ilist, m.d_nloff, m.d_nlj, a.x, a.ftype,
+                     a.cutsq, a.nft, (unsigned int *)hdr, (unsigned long long *)((char *)st.flags.p + 64), m.b_eoff.as<int>(),
+                     m.b_eii.as<int>(), m.b_ej.as<int>(), m.b_rvec.as<float>(), hdr + 1, hdr + 2);
+  AHIP_CHECK(hipGetLastError());
+  int h3[3] = {0, 0, 0}, tot = 0;
+  // the scalar read-back per step (the Kokkos path has the same one: pair_nequip_allegro_kokkos.cpp:203-206)
+  AHIP_CHECK(hipMemcpyAsync(h3, hdr, 3 * sizeof(int), hipMemcpyDeviceToHost, a.stream));
+  AHIP_CHECK(hipMemcpyAsync(&tot, m.b_eoff.as<int>() + inum, sizeof(int), hipMemcpyDeviceToHost, a.stream));
+  AHIP_CHECK(hipStreamSynchronize(a.stream));
+  if (h3[2] != 0) return false;                     // a row longer than 128 entries: caller uses the two-pass kernels
+  m.nedges = tot;
+  m.last_max_deg = h3[1];
+  return true;
+}
+
+void edges_free(Model &m) {
+  if (!m.edge_state) return;
+  EdgeState *st = (EdgeState *)m.edge_state;
+  st->flags.release();
+  delete st;
+  m.edge_state = nullptr;
+}
+
+}  // namespace ahip

@@ -125,6 +125,8 @@ struct Model {
 
   // neighbor builder state
   void *nb_state = nullptr;
+  // single-pass edge build state (edges.hip)
+  void *edge_state = nullptr;
 };
 
 // ---- stage timing ------------------------------------------------------------------------------
@@ -165,6 +167,12 @@ bool fused_model_supported(const Model &m, std::string *why);
 // Returns false (and sets *why) if this particular list cannot be handled (e.g. too many edges per atom).
 bool fused_run(Model &m, const ComputeArgs &a, std::string *why);
 void fused_free(Model &m);
+
+// ---- single-pass float32 edge build (edges.hip; the host-emulation build links a stub returning false) ----
+// Fills m.nedges, m.last_max_deg, b_eoff/b_eii/b_ej/b_rvec exactly like build_edges<float>; false = a list
+// row is too long for the register-resident version and the caller must run the two-pass kernels.
+bool edges_build_f32(Model &m, const ComputeArgs &a);
+void edges_free(Model &m);
 
 // ---- neighbor builder (neigh.hip; stubbed in the host-emulation build) -------------------------
 void neigh_build(Model &m, int nlocal, int nall, const double *x_dev, const double *lo, const double *hi,

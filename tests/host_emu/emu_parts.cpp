@@ -31,6 +31,8 @@ hipError_t prim_max_i32(const int *in, int n, int *out, hipStream_t) {
 bool fused_model_supported(const Model &, std::string *why) { if (why) *why = "host emulation has no MFMA"; return false; }
 bool fused_run(Model &, const ComputeArgs &, std::string *why) { if (why) *why = "host emulation has no MFMA"; return false; }
 void fused_free(Model &) {}
+bool edges_build_f32(Model &, const ComputeArgs &) { return false; }   // emulation runs the two-pass kernels
+void edges_free(Model &) {}
 }  // namespace ahip
 
 extern "C" int ahip_debug_fused_linear(int, int, const double *, const float *, float *) { return 5; }

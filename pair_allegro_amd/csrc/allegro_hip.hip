@@ -133,7 +133,7 @@ void ahip_model_free(ahip_model *m) {
   if (m->cg_dev) (void)hipFree(m->cg_dev);
   if (m->rcut_model_dev) (void)hipFree(m->rcut_model_dev);
   for (DevBuf *b : {&m->b_ilist, &m->b_nloff, &m->b_nlj, &m->b_x, &m->b_ftype, &m->b_mtype, &m->b_f, &m->b_eatom,
-                    &m->b_engvir, &m->b_cutsq, &m->b_cnt, &m->b_eoff, &m->b_eii, &m->b_ej, &m->b_rvec, &m->b_partial,
+                    &m->b_engvir, &m->b_cutsq, &m->b_cnt, &m->b_eoff, &m->b_eii, &m->b_ej, &m->b_rvec, &m->b_ett, &m->b_partial,
                     &m->b_ws, &m->b_misc})
     b->release();
   for (auto &t : m->slots) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
@@ -298,6 +298,7 @@ static void run_model(ahip_model *m, const ComputeArgs &a) {
     m->last_path = "generic_f64";
     return;
   }
+  m->have_ett = false;
   if (!edges_build_f32(*m, a)) build_edges<float>(*m, a);
   std::string why;
   bool fused_ok = false;

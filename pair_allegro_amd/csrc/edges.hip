@@ -27,7 +27,8 @@ __global__ void __launch_bounds__(256) k_build_edges(int inum, const int *__rest
                                                        const int *__restrict__ nl_j, const double *__restrict__ x,
                                                        const int *__restrict__ ftype, const double *__restrict__ cutsq, int nft,
                                                        unsigned int *ticket, unsigned long long *status, int *eoff, int *e_ii,
-                                                       int *e_j, float *rvec, int *maxdeg, int *overflow) {
+                                                       int *e_j, float *rvec, int *maxdeg, int *overflow,
+                                                       const int *__restrict__ mtype, unsigned char *e_tt) {
   __shared__ int s_cnt[EB_ATOMS];
   __shared__ int s_base[EB_ATOMS + 1];
   __shared__ int s_blk;
@@ -42,7 +43,9 @@ __global__ void __launch_bounds__(256) k_build_edges(int inum, const int *__rest
   int jj[EB_PER_WAVE][EB_CHUNKS];
   float dxs[EB_PER_WAVE][EB_CHUNKS], dys[EB_PER_WAVE][EB_CHUNKS], dzs[EB_PER_WAVE][EB_CHUNKS];
   int rank[EB_PER_WAVE][EB_CHUNKS];      // -1 = dropped, else position inside the centre's edge range
+  int tts[EB_PER_WAVE][EB_CHUNKS];       // (model type of centre) << 4 | (model type of neighbour), for the fused kernel
   int kept_k[EB_PER_WAVE];
+  const bool same_types = (mtype == ftype);
 #pragma unroll
   for (int k = 0; k < EB_PER_WAVE; ++k) {
     const int la = wave * EB_PER_WAVE + k;
@@ -51,32 +54,36 @@ __global__ void __launch_bounds__(256) k_build_edges(int inum, const int *__rest
     if (ii < inum) {
       const int i = ilist[ii];
       const double xi = x[3 * (size_t)i], yi = x[3 * (size_t)i + 1], zi = x[3 * (size_t)i + 2];
-      const double *crow = cutsq + (size_t)ftype[i] * nft;
+      const int fti = ftype[i];
+      const double *crow = cutsq + (size_t)fti * nft;
+      const int mti = same_types ? fti : mtype[i];
       const int p0 = nl_off[ii], p1 = nl_off[ii + 1];
       if (p1 - p0 > 64 * EB_CHUNKS && lane == 0) atomicOr(overflow, 1);
 #pragma unroll
       for (int c = 0; c < EB_CHUNKS; ++c) {
         const int p = p0 + c * 64 + lane;
         const bool valid = p < p1;
-        int j = 0;
+        int j = 0, tt = 0;
         bool keep = false;
         float fx = 0.f, fy = 0.f, fz = 0.f;
         if (valid) {
           j = nl_j[p];
           const double ddx = x[3 * (size_t)j] - xi, ddy = x[3 * (size_t)j + 1] - yi, ddz = x[3 * (size_t)j + 2] - zi;
           const double rsq = ddx * ddx + ddy * ddy + ddz * ddz;
-          keep = rsq <= crow[ftype[j]];
+          const int ftj = ftype[j];
+          keep = rsq <= crow[ftj];
+          tt = (mti << 4) | (same_types ? ftj : mtype[j]);
           fx = (float)ddx; fy = (float)ddy; fz = (float)ddz;       // neighbour - centre, f64 difference cast to f32
         }
         const unsigned long long mask = __ballot(keep);
         const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-        jj[k][c] = j; dxs[k][c] = fx; dys[k][c] = fy; dzs[k][c] = fz;
+        jj[k][c] = j; dxs[k][c] = fx; dys[k][c] = fy; dzs[k][c] = fz; tts[k][c] = tt;
         rank[k][c] = keep ? kept + below : -1;
         kept += __popcll(mask);
       }
     } else {
 #pragma unroll
-      for (int c = 0; c < EB_CHUNKS; ++c) { jj[k][c] = 0; dxs[k][c] = dys[k][c] = dzs[k][c] = 0.f; rank[k][c] = -1; }
+      for (int c = 0; c < EB_CHUNKS; ++c) { jj[k][c] = 0; dxs[k][c] = dys[k][c] = dzs[k][c] = 0.f; rank[k][c] = -1; tts[k][c] = 0; }
     }
     kept_k[k] = kept;
     if (lane == 0) s_cnt[la] = kept;
@@ -139,6 +146,7 @@ __global__ void __launch_bounds__(256) k_build_edges(int inum, const int *__rest
         e_ii[e] = ii;
         e_j[e] = jj[k][c];
         rvec[3 * e] = dxs[k][c]; rvec[3 * e + 1] = dys[k][c]; rvec[3 * e + 2] = dzs[k][c];
+        e_tt[e] = (unsigned char)tts[k][c];
       }
     }
   }
@@ -161,11 +169,12 @@ bool edges_build_f32(Model &m, const ComputeArgs &a) {
   m.b_eii.reserve(cap * sizeof(int));
   m.b_ej.reserve(cap * sizeof(int));
   m.b_rvec.reserve(cap * 3 * sizeof(float));
+  m.b_ett.reserve(cap);
   m.edges_T_size = 4;
   int *hdr = st.flags.as<int>();
   hipLaunchKernelGGL(k_build_edges, dim3(nblocks), dim3(256), 0, a.stream, inum, m.d_ilist, m.d_nloff, m.d_nlj, a.x, a.ftype,
                      a.cutsq, a.nft, (unsigned int *)hdr, (unsigned long long *)((char *)st.flags.p + 64), m.b_eoff.as<int>(),
-                     m.b_eii.as<int>(), m.b_ej.as<int>(), m.b_rvec.as<float>(), hdr + 1, hdr + 2);
+                     m.b_eii.as<int>(), m.b_ej.as<int>(), m.b_rvec.as<float>(), hdr + 1, hdr + 2, a.mtype, m.b_ett.as<unsigned char>());
   AHIP_CHECK(hipGetLastError());
   int h3[3] = {0, 0, 0}, tot = 0;
   // the scalar read-back per step (the Kokkos path has the same one: pair_nequip_allegro_kokkos.cpp:203-206)
@@ -175,6 +184,7 @@ bool edges_build_f32(Model &m, const ComputeArgs &a) {
   if (h3[2] != 0) return false;                     // a row longer than 128 entries: caller uses the two-pass kernels
   m.nedges = tot;
   m.last_max_deg = h3[1];
+  m.have_ett = true;
   return true;
 }
 

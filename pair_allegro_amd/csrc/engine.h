@@ -109,6 +109,8 @@ struct Model {
 
   // edge list + workspace
   DevBuf b_cnt, b_eoff, b_eii, b_ej, b_rvec, b_partial, b_ws, b_misc;
+  DevBuf b_ett;                              // per-edge packed model types (centre << 4 | neighbour), fused path only
+  bool have_ett = false;                     // b_ett matches the current edge list (written by the single-pass edge build)
   long long nedges = 0;
   int edges_T_size = 0;                      // sizeof(T) of b_rvec contents
   std::vector<int> h_eoff;

@@ -51,18 +51,22 @@ static constexpr int ENV_LD = 129;       // per-atom environment row
 static constexpr int SEG = 512;          // atoms per sequential packing segment
 static constexpr int ROW = 256;          // floats per saved register image of one 16-feature tile (4 regs x 64 lanes)
 static constexpr int RING = 8;           // weight fragments in flight per wave
+static constexpr int TCHUNK = 4;         // tiles per claim of the dynamic tile schedule
 
 __host__ __device__ inline int feat16(int t, int r, int g) { return 16 * t + 4 * g + r; }
 
 struct FusedArgs {
   // edge list
-  const int *eoff, *e_ii, *e_j, *ilist, *mtype;
+  const int *eoff, *e_ii, *e_j;
+  const unsigned char *e_tt;     // per edge: (model type of centre) << 4 | (model type of neighbour)
+  const int2 *centre;            // per centre ii: {atom index ilist[ii], model type}
   const float *rvec;
   const double *rcut;            // [T*T]
   int T, NL, p;
   float cenv;
   // tiles
-  const int *tile_a0, *ntiles;
+  unsigned int *tile_counter;    // dynamic tile schedule (zeroed by k_pack_finish)
+  const int *tile_a0, *tile_e0, *ntiles;   // tile t = centres [tile_a0[t], tile_a0[t+1]), edges [tile_e0[t], tile_e0[t+1])
   // weights (offsets in floats into wbase)
   const float *wbase;
   int wbytes;
@@ -86,9 +90,13 @@ template <int NW> struct __attribute__((aligned(16))) Lds {
   float denv[MAXA * ENV_LD];
   float tp[MAXNL][5 * 32];                // tensor-product path weights [layer][path][u]
   float park[NW][8 * ROW];                // per-wave private park: V^{k+1} forward, dE/dV backward ([lm][t] images)
-  float vir[NW][8];                       // per-wave virial partials
-  float ea[MAXA];
-  int aoff[MAXA + 2];
+  double eacc[MAXA];                      // energy accumulated over this workgroup's tiles, per centre slot (one owner thread each)
+  double virw[NW][6];                     // virial accumulated per wave (owner: lanes 0..5 of the wave)
+  int aoff[2][MAXA + 2];                  // slot offsets of the tile's centres, double-buffered by tile parity
+  float rc[16];                           // model cutoff table [T*T]
+  float scale[4], shift[4];               // per-type energy scale / shift
+  float res[MAXNL][2];                    // residual update coefficients per layer
+  int chunk[2];                           // first tile of the current / next claimed chunk
 };
 
 // ---------------------------------------------------------------------------- device helpers
@@ -155,11 +163,13 @@ static constexpr float C_P4 = 0.7071067811865476f;     // (1,1,1): sqrt(3) * w3j
 struct EpiNone {
   __device__ __forceinline__ void tile_done(int, const f32x4 &) const {}
   __device__ __forceinline__ float apply(int, int, float v) const { return v; }
+  __device__ __forceinline__ void flush(int) const {}
 };
 struct EpiSave {             // raw rows to scratch, value unchanged
   __amdgpu_buffer_rsrc_t S; int row0, v16;
   __device__ __forceinline__ void tile_done(int ot, const f32x4 &acc) const { bstore(S, v16, (row0 + ot) * ROW * 4, acc); }
   __device__ __forceinline__ float apply(int, int, float v) const { return v; }
+  __device__ __forceinline__ void flush(int) const {}
 };
 struct EpiSavePark : EpiSave {  // raw rows to scratch (for the backward pass) and to the LDS park (next layer's forward)
   float *pk; int prow, lane;
@@ -168,17 +178,31 @@ struct EpiSavePark : EpiSave {  // raw rows to scratch (for the backward pass) a
     park_store(pk, prow + ot, acc, lane);
   }
 };
-struct EpiSiluSave : EpiSave {   // raw rows to scratch, out = silu
-  __device__ __forceinline__ float apply(int, int, float v) const { return silu1(v); }
+// out = silu(z); the rows saved for the backward pass hold silu'(z) = s + silu (1 - s) (two extra VALU ops here, no
+// exp/rcp and no z there): they are written when all 8 registers of a tile pair have gone through apply()
+struct EpiSiluSaveD {
+  __amdgpu_buffer_rsrc_t S; int row0, v16;
+  f32x4 d[2];
+  __device__ __forceinline__ void tile_done(int, const f32x4 &) const {}
+  __device__ __forceinline__ float apply(int ot, int r, float z) {
+    const float sg = sigmoidf_fast(z), y = z * sg;
+    d[ot & 1][r] = fmaf(y, 1.f - sg, sg);
+    return y;
+  }
+  __device__ __forceinline__ void flush(int ot0) const {
+    bstore(S, v16, (row0 + ot0) * ROW * 4, d[0]);
+    bstore(S, v16, (row0 + ot0 + 1) * ROW * 4, d[1]);
+  }
 };
 struct EpiSaveScale : EpiSave {  // raw rows to scratch, out = c * v
   float c;
   __device__ __forceinline__ float apply(int, int, float v) const { return c * v; }
 };
-template <int NT> struct EpiMulDsilu {       // out = v * silu'(z)
-  const f32x4 (&z)[NT];
+template <int NT> struct EpiMulRows {        // out = v * d (d = the saved silu' rows)
+  const f32x4 (&d)[NT];
   __device__ __forceinline__ void tile_done(int, const f32x4 &) const {}
-  __device__ __forceinline__ float apply(int ot, int r, float v) const { return v * dsilu1(z[ot][r]); }
+  __device__ __forceinline__ float apply(int ot, int r, float v) const { return v * d[ot][r]; }
+  __device__ __forceinline__ void flush(int) const {}
 };
 template <int NT> struct EpiResidual : EpiSave {   // raw u rows to scratch, out = ra * xold + rbf * u
   const f32x4 (&xold)[NT]; float ra, rbf;
@@ -187,7 +211,7 @@ template <int NT> struct EpiResidual : EpiSave {   // raw u rows to scratch, out
 
 template <int KT, int NT, bool ACC, int RP, class Epi>
 __device__ __forceinline__ void linear_s(__amdgpu_buffer_rsrc_t W, int &wp, const f32x4 (&in)[KT], f32x4 (&out)[NT], int v16,
-                                         f32x4 (&ring)[RING], const Epi &epi) {
+                                         f32x4 (&ring)[RING], Epi epi) {
   static_assert(NT % 2 == 0, "output tiles are processed in pairs");
   constexpr int NP = NT / 2, NSTEP = NP * KT, NS = 2 * NSTEP;
   f32x4 acc0, acc1, prev0, prev1;
@@ -213,6 +237,7 @@ __device__ __forceinline__ void linear_s(__amdgpu_buffer_rsrc_t W, int &wp, cons
             const int e = idx / KT;                   // 0..7: element of the previous pair
             if (e < 4) out[2 * (p - 1)][e] = epi.apply(2 * (p - 1), e, prev0[e]);
             else out[2 * (p - 1) + 1][e - 4] = epi.apply(2 * (p - 1) + 1, e - 4, prev1[e - 4]);
+            if (e == 7) epi.flush(2 * (p - 1));
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -224,6 +249,7 @@ __device__ __forceinline__ void linear_s(__amdgpu_buffer_rsrc_t W, int &wp, cons
       if (p == NP - 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { out[2 * p][r] = epi.apply(2 * p, r, acc0[r]); out[2 * p + 1][r] = epi.apply(2 * p + 1, r, acc1[r]); }
+        epi.flush(2 * p);
       } else { prev0 = acc0; prev1 = acc1; }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -238,10 +264,10 @@ __device__ __forceinline__ void ring_prime(__amdgpu_buffer_rsrc_t W, int wp, int
 
 // Per-centre sum of the staged tile: dst[a][f] = scale * sum_{slots of a} stage[slot][f], f < 128.
 // 128 features x (NW/2) atoms per pass; 4 independent accumulators keep 4 LDS reads in flight.
-template <int NW> __device__ __forceinline__ void reduce_stage(const Lds<NW> &lds, float *dst, int na, float scale, int tid) {
+template <int NW> __device__ __forceinline__ void reduce_stage(const Lds<NW> &lds, const int *aoff, float *dst, int na, float scale, int tid) {
   const int fidx = tid & 127;
   for (int a = tid >> 7; a < na; a += NW / 2) {
-    const int s0 = lds.aoff[a], s1 = lds.aoff[a + 1];
+    const int s0 = aoff[a], s1 = aoff[a + 1];
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     int sl = s0;
     for (; sl + 4 <= s1; sl += 4) {
@@ -286,6 +312,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
   double acc_part = 0.0;       // thread 0: energy; threads 64..69: virial components
   long long pacc[PH_N];
   long long tprev = 0;
+  const long long t_clk0 = clock64(), t_wall0 = wall_clock64();
   if (PROF) {
 #pragma unroll
     for (int k = 0; k < PH_N; ++k) pacc[k] = 0;
@@ -295,32 +322,54 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
   f32x4 ring[RING];                            // the weight-fragment stream (see linear_s)
   int wp = A.o_stream;
   ring_prime(WB, wp, v16, ring);
+  if (tid < MAXA) lds.eacc[tid] = 0.0;
+  if (lane < 6) lds.virw[wave][lane] = 0.0;
+  if (tid < A.T * A.T) lds.rc[tid] = (float)A.rcut[tid];
+  if (tid < A.T) { lds.scale[tid] = Wb[A.o_scale + tid]; lds.shift[tid] = Wb[A.o_shift + tid]; }
+  if (tid < 2 * A.NL) lds.res[tid >> 1][tid & 1] = Wb[A.o_res[tid >> 1] + (tid & 1)];
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int a0 = A.tile_a0[tile], a1 = A.tile_a0[tile + 1];
+  const int s = wave * 16 + j;                 // this lane's edge slot
+  const int ca = tid >> 4;                     // centre slot served by this thread in the per-centre output step
+  float *const st = lds.stage + s * STG_LD;
+  // Dynamic tile schedule: workgroups claim chunks of TCHUNK consecutive tiles from a global counter (workgroup
+  // speeds differ by +-12 % across the chip, a static round-robin leaves the slowest one 13 % behind the average).
+  // The next chunk is claimed while the first tile of the current one runs.
+  if (tid == 0) lds.chunk[0] = (int)atomicAdd(A.tile_counter, (unsigned)TCHUNK);
+  __syncthreads();
+  int par = 0, cpar = 0, ck = 0;
+  int cbase = __builtin_amdgcn_readfirstlane(lds.chunk[0]);
+
+  for (;;) {
+    const int tile = cbase + ck;
+    if (tile >= ntiles) break;
+    int claimed = 0;
+    if (ck == 0 && tid == 0) claimed = (int)atomicAdd(A.tile_counter, (unsigned)TCHUNK);
+    // Everything a tile reads from the lists is ONE level of loads behind the (scalar) tile bounds: the edge
+    // build packs the type pair per edge and k_tile_info the centre index/type, so no dependent chain
+    // (edge -> centre -> type) is exposed here.
+    const int a0 = A.tile_a0[tile], a1 = A.tile_a0[tile + 1], e0 = A.tile_e0[tile], e1 = A.tile_e0[tile + 1];
     const int na = a1 - a0;
-    const int e0 = A.eoff[a0], e1 = A.eoff[a1];
-    if (tid <= na) lds.aoff[tid] = A.eoff[a0 + tid] - e0;
-    const int s = wave * 16 + j;
+    par ^= 1;
+    int *const aoffp = lds.aoff[par];
     const int e = e0 + s;
     const bool valid = e < e1;
-    float *const st = lds.stage + s * STG_LD;
-
-    // ---------------- geometry ----------------
     float rx = 1.f, ry = 0.f, rz = 0.f;
-    int aloc = 0, ti = 0, tj = 0, jat = 0;
+    int aloc = 0, ti = 0, tj = 0, jat = 0, c_i = 0, c_t = 0;
     if (valid) {
       rx = A.rvec[3 * (size_t)e]; ry = A.rvec[3 * (size_t)e + 1]; rz = A.rvec[3 * (size_t)e + 2];
-      const int ii = A.e_ii[e];
-      aloc = ii - a0;
-      ti = A.mtype[A.ilist[ii]];
+      aloc = A.e_ii[e] - a0;
       jat = A.e_j[e];
-      tj = A.mtype[jat];
+      const int tt = A.e_tt[e];
+      ti = tt >> 4; tj = tt & 15;
     }
+    if (ca < na) { const int2 ci = A.centre[a0 + ca]; c_i = ci.x; c_t = ci.y; }   // per-centre output step: atom index, type
+    if (tid <= na) aoffp[tid] = A.eoff[a0 + tid] - e0;
+
+    // ---------------- geometry ----------------
     const float d = sqrtf(rx * rx + ry * ry + rz * rz);
     const float inv = 1.f / d;
     const float nx = rx * inv, ny = ry * inv, nz = rz * inv;
-    const float rc = (float)A.rcut[ti * A.T + tj];
+    const float rc = lds.rc[ti * A.T + tj];
     const float xx = d / rc;
     float fc, dfc_dx;
     cutoff_poly(A.p, xx, fc, dfc_dx);
@@ -349,8 +398,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         bfin[0][r] = g < 2 ? pref * __builtin_amdgcn_sinf(0.5f * n * xx) * inv * fc : 0.f;
         bfin[1][r] = 0.f;
       }
-      linear_s<2, 4, true, 0>(WB, wp, bfin, z, v16, ring, EpiSiluSave{{SB, R_Z1TB(), v16}});
-      linear_s<4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSave{{SB, R_Z2TB(), v16}});
+      linear_s<2, 4, true, 0>(WB, wp, bfin, z, v16, ring, EpiSiluSaveD{SB, R_Z1TB(), v16});
+      linear_s<4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, R_Z2TB(), v16});
       linear_s<4, 4, false, 0>(WB, wp, z2, x, v16, ring, EpiSaveScale{{SB, R_U0(), v16}, fc});
     }
     PHASE(PH_TB);
@@ -359,6 +408,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       f32x4 w0[4];
       linear_s<4, 4, false, 0>(WB, wp, x, w0, v16, ring, EpiSave{SB, R_W0(), v16});
     }
+    if (ck == 0 && tid == 0) lds.chunk[cpar ^ 1] = claimed;
     __syncthreads();          // aoff visible; previous tile's LDS users done
     PHASE(PH_EMB);
 
@@ -386,7 +436,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
             st[96 + fidx] = om[2 + t][r] * Y3;
           }
         __syncthreads();
-        reduce_stage(lds, envk, na, A.cenv, tid);
+        reduce_stage(lds, aoffp, envk, na, A.cenv, tid);
         __syncthreads();
       }
       if (kk == 0) {
@@ -440,9 +490,9 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       {
         f32x4 cat[6], z[4], z2[4];
         cat[0] = x[0]; cat[1] = x[1]; cat[2] = x[2]; cat[3] = x[3]; cat[4] = Vp[0][0]; cat[5] = Vp[0][1];
-        linear_s<6, 4, false, 0>(WB, wp, cat, z, v16, ring, EpiSiluSave{{SB, RL + 4, v16}});
-        linear_s<4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSave{{SB, RL + 8, v16}});
-        const float ra = Wb[A.o_res[kk]], rbf = Wb[A.o_res[kk] + 1] * fc;
+        linear_s<6, 4, false, 0>(WB, wp, cat, z, v16, ring, EpiSiluSaveD{SB, RL + 4, v16});
+        linear_s<4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, RL + 8, v16});
+        const float ra = lds.res[kk][0], rbf = lds.res[kk][1] * fc;
         f32x4 xn[4];
         linear_s<4, 4, false, 0>(WB, wp, z2, xn, v16, ring, EpiResidual<4>{{SB, RL + 12, v16}, x, ra, rbf});
         x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2]; x[3] = xn[3];
@@ -451,6 +501,12 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     }
 
     // ---------------- read-out ----------------
+    // saved rows are requested one linear ahead of their first use all through the backward pass (their
+    // round trip is an L2 miss: ~2 us): u and z2 of the last layer now, under the read-out MFMAs
+    f32x4 upre[4], zt[4], w0h[2];
+    load_rows<4>(SB, R_LAYER(NL - 1) + 12, upre, v16);
+    load_rows<4>(SB, R_LAYER(NL - 1) + 8, zt, v16);
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 zr[2];
     linear_s<4, 2, false, 0>(WB, wp, x, zr, v16, ring, EpiNone{});
     f32x4 wo1[2];
@@ -464,10 +520,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     eps = gsum(eps);
 
     // =========================== backward ===========================
-    const float deps = valid ? Wb[A.o_scale + ti] * A.cenv : 0.f;
-    f32x4 dx[4], upre[4];
-    load_rows<4>(SB, R_LAYER(NL - 1) + 12, upre, v16);     // u of the last layer, lands under the out0^T MFMAs
-    __builtin_amdgcn_sched_barrier(0);
+    const float deps = valid ? lds.scale[ti] * A.cenv : 0.f;
+    f32x4 dx[4];
     {
       f32x4 dzr[2];
 #pragma unroll
@@ -486,7 +540,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       {
         f32x4 du[4], dh[4];
         {
-          const float ra = Wb[A.o_res[kk]], rb = Wb[A.o_res[kk] + 1];
+          const float ra = lds.res[kk][0], rb = lds.res[kk][1];
           float acc = 0.f;
 #pragma unroll
           for (int t = 0; t < 4; ++t)
@@ -498,18 +552,17 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
             }
           dfc_part += rb * acc;
         }
-        f32x4 zt[4], zt1[4];
-        load_rows<4>(SB, RL + 8, zt, v16);                   // z2, lands under the next MFMAs
-        load_rows<4>(SB, RL + 4, zt1, v16);                  // z1
+        f32x4 zt1[4];
+        load_rows<4>(SB, RL + 4, zt1, v16);                  // z1: first used 96 MFMAs from here
         __builtin_amdgcn_sched_barrier(0);
-        linear_s<4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulDsilu<4>{zt});
+        linear_s<4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt});
         // prefetch V^{kk} (input of this layer's tensor product) under the MFMAs that follow
         if (kk > 0) {
 #pragma unroll
           for (int lm = 0; lm < 4; ++lm) load_rows<2>(SB, RL + 16 + 2 * lm, Vk[lm], v16);
         } else load_rows<4>(SB, R_W0(), W0b, v16);
         __builtin_amdgcn_sched_barrier(0);
-        linear_s<4, 4, false, 0>(WB, wp, dh, du, v16, ring, EpiMulDsilu<4>{zt1});
+        linear_s<4, 4, false, 0>(WB, wp, dh, du, v16, ring, EpiMulRows<4>{zt1});
         f32x4 dcat[6];
         linear_s<4, 6, false, 0>(WB, wp, du, dcat, v16, ring, EpiNone{});
 #pragma unroll
@@ -523,6 +576,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
           Vk[1][t] = W0b[2 + t] * Y1; Vk[2][t] = W0b[2 + t] * Y2; Vk[3][t] = W0b[2 + t] * Y3;
         }
       }
+      f32x4 om[4];
+      load_rows<4>(SB, RL + 0, om, v16);                     // omega of this layer: used after the gradient reduction
       __builtin_amdgcn_sched_barrier(0);
       PHASE(PH_BLAT);
       if (!last) {
@@ -540,7 +595,6 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       __builtin_amdgcn_sched_barrier(0);
       PHASE(PH_BMIX);
       // tensor-product backward: dV (w.r.t. V^{kk}, parked) and the per-edge environment gradient
-      f32x4 om[4];
       {
         const float *en = envrow + kk * (MAXA * ENV_LD);
         const float *tp = lds.tp[kk];
@@ -577,10 +631,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
           park_store(pk, 6 + t, o3, lane);
           __builtin_amdgcn_sched_barrier(0);
         }
-        load_rows<4>(SB, RL + 0, om, v16);                   // omega of this layer, lands during the reduction
-        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
-        reduce_stage(lds, lds.denv, na, A.cenv, tid);
+        reduce_stage(lds, aoffp, lds.denv, na, A.cenv, tid);
         __syncthreads();
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -599,23 +651,32 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (kk > 0) load_rows<4>(SB, R_LAYER(kk - 1) + 12, upre, v16);     // next iteration's u rows
+        if (kk > 0) {                                                      // next iteration's u and z2 rows
+          load_rows<4>(SB, R_LAYER(kk - 1) + 12, upre, v16);
+          load_rows<4>(SB, R_LAYER(kk - 1) + 8, zt, v16);
+        } else {                                                           // two-body u and z2 rows, l=1 embedding weights
+          load_rows<4>(SB, R_U0(), upre, v16);
+          load_rows<4>(SB, R_Z2TB(), zt, v16);
+          load_rows<2>(SB, R_W0() + 2, w0h, v16);
+        }
         __builtin_amdgcn_sched_barrier(0);
         linear_s<4, 4, true, 0>(WB, wp, dom, dx, v16, ring, EpiNone{});
       }
       PHASE(PH_BENV);
     }
     // ---------------- embedding backward ----------------
+    f32x4 zt1b[4];
+    load_rows<4>(SB, R_Z1TB(), zt1b, v16);
+    __builtin_amdgcn_sched_barrier(0);
     {
-      f32x4 w0[4], dw0[4];
-      load_rows<4>(SB, R_W0(), w0, v16);
+      f32x4 dw0[4];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const f32x4 d0 = park_load(pk, 0 + t, lane), d1 = park_load(pk, 2 + t, lane), d2 = park_load(pk, 4 + t, lane), d3 = park_load(pk, 6 + t, lane);
         dw0[t] = d0;
         dw0[2 + t] = d1 * Y1 + d2 * Y2 + d3 * Y3;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { dY1 += d1[r] * w0[2 + t][r]; dY2 += d2[r] * w0[2 + t][r]; dY3 += d3[r] * w0[2 + t][r]; }
+        for (int r = 0; r < 4; ++r) { dY1 += d1[r] * w0h[t][r]; dY2 += d2[r] * w0h[t][r]; dY3 += d3[r] * w0h[t][r]; }
       }
       linear_s<4, 4, true, 0>(WB, wp, dw0, dx, v16, ring, EpiNone{});
     }
@@ -623,20 +684,16 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     // ---------------- two-body MLP backward ----------------
     float dd_part = 0.f;
     {
-      f32x4 du[4], dh[4], u0[4];
-      load_rows<4>(SB, R_U0(), u0, v16);
-      f32x4 zt[4], zt1[4];
-      load_rows<4>(SB, R_Z2TB(), zt, v16);
-      load_rows<4>(SB, R_Z1TB(), zt1, v16);
+      f32x4 du[4], dh[4];
       float acc = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { acc += u0[t][r] * dx[t][r]; du[t][r] = fc * dx[t][r]; }
+        for (int r = 0; r < 4; ++r) { acc += upre[t][r] * dx[t][r]; du[t][r] = fc * dx[t][r]; }
       dfc_part += acc;
       __builtin_amdgcn_sched_barrier(0);
-      linear_s<4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulDsilu<4>{zt});
-      linear_s<4, 4, false, 0>(WB, wp, dh, du, v16, ring, EpiMulDsilu<4>{zt1});
+      linear_s<4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt});
+      linear_s<4, 4, false, 0>(WB, wp, dh, du, v16, ring, EpiMulRows<4>{zt1b});
       f32x4 dbf[2];
       linear_s<4, 2, false, 0>(WB, wp, du, dbf, v16, ring, EpiNone{});   // its prefetches already fetch the next tile's first fragments
       wp = A.o_stream;                                                    // (the stream ends with a copy of its first RING entries)
@@ -684,49 +741,51 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) w6[c] += __shfl_xor(w6[c], off, 64);
       }
-      if (lane == 0) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) lds.vir[wave][c] = w6[c];
+      if (lane < 6) {         // after the butterfly every lane holds the 6 totals: lane c owns component c
+        const float mine = lane == 0 ? w6[0] : lane == 1 ? w6[1] : lane == 2 ? w6[2] : lane == 3 ? w6[3] : lane == 4 ? w6[4] : w6[5];
+        lds.virw[wave][lane] += (double)mine;
       }
     }
     __syncthreads();
     {
-      // per-centre sums of (g, eps): 16 lanes per atom = 4 columns x 4 row-parts
-      const int a = tid >> 4, col = tid & 3, part = (tid >> 2) & 3;
+      // per-centre sums of (g, eps): 16 lanes per atom = 4 columns x 4 row-parts; the atom index, scale and
+      // shift of this thread's centre were prefetched with the tile.  No trailing barrier: the next tile's first
+      // staging write sits behind its own barrier, and its slot offsets go to the other parity buffer.
+      const int col = tid & 3, part = (tid >> 2) & 3;
       float sum = 0.f;
-      if (a < na)
-        for (int sl = lds.aoff[a] + part; sl < lds.aoff[a + 1]; sl += 4) sum += lds.stage[sl * STG_LD + col];
+      if (ca < na)
+        for (int sl = aoffp[ca] + part; sl < aoffp[ca + 1]; sl += 4) sum += lds.stage[sl * STG_LD + col];
       sum += __shfl_xor(sum, 4, 64);
       sum += __shfl_xor(sum, 8, 64);
-      if (a < na && part == 0) {
-        const int i = A.ilist[a0 + a];
-        if (col < 3) atomicAdd(&A.f[3 * (size_t)i + col], (double)sum);
+      if (ca < na && part == 0) {
+        if (col < 3) atomicAdd(&A.f[3 * (size_t)c_i + col], (double)sum);
         else {
-          const int t = A.mtype[i];
-          const float ei = Wb[A.o_scale + t] * (sum * A.cenv) + Wb[A.o_shift + t];
-          if (A.eatom) A.eatom[i] = (double)ei;
-          lds.ea[a] = ei;
+          const float ei = lds.scale[c_t] * (sum * A.cenv) + lds.shift[c_t];
+          if (A.eatom) A.eatom[c_i] = (double)ei;
+          lds.eacc[ca] += (double)ei;
         }
       }
     }
-    __syncthreads();
-    if (tid == 0) {
-      double se = 0;
-      for (int a = 0; a < na; ++a) se += lds.ea[a];
-      acc_part += se;
-    } else if (tid >= 64 && tid < 70) {
-      const int c = tid - 64;
-      float sv = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) sv += lds.vir[w][c];
-      acc_part += (double)sv;
-    }
-    __syncthreads();
     PHASE(PH_FIN);
+    if (++ck == TCHUNK) { ck = 0; cpar ^= 1; cbase = __builtin_amdgcn_readfirstlane(lds.chunk[cpar]); }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int a = 0; a < MAXA; ++a) acc_part += lds.eacc[a];
+  } else if (tid >= 64 && tid < 70) {
+    for (int w = 0; w < NW; ++w) acc_part += lds.virw[w][tid - 64];
   }
   if (PROF && lane == 0) {
 #pragma unroll
     for (int k = 0; k < PH_N; ++k) atomicAdd((unsigned long long *)&A.prof[k], (unsigned long long)pacc[k]);
+  }
+  if (A.prof && tid == 0) {
+    // per workgroup: shader cycles, start and end on the constant 100 MHz counter, hardware id (placement)
+    long long *o = A.prof + PH_N + 4 * (size_t)blockIdx.x;
+    o[0] = clock64() - t_clk0;
+    o[1] = t_wall0;
+    o[2] = wall_clock64();
+    o[3] = ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
   }
   if (tid == 0) A.partial[7 * (size_t)blockIdx.x] = acc_part;
   if (tid >= 64 && tid < 70) A.partial[7 * (size_t)blockIdx.x + 1 + (tid - 64)] = acc_part;
@@ -757,15 +816,29 @@ __global__ void k_pack_finish(int inum, int nseg, const int *seg_base, int *tile
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     int n = seg_base[nseg];
     tile_a0[n] = inum;
-    *ntiles = n;
+    ntiles[0] = n;
+    ntiles[1] = 0;          // the fused kernel's tile counter
   }
+}
+__global__ void k_centre_info(int inum, const int *ilist, const int *mtype, int2 *centre) {
+  int ii = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ii < inum) { const int i = ilist[ii]; centre[ii] = make_int2(i, mtype[i]); }
+}
+// packed per-edge types when the edge list did not come from the single-pass build (edges.hip writes them itself)
+__global__ void k_edge_types(long long E, const int *e_ii, const int *e_j, const int *ilist, const int *mtype, unsigned char *e_tt) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < E) e_tt[e] = (unsigned char)((mtype[ilist[e_ii[e]]] << 4) | mtype[e_j[e]]);
+}
+__global__ void k_tile_e0(const int *ntiles, const int *tile_a0, const int *eoff, int *tile_e0) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t <= *ntiles) tile_e0[t] = eoff[tile_a0[t]];
 }
 
 // ---------------------------------------------------------------------------- host side
 struct FusedState {
-  DevBuf wbuf, scratch, seg_count, seg_base, tile_a0, ntiles, partial;
+  DevBuf wbuf, scratch, seg_count, seg_base, tile_a0, tile_e0, centre, ntiles, partial;
   FusedArgs args;
-  bool ready = false, prof_on = false, dbg_on = false;
+  bool ready = false, prof_on = false, dbg_on = false, clk_on = false;
   DevBuf prof, dbg;
   int ncu = 256;
   int force_nw = 0;            // AHIP_FUSED_NW=4|8 pins the workgroup shape (A/B measurements)
@@ -905,9 +978,10 @@ static void fused_prepare(Model &m) {
   st.partial.reserve((size_t)st.ncu * 2 * 7 * sizeof(double));
   if (const char *nwe = std::getenv("AHIP_FUSED_NW")) st.force_nw = std::atoi(nwe);
   st.ntiles.reserve(64);
-  st.prof.reserve(64 * sizeof(long long));
+  st.prof.reserve((64 + 4 * 2 * (size_t)st.ncu) * sizeof(long long));
   const char *pe = std::getenv("AHIP_FUSED_PROF");
   st.prof_on = pe && pe[0] == '1';
+  st.clk_on = std::getenv("AHIP_FUSED_CLK") != nullptr;
   const char *de = std::getenv("AHIP_FUSED_DBG");
   st.dbg_on = de && de[0] == '1';
   st.ready = true;
@@ -931,6 +1005,7 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
   st.seg_count.reserve((size_t)(nseg + 1) * sizeof(int));
   st.seg_base.reserve((size_t)(nseg + 2) * sizeof(int));
   st.tile_a0.reserve((size_t)(inum + nseg + 2) * sizeof(int));
+  st.tile_e0.reserve((size_t)(inum + nseg + 2) * sizeof(int));
   {
     StageTimer tm(m, "tile_pack", s);
     const unsigned B = 64;
@@ -938,12 +1013,23 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
     AHIP_CHECK(prim_exclusive_scan_i32(st.seg_count.as<int>(), st.seg_base.as<int>(), nseg, s));
     hipLaunchKernelGGL(k_pack_tiles<true>, dim3((nseg + B - 1) / B), dim3(B), 0, s, inum, m.b_eoff.as<int>(), nseg, (int *)nullptr, st.seg_base.as<int>(), st.tile_a0.as<int>(), tile_slots, maxa);
     hipLaunchKernelGGL(k_pack_finish, dim3(1), dim3(1), 0, s, inum, nseg, st.seg_base.as<int>(), st.tile_a0.as<int>(), st.ntiles.as<int>());
+    const int tcap = inum + nseg + 1;              // upper bound on tiles + 1
+    st.centre.reserve((size_t)std::max(inum, 1) * sizeof(int2));
+    hipLaunchKernelGGL(k_centre_info, dim3((inum + 255) / 256), dim3(256), 0, s, inum, m.d_ilist, a.mtype, st.centre.as<int2>());
+    if (!m.have_ett) {
+      m.b_ett.reserve((size_t)std::max<long long>(m.nedges, 1));
+      hipLaunchKernelGGL(k_edge_types, dim3((unsigned)((m.nedges + 255) / 256)), dim3(256), 0, s, m.nedges, m.b_eii.as<int>(), m.b_ej.as<int>(), m.d_ilist, a.mtype, m.b_ett.as<unsigned char>());
+      m.have_ett = true;
+    }
+    hipLaunchKernelGGL(k_tile_e0, dim3((tcap + 255) / 256), dim3(256), 0, s, st.ntiles.as<int>(), st.tile_a0.as<int>(), m.b_eoff.as<int>(), st.tile_e0.as<int>());
   }
   FusedArgs A = st.args;
   A.wg_scratch = nw * A.wave_scratch;
+  if (std::getenv("AHIP_FUSED_EXP_ALIAS")) A.wg_scratch = 0;      // timing experiment only: all workgroups share one scratch block (wrong results)
   A.eoff = m.b_eoff.as<int>(); A.e_ii = m.b_eii.as<int>(); A.e_j = m.b_ej.as<int>();
-  A.ilist = m.d_ilist; A.mtype = a.mtype; A.rvec = m.b_rvec.as<float>(); A.rcut = m.rcut_model_dev;
-  A.tile_a0 = st.tile_a0.as<int>(); A.ntiles = st.ntiles.as<int>();
+  A.e_tt = m.b_ett.as<unsigned char>(); A.centre = st.centre.as<int2>(); A.rvec = m.b_rvec.as<float>(); A.rcut = m.rcut_model_dev;
+  A.tile_a0 = st.tile_a0.as<int>(); A.tile_e0 = st.tile_e0.as<int>(); A.ntiles = st.ntiles.as<int>();
+  A.tile_counter = (unsigned int *)(st.ntiles.as<int>() + 1);
   A.f = a.f; A.eatom = a.eatom; A.partial = st.partial.as<double>();
   {
     StageTimer tm(m, "model_fused", s);
@@ -952,9 +1038,11 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
       AHIP_CHECK(hipMemsetAsync(st.dbg.p, 0, (size_t)m.nedges * 8 * sizeof(float), s));
       A.dbg = st.dbg.as<float>();
     }
-    if (st.prof_on) {
-      AHIP_CHECK(hipMemsetAsync(st.prof.p, 0, 64 * sizeof(long long), s));
+    if (st.prof_on || st.clk_on) {
+      AHIP_CHECK(hipMemsetAsync(st.prof.p, 0, (64 + 4 * (size_t)grid) * sizeof(long long), s));
       A.prof = st.prof.as<long long>();
+    }
+    if (st.prof_on) {
       if (nw == 4) hipLaunchKernelGGL((k_fused<4, true>), dim3(grid), dim3(256), 0, s, A);
       else hipLaunchKernelGGL((k_fused<8, true>), dim3(grid), dim3(512), 0, s, A);
     } else {
@@ -964,16 +1052,41 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
   }
   AHIP_CHECK(hipGetLastError());
   AHIP_CHECK(prim_sum_columns_f64(st.partial.as<double>(), grid, 7, a.engvir, s));
-  if (st.prof_on) {
-    long long hp[PH_N];
-    AHIP_CHECK(hipMemcpyAsync(hp, st.prof.p, sizeof(hp), hipMemcpyDeviceToHost, s));
+  if (st.prof_on || st.clk_on) {
+    std::vector<long long> hp(PH_N + 4 * (size_t)grid);
+    AHIP_CHECK(hipMemcpyAsync(hp.data(), st.prof.p, hp.size() * sizeof(long long), hipMemcpyDeviceToHost, s));
     AHIP_CHECK(hipStreamSynchronize(s));
-    static const char *names[PH_N] = {"geom", "tb_mlp", "embed", "env+reduce", "tp", "mix", "latent_mlp", "readout", "b_latent", "b_mix", "b_tp+reduce", "b_env", "b_embed", "b_tb", "finish"};
-    double tot = 0;
-    for (int k = 0; k < PH_N; ++k) tot += (double)hp[k];
-    std::fprintf(stderr, "[ahip fused prof] wave-cycles by phase (sum over %d waves):", grid * nw);
-    for (int k = 0; k < PH_N; ++k) std::fprintf(stderr, " %s=%.1f%%", names[k], 100.0 * hp[k] / tot);
-    std::fprintf(stderr, " | total=%.3g cycles\n", tot);
+    if (st.prof_on) {
+      static const char *names[PH_N] = {"geom", "tb_mlp", "embed", "env+reduce", "tp", "mix", "latent_mlp", "readout", "b_latent", "b_mix", "b_tp+reduce", "b_env", "b_embed", "b_tb", "finish"};
+      double tot = 0;
+      for (int k = 0; k < PH_N; ++k) tot += (double)hp[k];
+      std::fprintf(stderr, "[ahip fused prof] wave-cycles by phase (sum over %d waves):", grid * nw);
+      for (int k = 0; k < PH_N; ++k) std::fprintf(stderr, " %s=%.1f%%", names[k], 100.0 * hp[k] / tot);
+      std::fprintf(stderr, " | total=%.3g cycles\n", tot);
+    }
+    {
+      // workgroup timeline: spread of start/end times, effective clock, and (AHIP_FUSED_CLK=2) one line per workgroup
+      long long t0 = hp[PH_N + 1], t1 = hp[PH_N + 2];
+      for (int b = 0; b < grid; ++b) { t0 = std::min(t0, hp[PH_N + 4 * b + 1]); t1 = std::max(t1, hp[PH_N + 4 * b + 2]); }
+      double dmin = 1e30, dmax = 0, dsum = 0, smax = 0, mhz = 0;
+      for (int b = 0; b < grid; ++b) {
+        const long long *o = &hp[PH_N + 4 * b];
+        const double d = (double)(o[2] - o[1]) * 1e-5;
+        dmin = std::min(dmin, d); dmax = std::max(dmax, d); dsum += d;
+        smax = std::max(smax, (double)(o[1] - t0) * 1e-5);
+        mhz += (double)o[0] / ((double)(o[2] - o[1]) * 1e-2);
+      }
+      std::fprintf(stderr, "[ahip fused clk] %d workgroups: kernel span %.3f ms, workgroup duration min/avg/max %.3f/%.3f/%.3f ms, latest start +%.3f ms, %.0f MHz\n",
+                   grid, (double)(t1 - t0) * 1e-5, dmin, dsum / grid, dmax, smax, mhz / grid);
+      const char *ce = std::getenv("AHIP_FUSED_CLK");
+      if (ce && ce[0] == '2')
+        for (int b = 0; b < grid; ++b) {
+          const long long *o = &hp[PH_N + 4 * b];
+          const unsigned hw = (unsigned)o[3], xcc = (unsigned)(o[3] >> 32);
+          std::fprintf(stderr, "[ahip fused wg] %d start %.3f end %.3f xcc %u se %u sh %u cu %u\n", b, (double)(o[1] - t0) * 1e-5, (double)(o[2] - t0) * 1e-5,
+                       xcc & 15, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15);
+        }
+    }
   }
   return true;
 }
@@ -981,7 +1094,7 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
 void fused_free(Model &m) {
   if (!m.fused_state) return;
   FusedState *st = (FusedState *)m.fused_state;
-  for (DevBuf *b : {&st->wbuf, &st->scratch, &st->seg_count, &st->seg_base, &st->tile_a0, &st->ntiles, &st->partial, &st->prof, &st->dbg}) b->release();
+  for (DevBuf *b : {&st->wbuf, &st->scratch, &st->seg_count, &st->seg_base, &st->tile_a0, &st->tile_e0, &st->centre, &st->ntiles, &st->partial, &st->prof, &st->dbg}) b->release();
   delete st;
   m.fused_state = nullptr;
 }

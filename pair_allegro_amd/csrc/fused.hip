@@ -406,7 +406,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     // ---------------- tensor embedding weights (V^0 = w0 (x) Y is rebuilt where needed) -------------
     {
       f32x4 w0[4];
-      linear_s<4, 4, false, 0>(WB, wp, x, w0, v16, ring, EpiSave{SB, R_W0(), v16});
+      // w0 goes to scratch (backward) and to the LDS park rows 0..3, where layer 0 picks it up
+      linear_s<4, 4, false, 0>(WB, wp, x, w0, v16, ring, EpiSavePark{{SB, R_W0(), v16}, pk, 0, lane});
     }
     if (ck == 0 && tid == 0) lds.chunk[cpar ^ 1] = claimed;
     __syncthreads();          // aoff visible; previous tile's LDS users done
@@ -417,13 +418,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       const bool last = (kk == NL - 1);
       const int RL = R_LAYER(kk);
       float *const envk = lds.env[0] + kk * (MAXA * ENV_LD);
-      f32x4 V[4][2], W0a[4];
+      f32x4 V[4][2];
       {
         f32x4 om[4];
         linear_s<4, 4, false, 0>(WB, wp, x, om, v16, ring, EpiSave{SB, RL + 0, v16});
-        // prefetch w0 for the first layer now: it lands while the environment is reduced
-        if (kk == 0) load_rows<4>(SB, R_W0(), W0a, v16);
-        __builtin_amdgcn_sched_barrier(0);
         // environment sum over the centre's edges
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -442,8 +440,9 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       if (kk == 0) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          V[0][t] = W0a[t];
-          V[1][t] = W0a[2 + t] * Y1; V[2][t] = W0a[2 + t] * Y2; V[3][t] = W0a[2 + t] * Y3;
+          const f32x4 w1 = park_load(pk, 2 + t, lane);
+          V[0][t] = park_load(pk, t, lane);
+          V[1][t] = w1 * Y1; V[2][t] = w1 * Y2; V[3][t] = w1 * Y3;
         }
       } else {
 #pragma unroll

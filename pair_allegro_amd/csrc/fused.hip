@@ -256,6 +256,109 @@ __device__ __forceinline__ void linear_s(__amdgpu_buffer_rsrc_t W, int &wp, cons
   }
   wp += NS * 256;
 }
+// ---- bf16x3 arithmetic: every f32 value is split EXACTLY into three bf16 terms (truncation: 8+8+8 significant
+// bits), x = hi + mid + lo, and a product w*x is evaluated on the bf16 matrix cores as the six terms of weight
+// 2^-16 and above:  w_hi x_hi + w_hi x_mid + w_mid x_hi + w_hi x_lo + w_mid x_mid + w_lo x_hi  (each bf16 product is
+// exact in f32, accumulation is f32; the dropped terms are <= 3 * 2^-24 |w x|, the size of one f32 rounding).  One
+// v_mfma_f32_16x16x32_bf16 (16 cycles on the matrix core, which -- unlike the f32-input MFMA -- runs beside the
+// VALU) contracts 32 input features, so a K-step is a PAIR of 16-feature tiles: lane (j, g) supplies its 4
+// registers of tile 2s and of tile 2s+1 as the 8 k-slots of its lane group.  The C/D layout is the same as the
+// f32 form, so the register chaining of the f32 kernel carries over unchanged.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct Bop { u32x4 hi, mid, lo; };           // B operand of one K-step: 8 bf16 per lane and term
+
+__device__ __forceinline__ f32x4 mfma_b(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// two f32 -> packed bf16 terms (low half = first value)
+__device__ __forceinline__ void split2(float v0, float v1, unsigned &hi, unsigned &mid, unsigned &lo) {
+  const unsigned a = __builtin_bit_cast(unsigned, v0), b = __builtin_bit_cast(unsigned, v1);
+  hi = __builtin_amdgcn_perm(b, a, 0x07060302u);
+  const float r0 = v0 - __builtin_bit_cast(float, a & 0xffff0000u), r1 = v1 - __builtin_bit_cast(float, b & 0xffff0000u);
+  const unsigned ra = __builtin_bit_cast(unsigned, r0), rb = __builtin_bit_cast(unsigned, r1);
+  mid = __builtin_amdgcn_perm(rb, ra, 0x07060302u);
+  const float q0 = r0 - __builtin_bit_cast(float, ra & 0xffff0000u), q1 = r1 - __builtin_bit_cast(float, rb & 0xffff0000u);
+  lo = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, q1), __builtin_bit_cast(unsigned, q0), 0x07060302u);
+}
+__device__ __forceinline__ Bop split_pair(const f32x4 &t0, const f32x4 &t1) {
+  Bop b;
+  unsigned h, m, l;
+  split2(t0[0], t0[1], h, m, l); b.hi[0] = h; b.mid[0] = m; b.lo[0] = l;
+  split2(t0[2], t0[3], h, m, l); b.hi[1] = h; b.mid[1] = m; b.lo[1] = l;
+  split2(t1[0], t1[1], h, m, l); b.hi[2] = h; b.mid[2] = m; b.lo[2] = l;
+  split2(t1[2], t1[3], h, m, l); b.hi[3] = h; b.mid[3] = m; b.lo[3] = l;
+  return b;
+}
+
+// Streamed linear on the bf16x3 arithmetic.  in: KS K-steps (pairs of 16-feature tiles, already split); out: NT f32
+// tiles through the same epilogue functors as linear_s; SPLIT additionally emits the outputs as the next linear's
+// B operands (outb[p] = tiles 2p, 2p+1).  Fragments per (tile pair p, K-step): hi0 hi1 mid0 mid1 lo0 lo1, 1 KiB each,
+// in consumption order; RINGB of them are in flight (a multiple of 6: every linear consumes a multiple of 6).
+static constexpr int RINGB = 12;
+template <int KS, int NT, bool ACC, bool SPLIT, int RP, class Epi>
+__device__ __forceinline__ void linear_b(__amdgpu_buffer_rsrc_t W, int &wp, const Bop (&in)[KS], f32x4 (&out)[NT], Bop (&outb)[NT / 2],
+                                         int v16, u32x4 (&ring)[RINGB], Epi epi) {
+  static_assert(NT % 2 == 0, "output tiles are processed in pairs");
+  constexpr int NP = NT / 2, NSTEP = NP * KS, NS = 6 * NSTEP;
+  f32x4 acc0, acc1, prev0, prev1;
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    const int p = s / KS, ks = s % KS;
+    if (ks == 0) {
+      if (ACC) { acc0 = out[2 * p]; acc1 = out[2 * p + 1]; }
+      else { acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    u32x4 a[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      a[i] = ring[(RP + 6 * s + i) % RINGB];
+      ring[(RP + 6 * s + i) % RINGB] = __builtin_bit_cast(u32x4, bload(W, v16, (wp + (6 * s + i + RINGB) * 256) * 4));
+    }
+    // 12 MFMAs, the two accumulators alternate; smallest terms first
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+      // term m: (weight term, activation term) = (lo,hi) (mid,mid) (hi,lo) (mid,hi) (hi,mid) (hi,hi)
+      const int wt = m == 0 ? 2 : (m == 1 || m == 3) ? 1 : 0;
+      const u32x4 bx = (m == 0 || m == 3 || m == 5) ? in[ks].hi : (m == 1 || m == 4) ? in[ks].mid : in[ks].lo;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        if (hh == 0) acc0 = mfma_b(a[2 * wt], bx, acc0);
+        else acc1 = mfma_b(a[2 * wt + 1], bx, acc1);
+        if (p > 0) {
+          const int idx = ks * 12 + 2 * m + hh;       // MFMA index inside this pair
+          constexpr int PER = (KS * 12) / 8;          // MFMAs per epilogue element (>= 1)
+          if (idx % PER == 0 && idx / PER < 8) {
+            const int e = idx / PER;
+            if (e < 4) out[2 * (p - 1)][e] = epi.apply(2 * (p - 1), e, prev0[e]);
+            else out[2 * (p - 1) + 1][e - 4] = epi.apply(2 * (p - 1) + 1, e - 4, prev1[e - 4]);
+            if (e == 7) {
+              epi.flush(2 * (p - 1));
+              if (SPLIT) outb[p - 1] = split_pair(out[2 * (p - 1)], out[2 * (p - 1) + 1]);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (ks == KS - 1) {
+      epi.tile_done(2 * p, acc0);
+      epi.tile_done(2 * p + 1, acc1);
+      if (p == NP - 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { out[2 * p][r] = epi.apply(2 * p, r, acc0[r]); out[2 * p + 1][r] = epi.apply(2 * p + 1, r, acc1[r]); }
+        epi.flush(2 * p);
+        if (SPLIT) outb[p] = split_pair(out[2 * p], out[2 * p + 1]);
+      } else { prev0 = acc0; prev1 = acc1; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  wp += NS * 256;
+}
+__device__ __forceinline__ void ring_prime_b(__amdgpu_buffer_rsrc_t W, int wp, int v16, u32x4 (&ring)[RINGB]) {
+#pragma unroll
+  for (int j = 0; j < RINGB; ++j) ring[j] = __builtin_bit_cast(u32x4, bload(W, v16, (wp + j * 256) * 4));
+}
+
 // first RING fragments of the stream at wp into the ring
 __device__ __forceinline__ void ring_prime(__amdgpu_buffer_rsrc_t W, int wp, int v16, f32x4 (&ring)[RING]) {
 #pragma unroll
@@ -291,7 +394,26 @@ __device__ __forceinline__ float gsum(float v) {       // sum over the 4 lanes (
 enum { PH_GEOM = 0, PH_TB, PH_EMB, PH_ENV, PH_TP, PH_MIX, PH_LAT, PH_OUT, PH_BLAT, PH_BMIX, PH_BTP, PH_BENV, PH_BEMB, PH_BTB, PH_FIN, PH_N };
 #define PHASE(id) do { if (PROF) { long long _t = clock64(); pacc[id] += _t - tprev; tprev = _t; } } while (0)
 
-template <int NW, bool PROF>
+// One weight-fragment ring per arithmetic (see linear_s / linear_b); lin<> dispatches a linear of the tile sequence to
+// the f32-input MFMA form or to the bf16x3 form (inputs are split into their three bf16 terms right here).
+template <bool B3> struct RingT {
+  f32x4 f[B3 ? 1 : RING];
+  u32x4 b[B3 ? RINGB : 1];
+};
+template <bool B3, int KT, int NT, bool ACC, int RPI, class Epi>
+__device__ __forceinline__ void lin(__amdgpu_buffer_rsrc_t W, int &wp, const f32x4 (&in)[KT], f32x4 (&out)[NT], int v16, RingT<B3> &ring, Epi epi) {
+  if constexpr (B3) {
+    static_assert(KT % 2 == 0, "K-steps are pairs of 16-feature tiles");
+    Bop b[KT / 2], unused[NT / 2];
+#pragma unroll
+    for (int ks = 0; ks < KT / 2; ++ks) b[ks] = split_pair(in[2 * ks], in[2 * ks + 1]);
+    linear_b<KT / 2, NT, ACC, false, 6 * RPI>(W, wp, b, out, unused, v16, ring.b, epi);
+  } else {
+    linear_s<KT, NT, ACC, 4 * RPI>(W, wp, in, out, v16, ring.f, epi);
+  }
+}
+
+template <int NW, bool PROF, bool B3>
 __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
   constexpr int NTHREADS = NW * 64, MAXA = Lds<NW>::MAXA;
   __shared__ Lds<NW> lds;
@@ -319,9 +441,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     tprev = clock64();
   }
   float *const pk = lds.park[wave];
-  f32x4 ring[RING];                            // the weight-fragment stream (see linear_s)
+  RingT<B3> ring;                              // the weight-fragment stream (see linear_s / linear_b)
   int wp = A.o_stream;
-  ring_prime(WB, wp, v16, ring);
+  if constexpr (B3) ring_prime_b(WB, wp, v16, ring.b);
+  else ring_prime(WB, wp, v16, ring.f);
   if (tid < MAXA) lds.eacc[tid] = 0.0;
   if (lane < 6) lds.virw[wave][lane] = 0.0;
   if (tid < A.T * A.T) lds.rc[tid] = (float)A.rcut[tid];
@@ -398,16 +521,16 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         bfin[0][r] = g < 2 ? pref * __builtin_amdgcn_sinf(0.5f * n * xx) * inv * fc : 0.f;
         bfin[1][r] = 0.f;
       }
-      linear_s<2, 4, true, 0>(WB, wp, bfin, z, v16, ring, EpiSiluSaveD{SB, R_Z1TB(), v16});
-      linear_s<4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, R_Z2TB(), v16});
-      linear_s<4, 4, false, 0>(WB, wp, z2, x, v16, ring, EpiSaveScale{{SB, R_U0(), v16}, fc});
+      lin<B3, 2, 4, true, 0>(WB, wp, bfin, z, v16, ring, EpiSiluSaveD{SB, R_Z1TB(), v16});
+      lin<B3, 4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, R_Z2TB(), v16});
+      lin<B3, 4, 4, false, 0>(WB, wp, z2, x, v16, ring, EpiSaveScale{{SB, R_U0(), v16}, fc});
     }
     PHASE(PH_TB);
     // ---------------- tensor embedding weights (V^0 = w0 (x) Y is rebuilt where needed) -------------
     {
       f32x4 w0[4];
       // w0 goes to scratch (backward) and to the LDS park rows 0..3, where layer 0 picks it up
-      linear_s<4, 4, false, 0>(WB, wp, x, w0, v16, ring, EpiSavePark{{SB, R_W0(), v16}, pk, 0, lane});
+      lin<B3, 4, 4, false, 0>(WB, wp, x, w0, v16, ring, EpiSavePark{{SB, R_W0(), v16}, pk, 0, lane});
     }
     if (ck == 0 && tid == 0) lds.chunk[cpar ^ 1] = claimed;
     __syncthreads();          // aoff visible; previous tile's LDS users done
@@ -421,7 +544,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       f32x4 V[4][2];
       {
         f32x4 om[4];
-        linear_s<4, 4, false, 0>(WB, wp, x, om, v16, ring, EpiSave{SB, RL + 0, v16});
+        lin<B3, 4, 4, false, 0>(WB, wp, x, om, v16, ring, EpiSave{SB, RL + 0, v16});
         // environment sum over the centre's edges
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -479,21 +602,21 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       // channel mixing -> V^{kk+1}: saved in the next layer's VIN rows and parked in LDS
       if (!last) {
         f32x4 o2[2];
-        linear_s<2, 2, false, 0>(WB, wp, Vp[0], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1) + 16 + 0, v16}, pk, 0, lane});
-        linear_s<2, 2, false, 4>(WB, wp, Vp[1], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1) + 16 + 2, v16}, pk, 2, lane});
-        linear_s<2, 2, false, 0>(WB, wp, Vp[2], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1) + 16 + 4, v16}, pk, 4, lane});
-        linear_s<2, 2, false, 4>(WB, wp, Vp[3], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1) + 16 + 6, v16}, pk, 6, lane});
+        lin<B3, 2, 2, false, 0>(WB, wp, Vp[0], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1) + 16 + 0, v16}, pk, 0, lane});
+        lin<B3, 2, 2, false, 1>(WB, wp, Vp[1], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1) + 16 + 2, v16}, pk, 2, lane});
+        lin<B3, 2, 2, false, 0>(WB, wp, Vp[2], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1) + 16 + 4, v16}, pk, 4, lane});
+        lin<B3, 2, 2, false, 1>(WB, wp, Vp[3], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1) + 16 + 6, v16}, pk, 6, lane});
       }
       PHASE(PH_MIX);
       // latent MLP
       {
         f32x4 cat[6], z[4], z2[4];
         cat[0] = x[0]; cat[1] = x[1]; cat[2] = x[2]; cat[3] = x[3]; cat[4] = Vp[0][0]; cat[5] = Vp[0][1];
-        linear_s<6, 4, false, 0>(WB, wp, cat, z, v16, ring, EpiSiluSaveD{SB, RL + 4, v16});
-        linear_s<4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, RL + 8, v16});
+        lin<B3, 6, 4, false, 0>(WB, wp, cat, z, v16, ring, EpiSiluSaveD{SB, RL + 4, v16});
+        lin<B3, 4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, RL + 8, v16});
         const float ra = lds.res[kk][0], rbf = lds.res[kk][1] * fc;
         f32x4 xn[4];
-        linear_s<4, 4, false, 0>(WB, wp, z2, xn, v16, ring, EpiResidual<4>{{SB, RL + 12, v16}, x, ra, rbf});
+        lin<B3, 4, 4, false, 0>(WB, wp, z2, xn, v16, ring, EpiResidual<4>{{SB, RL + 12, v16}, x, ra, rbf});
         x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2]; x[3] = xn[3];
       }
       PHASE(PH_LAT);
@@ -507,7 +630,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     load_rows<4>(SB, R_LAYER(NL - 1) + 8, zt, v16);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 zr[2];
-    linear_s<4, 2, false, 0>(WB, wp, x, zr, v16, ring, EpiNone{});
+    lin<B3, 4, 2, false, 0>(WB, wp, x, zr, v16, ring, EpiNone{});
     f32x4 wo1[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) wo1[t] = *(const f32x4 *)(Wb + A.o_out1 + 16 * t + 4 * g);
@@ -527,7 +650,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dzr[t][r] = deps * wo1[t][r] * dsilu1(zr[t][r]);
-      linear_s<2, 4, false, 0>(WB, wp, dzr, dx, v16, ring, EpiNone{});
+      lin<B3, 2, 4, false, 0>(WB, wp, dzr, dx, v16, ring, EpiNone{});
     }
     float dfc_part = 0.f, dY1 = 0.f, dY2 = 0.f, dY3 = 0.f;
     PHASE(PH_OUT);
@@ -554,16 +677,16 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         f32x4 zt1[4];
         load_rows<4>(SB, RL + 4, zt1, v16);                  // z1: first used 96 MFMAs from here
         __builtin_amdgcn_sched_barrier(0);
-        linear_s<4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt});
+        lin<B3, 4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt});
         // prefetch V^{kk} (input of this layer's tensor product) under the MFMAs that follow
         if (kk > 0) {
 #pragma unroll
           for (int lm = 0; lm < 4; ++lm) load_rows<2>(SB, RL + 16 + 2 * lm, Vk[lm], v16);
         } else load_rows<4>(SB, R_W0(), W0b, v16);
         __builtin_amdgcn_sched_barrier(0);
-        linear_s<4, 4, false, 0>(WB, wp, dh, du, v16, ring, EpiMulRows<4>{zt1});
+        lin<B3, 4, 4, false, 0>(WB, wp, dh, du, v16, ring, EpiMulRows<4>{zt1});
         f32x4 dcat[6];
-        linear_s<4, 6, false, 0>(WB, wp, du, dcat, v16, ring, EpiNone{});
+        lin<B3, 4, 6, false, 0>(WB, wp, du, dcat, v16, ring, EpiNone{});
 #pragma unroll
         for (int t = 0; t < 4; ++t) dx[t] += dcat[t];
         dVp[0][0] = dcat[4]; dVp[0][1] = dcat[5];             // ds
@@ -582,14 +705,14 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       if (!last) {
         f32x4 in2[2], o2[2];
         in2[0] = park_load(pk, 0, lane); in2[1] = park_load(pk, 1, lane);
-        linear_s<2, 2, false, 0>(WB, wp, in2, o2, v16, ring, EpiNone{});
+        lin<B3, 2, 2, false, 0>(WB, wp, in2, o2, v16, ring, EpiNone{});
         dVp[0][0] += o2[0]; dVp[0][1] += o2[1];
         in2[0] = park_load(pk, 2, lane); in2[1] = park_load(pk, 3, lane);
-        linear_s<2, 2, false, 4>(WB, wp, in2, dVp[1], v16, ring, EpiNone{});
+        lin<B3, 2, 2, false, 1>(WB, wp, in2, dVp[1], v16, ring, EpiNone{});
         in2[0] = park_load(pk, 4, lane); in2[1] = park_load(pk, 5, lane);
-        linear_s<2, 2, false, 0>(WB, wp, in2, dVp[2], v16, ring, EpiNone{});
+        lin<B3, 2, 2, false, 0>(WB, wp, in2, dVp[2], v16, ring, EpiNone{});
         in2[0] = park_load(pk, 6, lane); in2[1] = park_load(pk, 7, lane);
-        linear_s<2, 2, false, 4>(WB, wp, in2, dVp[3], v16, ring, EpiNone{});
+        lin<B3, 2, 2, false, 1>(WB, wp, in2, dVp[3], v16, ring, EpiNone{});
       }
       __builtin_amdgcn_sched_barrier(0);
       PHASE(PH_BMIX);
@@ -659,7 +782,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
           load_rows<2>(SB, R_W0() + 2, w0h, v16);
         }
         __builtin_amdgcn_sched_barrier(0);
-        linear_s<4, 4, true, 0>(WB, wp, dom, dx, v16, ring, EpiNone{});
+        lin<B3, 4, 4, true, 0>(WB, wp, dom, dx, v16, ring, EpiNone{});
       }
       PHASE(PH_BENV);
     }
@@ -677,7 +800,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { dY1 += d1[r] * w0h[t][r]; dY2 += d2[r] * w0h[t][r]; dY3 += d3[r] * w0h[t][r]; }
       }
-      linear_s<4, 4, true, 0>(WB, wp, dw0, dx, v16, ring, EpiNone{});
+      lin<B3, 4, 4, true, 0>(WB, wp, dw0, dx, v16, ring, EpiNone{});
     }
     PHASE(PH_BEMB);
     // ---------------- two-body MLP backward ----------------
@@ -691,10 +814,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         for (int r = 0; r < 4; ++r) { acc += upre[t][r] * dx[t][r]; du[t][r] = fc * dx[t][r]; }
       dfc_part += acc;
       __builtin_amdgcn_sched_barrier(0);
-      linear_s<4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt});
-      linear_s<4, 4, false, 0>(WB, wp, dh, du, v16, ring, EpiMulRows<4>{zt1b});
+      lin<B3, 4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt});
+      lin<B3, 4, 4, false, 0>(WB, wp, dh, du, v16, ring, EpiMulRows<4>{zt1b});
       f32x4 dbf[2];
-      linear_s<4, 2, false, 0>(WB, wp, du, dbf, v16, ring, EpiNone{});   // its prefetches already fetch the next tile's first fragments
+      lin<B3, 4, 2, false, 0>(WB, wp, du, dbf, v16, ring, EpiNone{});   // its prefetches already fetch the next tile's first fragments
       wp = A.o_stream;                                                    // (the stream ends with a copy of its first RING entries)
       const float dfdd = dfc_dx / rc;
 #pragma unroll
@@ -838,6 +961,7 @@ struct FusedState {
   DevBuf wbuf, scratch, seg_count, seg_base, tile_a0, tile_e0, centre, ntiles, partial;
   FusedArgs args;
   bool ready = false, prof_on = false, dbg_on = false, clk_on = false;
+  bool b3 = false;             // f32-input MFMA (default) or bf16x3 arithmetic (option fused_arith=bf16x3 / AHIP_FUSED_ARITH=b3)
   DevBuf prof, dbg;
   int ncu = 256;
   int force_nw = 0;            // AHIP_FUSED_NW=4|8 pins the workgroup shape (A/B measurements)
@@ -865,6 +989,45 @@ static int append_frag(std::vector<float> &out, const double *W, int K, int N, i
             out.push_back((k < K && n < N) ? (float)W[(size_t)k * ldw + n] : 0.f);
           }
   return KT * NT;
+}
+// bf16x3 fragments of W [K][N]: per (tile pair p, K-step ks) six 1 KiB entries hi0 hi1 mid0 mid1 lo0 lo1; lane (i, g) of an
+// entry holds the 8 k-slots of its group: slots 0..3 = rows 16 (2 ks) + 4 g + s, slots 4..7 = rows 16 (2 ks + 1) + 4 g + s - 4;
+// column 16 (2 p + half) + i.  Terms by truncation (exact three-way split of the f32 weight).
+static inline unsigned bf16_trunc_bits(float f) { unsigned u; std::memcpy(&u, &f, 4); return u >> 16; }
+static inline float bf16_bits_to_f(unsigned h) { unsigned u = h << 16; float f; std::memcpy(&f, &u, 4); return f; }
+static void frag_dims_b(int K, int N, int &KS, int &NT) {
+  KS = (K + 31) / 32;
+  NT = (N + 15) / 16;
+  NT += NT & 1;
+}
+static int append_frag_b(std::vector<float> &out, const double *W, int K, int N, int ldw) {
+  int KS, NT;
+  frag_dims_b(K, N, KS, NT);
+  for (int p = 0; p < NT / 2; ++p)
+    for (int ks = 0; ks < KS; ++ks)
+      for (int term = 0; term < 3; ++term)
+        for (int half = 0; half < 2; ++half)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int w = 0; w < 4; ++w) {
+              unsigned word = 0;
+              for (int e = 0; e < 2; ++e) {
+                const int sl = 2 * w + e, g = lane >> 4;
+                const int k = sl < 4 ? 16 * (2 * ks) + 4 * g + sl : 16 * (2 * ks + 1) + 4 * g + (sl - 4);
+                const int n = 16 * (2 * p + half) + (lane & 15);
+                const float v = (k < K && n < N) ? (float)W[(size_t)k * ldw + n] : 0.f;
+                const unsigned hi = bf16_trunc_bits(v);
+                const float r1 = v - bf16_bits_to_f(hi);
+                const unsigned mid = bf16_trunc_bits(r1);
+                const float r2 = r1 - bf16_bits_to_f(mid);
+                const unsigned lo = bf16_trunc_bits(r2);
+                const unsigned t = term == 0 ? hi : term == 1 ? mid : lo;
+                word |= t << (16 * e);
+              }
+              float f;
+              std::memcpy(&f, &word, 4);
+              out.push_back(f);
+            }
+  return 6 * KS * (NT / 2);
 }
 static std::vector<double> transpose(const double *W, int K, int N) {
   std::vector<double> t((size_t)K * N);
@@ -904,8 +1067,17 @@ static void fused_prepare(Model &m) {
   // ---- the weight stream, in the order one tile consumes it ----
   A.o_stream = mark();
   const size_t stream0 = w.size();
-  auto fwd = [&](const double *W, int K, int N) { append_frag(w, W, K, N, N); };
-  auto bwd = [&](const double *W, int K, int N) { auto t = transpose(W, K, N); append_frag(w, t.data(), N, K, K); };
+  {
+    const char *ar = std::getenv("AHIP_FUSED_ARITH");
+    std::string arith = ar ? ar : m.opt_fused_arith;
+    st.b3 = arith == "b3" || arith == "bf16x3";
+  }
+  const bool b3 = st.b3;
+  auto fwd = [&](const double *W, int K, int N) { if (b3) append_frag_b(w, W, K, N, N); else append_frag(w, W, K, N, N); };
+  auto bwd = [&](const double *W, int K, int N) {
+    auto t = transpose(W, K, N);
+    if (b3) append_frag_b(w, t.data(), N, K, K); else append_frag(w, t.data(), N, K, K);
+  };
   auto T_ = [&](const std::string &name) -> const double * { return h.get(name).data.data(); };
   const double *wc = w0.data.data() + (size_t)2 * T * 64;       // Bessel block [8][64]
   fwd(wc, 8, 64);
@@ -943,7 +1115,7 @@ static void fused_prepare(Model &m) {
   bwd(T_("tb.w1"), 64, 64);
   bwd(wc, 8, 64);
   {   // wrap-around copy: the last linear of a tile prefetches the first fragments of the next tile
-    const size_t n = (size_t)RING * 256;
+    const size_t n = (size_t)(b3 ? RINGB : RING) * 256;
     for (size_t i = 0; i < n; ++i) w.push_back(w[stream0 + i]);
   }
   // small tables
@@ -1042,11 +1214,19 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
       A.prof = st.prof.as<long long>();
     }
     if (st.prof_on) {
-      if (nw == 4) hipLaunchKernelGGL((k_fused<4, true>), dim3(grid), dim3(256), 0, s, A);
-      else hipLaunchKernelGGL((k_fused<8, true>), dim3(grid), dim3(512), 0, s, A);
+      if (st.b3) {
+        if (nw == 4) hipLaunchKernelGGL((k_fused<4, true, true>), dim3(grid), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL((k_fused<8, true, true>), dim3(grid), dim3(512), 0, s, A);
+      } else {
+        if (nw == 4) hipLaunchKernelGGL((k_fused<4, true, false>), dim3(grid), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL((k_fused<8, true, false>), dim3(grid), dim3(512), 0, s, A);
+      }
+    } else if (st.b3) {
+      if (nw == 4) hipLaunchKernelGGL((k_fused<4, false, true>), dim3(grid), dim3(256), 0, s, A);
+      else hipLaunchKernelGGL((k_fused<8, false, true>), dim3(grid), dim3(512), 0, s, A);
     } else {
-      if (nw == 4) hipLaunchKernelGGL((k_fused<4, false>), dim3(grid), dim3(256), 0, s, A);
-      else hipLaunchKernelGGL((k_fused<8, false>), dim3(grid), dim3(512), 0, s, A);
+      if (nw == 4) hipLaunchKernelGGL((k_fused<4, false, false>), dim3(grid), dim3(256), 0, s, A);
+      else hipLaunchKernelGGL((k_fused<8, false, false>), dim3(grid), dim3(512), 0, s, A);
     }
   }
   AHIP_CHECK(hipGetLastError());
@@ -1125,6 +1305,34 @@ __global__ void __launch_bounds__(128) k_selftest_linear(const float *Wf, int wb
     }
 }
 
+template <int KS, int NT>
+__global__ void __launch_bounds__(128) k_selftest_linear_b(const float *Wf, int wbytes, const float *in, int K, float *out, int N) {
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, row = (threadIdx.x >> 6) * 16 + j;
+  f32x4 a[2 * KS], o[NT];
+#pragma unroll
+  for (int t = 0; t < 2 * KS; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int k = feat16(t, r, g);
+      a[t][r] = k < K ? in[row * K + k] : 0.f;
+    }
+  Bop b[KS], ob[NT / 2];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) b[ks] = split_pair(a[2 * ks], a[2 * ks + 1]);
+  __amdgpu_buffer_rsrc_t WB = __builtin_amdgcn_make_buffer_rsrc((void *)Wf, 0, wbytes, 0x00020000);
+  u32x4 ring[RINGB];
+  int wp = 0;
+  ring_prime_b(WB, wp, lane * 16, ring);
+  linear_b<KS, NT, false, false, 0>(WB, wp, b, o, ob, lane * 16, ring, EpiNone{});
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int n = feat16(t, r, g);
+      if (n < N) out[row * N + n] = o[t][r];
+    }
+}
+
 }  // namespace ahip
 
 using namespace ahip;
@@ -1141,11 +1349,13 @@ extern "C" int ahip_debug_fused_edges(ahip_model *mh, float *out, long long nedg
 
 extern "C" int ahip_debug_fused_linear(int K, int N, const double *W, const float *in, float *out) {
   try {
+    const char *ar = std::getenv("AHIP_FUSED_ARITH");
+    const bool b3 = ar && (std::string(ar) == "b3" || std::string(ar) == "bf16x3");
     std::vector<float> frag;
-    append_frag(frag, W, K, N, N);
-    frag.resize(frag.size() + (size_t)(RING + 2) * 256, 0.f);       // the ring prefetches past the end
     int KT, NT;
-    frag_dims(K, N, KT, NT);
+    if (b3) { append_frag_b(frag, W, K, N, N); frag_dims_b(K, N, KT, NT); }
+    else { append_frag(frag, W, K, N, N); frag_dims(K, N, KT, NT); }
+    frag.resize(frag.size() + (size_t)(RINGB + 2) * 256, 0.f);      // the ring prefetches past the end
     float *dW = nullptr, *din = nullptr, *dout = nullptr;
     AHIP_CHECK(hipMalloc((void **)&dW, frag.size() * sizeof(float)));
     AHIP_CHECK(hipMalloc((void **)&din, (size_t)32 * K * sizeof(float)));
@@ -1154,6 +1364,17 @@ extern "C" int ahip_debug_fused_linear(int K, int N, const double *W, const floa
     AHIP_CHECK(hipMemcpy(din, in, (size_t)32 * K * sizeof(float), hipMemcpyHostToDevice));
     bool ok = true;
     const int wbytes = (int)(frag.size() * sizeof(float));
+#define CASEB(ks, nt) hipLaunchKernelGGL((k_selftest_linear_b<ks, nt>), dim3(1), dim3(128), 0, 0, dW, wbytes, din, K, dout, N)
+    if (b3) {
+      if (KT == 1 && NT == 2) CASEB(1, 2);
+      else if (KT == 1 && NT == 4) CASEB(1, 4);
+      else if (KT == 2 && NT == 2) CASEB(2, 2);
+      else if (KT == 2 && NT == 4) CASEB(2, 4);
+      else if (KT == 3 && NT == 4) CASEB(3, 4);
+      else if (KT == 2 && NT == 6) CASEB(2, 6);
+      else ok = false;
+    } else
+#undef CASEB_
 #define CASE(kt, nt) hipLaunchKernelGGL((k_selftest_linear<kt, nt>), dim3(1), dim3(128), 0, 0, dW, wbytes, din, K, dout, N)
     if (KT == 2 && NT == 2) CASE(2, 2);
     else if (KT == 2 && NT == 4) CASE(2, 4);

@@ -36,7 +36,108 @@ __global__ void __launch_bounds__(256, OCC) k_rate(const float *W, int wbytes, f
   if (lane == 0) out[blockIdx.x * 4 + wave] = t1 - t0;
 }
 
+template <int EPI, int OCC>
+__global__ void __launch_bounds__(256, OCC) k_rate_b(const float *W, int wbytes, float *scr, long long *out, int iters) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, v16 = lane * 16;
+  __shared__ float pad[OCC == 2 ? 20000 : 40000];
+  pad[threadIdx.x] = 0.f;
+  __amdgpu_buffer_rsrc_t WB = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, wbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t SB = __builtin_amdgcn_make_buffer_rsrc((void *)(scr + ((size_t)blockIdx.x * 4 + wave) * 16 * ROW), 0, 16 * ROW * 4, 0x00020000);
+  f32x4 x[4], y[4];
+  u32x4 ring[RINGB];
+  for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r) x[t][r] = 0.001f * (float)((lane * 7 + t * 4 + r) % 13);
+  Bop xb[2], yb[2];
+  xb[0] = split_pair(x[0], x[1]); xb[1] = split_pair(x[2], x[3]);
+  int wp = 0;
+  ring_prime_b(WB, wp, v16, ring);
+  for (int it = 0; it < iters; ++it) {
+    wp = 0;
+    if (EPI == 0) {
+      linear_b<2, 4, false, true, 0>(WB, wp, xb, y, yb, v16, ring, EpiNone{});
+      linear_b<2, 4, false, true, 0>(WB, wp, yb, x, xb, v16, ring, EpiNone{});
+    } else {
+      linear_b<2, 4, false, true, 0>(WB, wp, xb, y, yb, v16, ring, EpiSiluSaveD{SB, 0, v16});
+      linear_b<2, 4, false, true, 0>(WB, wp, yb, x, xb, v16, ring, EpiSiluSaveD{SB, 4, v16});
+    }
+  }
+  float sum = 0.f;
+  for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r) sum += x[t][r];
+  if (sum == 12345.678f) out[0] = (long long)pad[lane];
+}
+
+// weight-stream bandwidth: every wave reads the same `entries`-KiB stream (L2 resident) with `DEPTH` 1-KiB loads in flight,
+// waves start at different positions (like 8 waves of a CU at different points of a tile)
+template <int DEPTH, int OCC, int SPREAD = 37>
+__global__ void __launch_bounds__(256, OCC) k_stream(const float *W, int wbytes, int entries, long long *out, int iters) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, v16 = lane * 16;
+  __shared__ float pad[OCC == 2 ? 20000 : 40000];
+  pad[threadIdx.x] = 0.f;
+  __amdgpu_buffer_rsrc_t WB = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, wbytes, 0x00020000);
+  f32x4 ring[DEPTH];
+  int pos = ((blockIdx.x * 4 + wave) * SPREAD) % entries;
+  for (int i = 0; i < DEPTH; ++i) { ring[i] = bload(WB, v16, pos * 1024); pos = pos + 1 == entries ? 0 : pos + 1; }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) {
+      acc += ring[i];
+      ring[i] = bload(WB, v16, pos * 1024);
+      pos = pos + 1 == entries ? 0 : pos + 1;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[0] = (long long)pad[lane];
+}
+
 int main() {
+  {
+    const int entries = 1344;     // ~ the bf16x3 stream of model S
+    float *dW; long long *out;
+    hipMalloc((void **)&dW, (size_t)entries * 1024); hipMemset(dW, 0, (size_t)entries * 1024);
+    hipMalloc((void **)&out, 64);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int iters = 4000;
+    auto run = [&](const char *name, int grid, int depth, auto kern) {
+      for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, dW, entries * 1024, entries, out, iters);
+        hipEventRecord(e1, 0); hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double bytes = (double)grid * 4 * iters * depth * 1024.0;
+        if (rep) std::printf("%-28s %7.3f ms  %6.2f TB/s  = %5.1f B/clk/CU at 2.3 GHz\n", name, ms, bytes / (ms * 1e-3) * 1e-12, bytes / 256.0 / (ms * 1e-3 * 2.3e9));
+      }
+    };
+    {
+      // bf16x3 linears: 64->64 = 24 entries, two per iteration + wrap copy
+      const int eb = 48 + RINGB;
+      float *dWb, *scrb;
+      hipMalloc((void **)&dWb, (size_t)eb * 1024); hipMemset(dWb, 0, (size_t)eb * 1024);
+      hipMalloc((void **)&scrb, (size_t)1024 * 4 * 16 * ROW * 4);
+      const int itb = 2000;
+      auto runb = [&](const char *name, int grid, auto kern) {
+        for (int rep = 0; rep < 2; ++rep) {
+          hipEventRecord(e0, 0);
+          hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, dWb, eb * 1024, scrb, out, itb);
+          hipEventRecord(e1, 0); hipDeviceSynchronize();
+          float ms; hipEventElapsedTime(&ms, e0, e1);
+          // f32-equivalent flops: 2 linears of 64x64 per 16 edges
+          const double fl = (double)grid * 4 * itb * 2.0 * 64 * 64 * 16 * 2;
+          if (rep) std::printf("%-40s %7.3f ms  %6.1f f32-equivalent TFLOP/s, %5.0f cycles per 64x64 linear per wave at 2.3 GHz\n", name, ms, fl / (ms * 1e-3) * 1e-12, ms * 1e-3 * 2.3e9 / (itb * 2.0));
+        }
+      };
+      runb("bf16x3 no epilogue + split, 1 wave/SIMD", 256, k_rate_b<0, 1>);
+      runb("bf16x3 no epilogue + split, 2 waves/SIMD", 512, k_rate_b<0, 2>);
+      runb("bf16x3 silu+save+split, 1 wave/SIMD", 256, k_rate_b<1, 1>);
+      runb("bf16x3 silu+save+split, 2 waves/SIMD", 512, k_rate_b<1, 2>);
+    }
+    run("stream depth 8, 4 waves/CU", 256, 8, k_stream<8, 1>);
+    run("stream depth 8, 8 waves/CU", 512, 8, k_stream<8, 2>);
+    run("stream depth 16, 8 waves/CU", 512, 16, k_stream<16, 2>);
+    run("stream depth 4, 8 waves/CU", 512, 4, k_stream<4, 2>);
+    run("depth 8, 8 waves/CU, same position", 512, 8, k_stream<8, 2, 0>);
+    run("depth 8, 8 waves/CU, 1 entry apart", 512, 8, k_stream<8, 2, 1>);
+  }
+
   const int entries = 32 + RING;
   std::vector<float> w((size_t)entries * 256);
   for (size_t i = 0; i < w.size(); ++i) w[i] = 0.01f * (float)((i * 2654435761u >> 7) % 17) - 0.08f;

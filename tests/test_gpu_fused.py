@@ -11,8 +11,12 @@ from pair_allegro_amd import cg, lmp_like, model_file
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("arith", ["f32", "bf16x3"])
 @pytest.mark.parametrize("K,N", [(8, 64), (32, 32), (32, 64), (64, 32), (64, 64), (96, 64), (64, 96), (64, 8)])
-def test_mfma_linear_primitive(hip_lib, K, N):
+def test_mfma_linear_primitive(hip_lib, K, N, arith, monkeypatch):
+    """The streamed register-chain linear, on the f32-input MFMA and on the bf16x3 split (six bf16 MFMA terms):
+    both must reproduce x @ W to float32 accuracy."""
+    monkeypatch.setenv("AHIP_FUSED_ARITH", arith)
     rng = np.random.RandomState(K * 100 + N)
     W = rng.normal(size=(K, N))                    # asymmetric: catches transposed fragments
     x = rng.normal(size=(32, K)).astype(np.float32)
@@ -51,6 +55,46 @@ def test_fused_vs_oracle_two_types(hip_lib, model_dir, nl):
     util.assert_close_to(fused, ref, 5e-4, what=f"fused vs f64 oracle nl={nl}")
     assert np.abs(fused["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
     np.testing.assert_allclose(fused["forces"], gen["forces"], atol=2e-5)
+
+
+def test_fused_bf16x3_arithmetic_matches_f32(hip_lib, model_dir):
+    """Option fused_arith=bf16x3 (exact 3-way bf16 split, six MFMA terms, f32 accumulate) is float32-equivalent:
+    same distance to the float64 oracle as the f32-input MFMA kernel."""
+    g = util.load_golden("CuPd-cubic-big_r5")
+    path, cfg, types, names, ref = _model_S_case(model_dir, "cupd_S_b3", ["Cu", "Pd"], g["symbols"], g["cell"], g["pos"])
+    f32 = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused"})
+    b3 = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused", "fused_arith": "bf16x3"})
+    util.assert_close_to(b3, ref, 5e-4, what="fused bf16x3 vs f64 oracle")
+    e32 = np.abs(f32["forces"] - ref["forces"]).max()
+    eb3 = np.abs(b3["forces"] - ref["forces"]).max()
+    assert eb3 < max(2.0 * e32, 1e-5), (eb3, e32)
+    np.testing.assert_allclose(b3["forces"], f32["forces"], atol=1e-5)
+    np.testing.assert_allclose(b3["pe"], f32["pe"], rtol=2e-6)
+
+
+def test_fused_wide_tiles_65_to_128_neighbours(hip_lib, model_dir):
+    """fcc Cu with r_max 6.1 A has 78 neighbours per atom: more than the 64-slot tile of the default 4-wave workgroup,
+    so the 8-wave / 128-slot kernel instance runs; it must agree with the oracle like the narrow one."""
+    g = util.load_golden("Cu-cubic_r15")
+    reps = 3
+    cell = g["cell"] * reps
+    shifts = np.array([[i, j, k] for i in range(reps) for j in range(reps) for k in range(reps)], dtype=float)
+    pos = np.concatenate([g["pos"] + s @ g["cell"] for s in shifts])
+    rng = np.random.RandomState(3)
+    pos = pos + rng.uniform(-0.05, 0.05, size=pos.shape)
+    symbols = ["Cu"] * len(pos)
+    nb = float(len(util.glue.brute_force_edges(cell, pos, 6.1)[0])) / len(pos)
+    cfg = model_file.model_S(type_names=["Cu"], r_max=6.1, avg_num_neighbors=nb)
+    w = model_file.init_weights(cfg)
+    path = f"{model_dir}/cu61_S.nequip.pth"
+    allegro_torch.export_nequip_pth(path, cfg, w)
+    types = np.ones(len(pos), dtype=np.int32)
+    ref = util.oracle_run(dict(cfg, model_dtype="float64"), w, cell, pos, types, ["Cu"])
+    res = util.run_pair(hip_lib, path, cell, pos, types, ["Cu"], options={"path": "fused"})
+    assert res["info"]["path"] == "fused_f32"
+    assert 64 < res["info"]["max_degree"] <= 128
+    util.assert_close_to(res, ref, 5e-4, what="wide-tile fused vs f64 oracle")
+    assert np.abs(res["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
 
 
 def test_fused_multi_rank_and_ragged_tiles(hip_lib, model_dir):

@@ -112,6 +112,18 @@ int ahip_compute_dev(ahip_model *m, int nlocal, int nghost, const double *x_dev,
                      const double *cutoff_matrix_model, double *f_dev, double *eatom_dev,
                      double *eng_vir_dev, void *stream);
 
+/* `compute allegro` / `compute allegro/atom` support: named entries of the model's output dict kept from the last
+ * ahip_compute call (reference: the pair style stashes `output.at(name)` for every name registered through
+ * add_custom_output, pair_nequip_allegro.cpp:403-406,681-684; compute/compute_allegro.cpp:81,114,145 reads them).
+ * Entries this model's graph returns: "atomic_energy" [nlocal+nghost] (ghosts carry only their per-type shift, as in the
+ * TorchScript model), "forces" [nlocal+nghost][3] (this evaluation's forces, before they are added to f),
+ * "virial" [3][3], "total_energy" [1] (sum of atomic_energy over locals AND ghosts, cf. compute/README.md).
+ * ahip_output_register: unknown names are accepted here and fail at the next ahip_compute, like the reference's
+ * `output.at(name)`.  ahip_output_get copies the flattened tensor (capacity in doubles; *count = its length; pass out = NULL
+ * to query the length).  Host-pointer ahip_compute only. */
+int ahip_output_register(ahip_model *m, const char *name);
+int ahip_output_get(ahip_model *m, const char *name, double *out, long long capacity, long long *count);
+
 /* Edge list of the last compute: the tensors the reference would have handed to the model
  * (edge_index i64 [2][E], pair_nequip_allegro.cpp:601-602) plus |r_ij|.  Pass NULL buffers to
  * query nedges only.  This is what the `_NEQUIP_LOG_LEVEL=DEBUG` dump prints (:562-565,625). */

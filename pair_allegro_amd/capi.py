@@ -21,7 +21,7 @@ AHIP_OK, AHIP_ERR_ARG, AHIP_ERR_FILE, AHIP_ERR_DEVICE, AHIP_ERR_STATE, AHIP_ERR_
 SYMBOLS = [
     "ahip_last_error", "ahip_device_count", "ahip_model_load", "ahip_model_free", "ahip_model_meta",
     "ahip_set_option", "ahip_neigh_update", "ahip_neigh_update_csr", "ahip_neigh_update_dev",
-    "ahip_compute", "ahip_compute_dev", "ahip_get_edges", "ahip_debug_dump_edges", "ahip_get_timings",
+    "ahip_compute", "ahip_compute_dev", "ahip_output_register", "ahip_output_get", "ahip_get_edges", "ahip_debug_dump_edges", "ahip_get_timings",
     "ahip_last_path", "ahip_last_max_degree", "ahip_debug_fused_linear", "ahip_debug_fused_edges", "ahip_build_neighbors_dev", "ahip_nve_dev",
 ]
 
@@ -51,6 +51,8 @@ class Library:
         L.ahip_last_path.restype = C.c_char_p
         L.ahip_last_path.argtypes = [C.c_void_p]
         L.ahip_last_max_degree.argtypes = [C.c_void_p]
+        L.ahip_output_register.argtypes = [C.c_void_p, C.c_char_p]
+        L.ahip_output_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.c_longlong, C.POINTER(C.c_longlong)]
         L.ahip_device_count.argtypes = [C.POINTER(C.c_int)]
         L.ahip_model_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
         L.ahip_model_free.argtypes = [C.c_void_p]
@@ -230,3 +232,14 @@ class Model:
     @property
     def last_max_degree(self) -> int:
         return int(self.L.lib.ahip_last_max_degree(self.h))
+
+    # ---- `compute allegro` outputs (pair_nequip_allegro.cpp:403-406,681-684) ---------------------
+    def output_register(self, name: str) -> None:
+        self.L.check(self.L.lib.ahip_output_register(self.h, name.encode()))
+
+    def output_get(self, name: str) -> np.ndarray:
+        n = C.c_longlong(0)
+        self.L.check(self.L.lib.ahip_output_get(self.h, name.encode(), None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.float64)
+        self.L.check(self.L.lib.ahip_output_get(self.h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_double)), n.value, C.byref(n)))
+        return out

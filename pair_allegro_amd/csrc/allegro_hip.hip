@@ -330,7 +330,12 @@ int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const i
     hipStream_t s = nullptr;
     *eng = 0;
     if (virial) for (int k = 0; k < 6; ++k) virial[k] = 0;
-    if (m->inum == 0) return;
+    m->custom_out.clear();
+    if (m->inum == 0) return;          // empty domain: nothing is stored (compute_allegro.cpp:106-112)
+    for (const std::string &nm : m->custom_names)                      // the reference's output.at(name) (:404-405)
+      if (nm != "atomic_energy" && nm != "forces" && nm != "virial" && nm != "total_energy")
+        throw ArgError("model output '" + nm + "' not found (this model returns atomic_energy, forces, virial, total_energy)");
+    const bool want_eatom = eatom != nullptr || !m->custom_names.empty();
 
     // types: LAMMPS 1-based -> filter index (type-1) and model type (pair_nequip_allegro.cpp:576)
     m->h_ftype.resize(nall); m->h_mtype.resize(nall);
@@ -356,17 +361,17 @@ int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const i
     AHIP_CHECK(hipMemcpyAsync(m->b_cutsq.p, cutsq.data(), cutsq.size() * sizeof(double), hipMemcpyHostToDevice, s));
     m->h_cutsq_dev.clear();
     AHIP_CHECK(hipMemsetAsync(m->b_f.p, 0, (size_t)nall * 3 * sizeof(double), s));
-    if (eatom) AHIP_CHECK(hipMemsetAsync(m->b_eatom.p, 0, (size_t)nall * sizeof(double), s));
+    if (want_eatom) AHIP_CHECK(hipMemsetAsync(m->b_eatom.p, 0, (size_t)nall * sizeof(double), s));
 
     ComputeArgs a{nlocal, nghost, m->b_x.as<double>(), m->b_ftype.as<int>(), m->b_cutsq.as<double>(), ntypes,
-                  m->b_mtype.as<int>(), m->b_f.as<double>(), eatom ? m->b_eatom.as<double>() : nullptr,
+                  m->b_mtype.as<int>(), m->b_f.as<double>(), want_eatom ? m->b_eatom.as<double>() : nullptr,
                   m->b_engvir.as<double>(), s};
     run_model(m, a);
 
     m->h_f.resize((size_t)nall * 3);
     double ev[7];
     AHIP_CHECK(hipMemcpyAsync(m->h_f.data(), m->b_f.p, (size_t)nall * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (eatom) {
+    if (want_eatom) {
       m->h_eatom.resize(nall);
       AHIP_CHECK(hipMemcpyAsync(m->h_eatom.data(), m->b_eatom.p, (size_t)nall * sizeof(double), hipMemcpyDeviceToHost, s));
     }
@@ -378,7 +383,45 @@ int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const i
       for (int ii = 0; ii < m->inum; ++ii) { int i = m->h_ilist.empty() ? ii : m->h_ilist[ii]; eatom[i] = m->h_eatom[i]; }
     *eng = ev[0];
     if (virial) for (int k = 0; k < 6; ++k) virial[k] = ev[1 + k];
+    if (!m->custom_names.empty()) {
+      // the model's output dict entries (pair_nequip_allegro.cpp:403-406): rows for locals AND ghosts
+      std::vector<double> ae(nall);
+      const HostTensor &shift = m->hm.get("shift");
+      for (int i = 0; i < nall; ++i) ae[i] = shift.data[m->h_mtype[i]];        // ghosts: no centre edges -> shift only
+      for (int ii = 0; ii < m->inum; ++ii) { int i = m->h_ilist.empty() ? ii : m->h_ilist[ii]; ae[i] = m->h_eatom[i]; }
+      double tot = 0;
+      for (double v : ae) tot += v;
+      for (const std::string &nm : m->custom_names) {
+        if (nm == "atomic_energy") m->custom_out[nm] = ae;
+        else if (nm == "forces") m->custom_out[nm] = m->h_f;
+        else if (nm == "total_energy") m->custom_out[nm] = {tot};
+        else m->custom_out[nm] = {ev[1], ev[4], ev[5], ev[4], ev[2], ev[6], ev[5], ev[6], ev[3]};    // [3][3] from xx yy zz xy xz yz
+      }
+    }
     collect_timings(m);
+  });
+}
+
+int ahip_output_register(ahip_model *m, const char *name) {
+  return guarded([&] {
+    require_model(m);
+    if (!name || !*name) throw ArgError("ahip_output_register: empty name");
+    m->custom_names.push_back(name);
+  });
+}
+
+int ahip_output_get(ahip_model *m, const char *name, double *out, long long capacity, long long *count) {
+  return guarded([&] {
+    require_model(m);
+    if (!name || !count) throw ArgError("ahip_output_get: NULL name/count");
+    auto it = m->custom_out.find(name);
+    if (it == m->custom_out.end())
+      throw StateError(std::string("output '") + name + "' is not stored: register it with ahip_output_register before ahip_compute "
+                       "(host-pointer call, nlocal > 0)");
+    *count = (long long)it->second.size();
+    if (!out) return;
+    if (capacity < *count) throw ArgError("ahip_output_get: buffer too small");
+    std::copy(it->second.begin(), it->second.end(), out);
   });
 }
 

@@ -118,6 +118,10 @@ struct Model {
   int last_max_deg = 0;
   std::string last_path;
 
+  // `compute allegro`: registered output names and their values from the last host-path compute
+  std::vector<std::string> custom_names;
+  std::map<std::string, std::vector<double>> custom_out;
+
   // timings
   std::vector<TimingSlot> slots;
   std::string timing_names;

@@ -127,6 +127,8 @@ void PairAllegroHIP::coeff(int narg, char **arg)
   int rc = ahip_model_load(model_path.c_str(), device, &model);
   if (rc == AHIP_ERR_FILE) throw std::runtime_error(ahip_last_error());    // the reference throws here too (:205)
   if (rc != AHIP_OK) error->all(FLERR, "pair_allegro: {}", ahip_last_error());
+  for (const std::string &name : custom_output_names)       // computes defined before pair_coeff
+    if (ahip_output_register(model, name.c_str()) != AHIP_OK) error->all(FLERR, "pair_allegro: {}", ahip_last_error());
 
   double r_max;
   int num_model_types;
@@ -168,7 +170,6 @@ void PairAllegroHIP::compute(int eflag, int vflag)
 {
   ev_init(eflag, vflag);
   if (vflag_atom) error->all(FLERR, "Pair styles nequip and allegro do not support per-atom virial");    // :394
-  for (const std::string &name : custom_output_names) error->all(FLERR, "missing {}", name);             // :404
 
   int inum = list->inum;
   if (inum == 0) return;    // empty sub-domain (:340-341)
@@ -195,4 +196,17 @@ void PairAllegroHIP::compute(int eflag, int vflag)
   if (debug_mode) ahip_debug_dump_edges(model, atom->tag);    // "Allegro edges: i j rij" (:562-565,620-633)
 }
 
-void PairAllegroHIP::add_custom_output(std::string name) { custom_output_names.push_back(name); }
+void PairAllegroHIP::add_custom_output(std::string name)    // :681-684
+{
+  custom_output_names.push_back(name);
+  if (model && ahip_output_register(model, name.c_str()) != AHIP_OK) error->all(FLERR, "pair_allegro: {}", ahip_last_error());
+}
+
+std::vector<double> PairAllegroHIP::custom_output(const std::string &name)
+{
+  long long n = 0;
+  if (ahip_output_get(model, name.c_str(), nullptr, 0, &n) != AHIP_OK) error->one(FLERR, "pair_allegro: {}", ahip_last_error());
+  std::vector<double> v((size_t)n);
+  if (n > 0 && ahip_output_get(model, name.c_str(), v.data(), n, &n) != AHIP_OK) error->one(FLERR, "pair_allegro: {}", ahip_last_error());
+  return v;
+}

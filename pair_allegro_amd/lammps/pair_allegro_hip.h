@@ -43,10 +43,11 @@ class PairAllegroHIP : public Pair {
   std::vector<int> type_mapper;    // LAMMPS type-1 -> model type, -1 = unmapped
   std::string model_path;
 
-  // `compute allegro` hooks of the reference (pair_nequip_allegro.h:80-82); the HIP model has no
-  // extra outputs yet, so a registered name is an error at compute time like the reference's "missing {}".
+  // `compute allegro` hooks of the reference (pair_nequip_allegro.h:80-82): names registered here are kept from the
+  // model's output dict at every compute(); custom_output(name) is the reference's custom_output.at(name).cpu().ravel().
   std::vector<std::string> custom_output_names;
   void add_custom_output(std::string);
+  std::vector<double> custom_output(const std::string &name);
 
  protected:
   int debug_mode = 0;

@@ -7,6 +7,7 @@ lammps_dir=${1:?usage: patch_lammps.sh <lammps dir> [repo dir]}
 repo_dir=${2:-$(cd "$(dirname "$0")/../.." && pwd)}
 [ -f "$lammps_dir/cmake/CMakeLists.txt" ] || { echo "$lammps_dir does not look like a LAMMPS tree"; exit 1; }
 cp "$repo_dir"/pair_allegro_amd/lammps/pair_allegro_hip.{h,cpp} "$lammps_dir/src/"
+cp "$repo_dir"/pair_allegro_amd/lammps/compute_allegro_hip.{h,cpp} "$lammps_dir/src/"      # compute allegro, compute allegro/atom
 cp "$repo_dir"/include/allegro_hip.h "$lammps_dir/src/"
 cat >> "$lammps_dir/cmake/CMakeLists.txt" <<CMAKE
 

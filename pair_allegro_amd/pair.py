@@ -106,6 +106,8 @@ class PairAllegro:
             print(f"NequIP/Allegro: Loading model from {self.model_path}")
         try:
             self.model = capi.Model(self.model_path, self.device, self.lib)                # :214-232
+            for name in self.custom_output_names:
+                self.model.output_register(name)
         except capi.AhipError as e:
             if e.code == capi.AHIP_ERR_FILE:
                 raise RuntimeError(e.msg) from None      # reference throws std::runtime_error (:205)
@@ -180,6 +182,16 @@ class PairAllegro:
 
     def add_custom_output(self, name: str) -> None:                                        # :681-684
         self.custom_output_names.append(name)
+        if self.model is not None:
+            self.model.output_register(name)
+
+    def custom_output(self, name: str) -> np.ndarray:
+        """`custom_output.at(name).cpu().ravel()` of the reference (pair_nequip_allegro.h:80-82): the entry of the
+        model's output dict kept from the last compute()."""
+        try:
+            return self.model.output_get(name)
+        except capi.AhipError as e:
+            raise LammpsError(e.msg) from None
 
 
 def atom_from_rank_system(rs: RankSystem, ntypes: int) -> Atom:

@@ -2,6 +2,7 @@
 // (settings -> coeff -> init_style -> init_one -> compute) on a system read from a flat binary file
 // written by tests/test_lammps_cpp.py, and writes forces / energy / virial back.
 #include "pair_allegro_hip.h"
+#include "compute_allegro_hip.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -32,8 +33,10 @@ int main(int argc, char **argv) {
   for (int i = 0; i < nall; i++) { xp[i] = &x[3 * (size_t)i]; fp[i] = &fr[3 * (size_t)i]; first[i] = flat.data() + off; off += numneigh[i]; }
   for (int i = 0; i < nlocal; i++) ilist[i] = i;
 
-  Atom atom; Comm comm; Force force; Neighbor neighbor; Error error; Memory memory; NeighList list;
+  Atom atom; Comm comm; Force force; Neighbor neighbor; Error error; Memory memory; NeighList list; Update update;
   LAMMPS lmp{&atom, &comm, &force, &neighbor, &error, &memory};
+  lmp.update = &update;
+  atom.nmax = nall; comm.tag = tag.data(); comm.nlocal = nlocal; comm.nghost = nghost;
   atom.ntypes = ntypes; atom.nlocal = nlocal; atom.nghost = nghost; atom.x = xp.data(); atom.f = fp.data(); atom.type = type.data(); atom.tag = tag.data();
   list.inum = nlocal; list.gnum = nghost; list.ilist = ilist.data(); list.numneigh = numneigh.data(); list.firstneigh = first.data();
   int rc = 0;
@@ -47,6 +50,15 @@ int main(int argc, char **argv) {
     args.push_back(star); args.push_back(star);
     for (int k = 3; k < argc; k++) args.push_back(argv[k]);
     pair.coeff((int)args.size(), args.data());
+    force.pair = &pair;
+    // `compute allegro` family, defined after the pair style like in a deck (only when the test asks: env DRIVER_COMPUTES)
+    const bool with_computes = std::getenv("DRIVER_COMPUTES") != nullptr;
+    char c_id[] = "c", c_all[] = "all", c_v[] = "allegro", c_a[] = "allegro/atom", q_vir[] = "virial", q_f[] = "forces", q_e[] = "atomic_energy",
+         n9[] = "9", n3[] = "3", n1[] = "1", n0[] = "0";
+    char *av[] = {c_id, c_all, c_v, q_vir, n9}, *af[] = {c_id, c_all, c_a, q_f, n3, n1}, *ae[] = {c_id, c_all, c_a, q_e, n1, n0};
+    ComputeAllegroHIP<0> *cvir = with_computes ? new ComputeAllegroHIP<0>(&lmp, 5, av) : nullptr;
+    ComputeAllegroHIP<1> *cfor = with_computes ? new ComputeAllegroHIP<1>(&lmp, 6, af) : nullptr;
+    ComputeAllegroHIP<1> *cen = with_computes ? new ComputeAllegroHIP<1>(&lmp, 6, ae) : nullptr;
     pair.init_style();
     if (neighbor.requested != (NeighConst::REQ_FULL | NeighConst::REQ_GHOST)) { fprintf(stderr, "bad neighbor request\n"); return 4; }
     const double cut = pair.init_one(1, 1);
@@ -59,6 +71,13 @@ int main(int argc, char **argv) {
     fwrite(pair.virial, sizeof(double), 6, o);
     fwrite(fr.data(), sizeof(double), fr.size(), o);
     fwrite(eatom.data(), sizeof(double), eatom.size(), o);
+    if (with_computes) {
+      cvir->compute_vector(); cfor->compute_peratom(); cen->compute_peratom();
+      fwrite(cvir->vector, sizeof(double), 9, o);
+      for (int i = 0; i < nlocal; i++) fwrite(cfor->array_atom[i], sizeof(double), 3, o);      // ghost rows folded in (newton 1)
+      fwrite(cen->vector_atom, sizeof(double), nlocal, o);
+      delete cvir; delete cfor; delete cen;
+    }
     fclose(o);
     printf("restartinfo=%d manybody=%d no_fdotr=%d setflag11=%d\n", pair.restartinfo, pair.manybody_flag, pair.no_virial_fdotr_compute, pair.setflag[1][1]);
   } catch (const LammpsAbort &e) { printf("LAMMPS error->all: %s\n", e.what()); rc = 10; }

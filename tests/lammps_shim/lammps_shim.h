@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #define FLERR __FILE__, __LINE__
 #define NEIGHMASK 0x1FFFFFFF
@@ -27,6 +28,7 @@ class Error {
   [[noreturn]] void all(const char *, int, const std::string &m, const char *a) { throw LammpsAbort(fmt(m, a)); }
   [[noreturn]] void all(const char *, int, const std::string &m, const std::string &a) { throw LammpsAbort(fmt(m, a.c_str())); }
   [[noreturn]] void one(const char *, int, const std::string &m, const char *a) { throw LammpsAbort(fmt(m, a)); }
+  void message(const char *, int, const std::string &m) { std::printf("%s\n", m.c_str()); }
 };
 class Memory {
  public:
@@ -37,18 +39,29 @@ class Memory {
     return a;
   }
   template <typename T> void destroy(T **&a) { if (a) { delete[] a[0]; delete[] a; a = nullptr; } }
+  template <typename T> T *create(T *&a, int n, const char *) { a = new T[n](); return a; }
+  template <typename T> void destroy(T *&a) { delete[] a; a = nullptr; }
 };
-class Atom { public: int tag_enable = 1, ntypes = 1, nlocal = 0, nghost = 0; double **x = nullptr, **f = nullptr; int *type = nullptr; tagint *tag = nullptr; };
-class Comm { public: int me = 0, nprocs = 1; };
-class Force { public: int newton_pair = 1; };
+class Atom { public: int tag_enable = 1, ntypes = 1, nlocal = 0, nghost = 0, nmax = 0; double **x = nullptr, **f = nullptr; int *type = nullptr; tagint *tag = nullptr; };
+class Compute;
+class Pair;
+class Comm {
+ public:
+  int me = 0, nprocs = 1;
+  // single-rank periodic reverse communication: ghost rows are added to their owner (tag-1 == owner index here)
+  tagint *tag = nullptr; int nlocal = 0, nghost = 0;
+  inline void reverse_comm(Compute *c);
+};
+class Force { public: int newton_pair = 1; Pair *pair = nullptr; };
+class Update { public: bigint ntimestep = 0; };
 class NeighList { public: int inum = 0, gnum = 0; int *ilist = nullptr, *numneigh = nullptr; int **firstneigh = nullptr; };
 namespace NeighConst { enum { REQ_FULL = 1, REQ_GHOST = 2 }; }
-class Pair;
 class Neighbor { public: bigint lastcall = 0; int requested = 0; void add_request(Pair *, int flags) { requested = flags; } };
 
 class LAMMPS {
  public:
   Atom *atom; Comm *comm; Force *force; Neighbor *neighbor; Error *error; Memory *memory; MPI_Comm world = 0;
+  Update *update = nullptr;
 };
 
 class Pair {
@@ -75,4 +88,28 @@ class Pair {
  protected:
   LAMMPS *lmp; Atom *atom; Comm *comm; Force *force; Neighbor *neighbor; Error *error; Memory *memory; MPI_Comm world;
 };
+
+class Compute {
+ public:
+  Compute(LAMMPS *l, int, char **) : lmp(l), atom(l->atom), comm(l->comm), force(l->force), error(l->error), memory(l->memory),
+                                     update(l->update), world(l->world) {}
+  virtual ~Compute() = default;
+  virtual void init() = 0;
+  virtual void compute_vector() {}
+  virtual void compute_peratom() {}
+  virtual int pack_reverse_comm(int, int, double *) { return 0; }
+  virtual void unpack_reverse_comm(int, int *, double *) {}
+  int peratom_flag = 0, vector_flag = 0, extvector = 0, size_vector = 0, size_peratom_cols = 0, comm_reverse = 0, copymode = 0;
+  bigint invoked_vector = -1, invoked_peratom = -1;
+  double *vector = nullptr, *vector_atom = nullptr, **array_atom = nullptr;
+ protected:
+  LAMMPS *lmp; Atom *atom; Comm *comm; Force *force; Error *error; Memory *memory; Update *update; MPI_Comm world;
+};
+inline void Comm::reverse_comm(Compute *c) {
+  std::vector<double> buf((size_t)nghost * c->comm_reverse);
+  c->pack_reverse_comm(nghost, nlocal, buf.data());
+  std::vector<int> owners(nghost);
+  for (int k = 0; k < nghost; k++) owners[k] = tag[nlocal + k] - 1;
+  c->unpack_reverse_comm(nghost, owners.data(), buf.data());
+}
 }    // namespace LAMMPS_NS

@@ -97,6 +97,36 @@ def test_fused_wide_tiles_65_to_128_neighbours(hip_lib, model_dir):
     assert np.abs(res["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
 
 
+def test_compute_allegro_outputs_on_the_fused_path(hip_lib, model_dir):
+    """`compute allegro/atom forces 3 1` and `atomic_energy 1 0` served by the fused kernel's results."""
+    from pair_allegro_amd.compute import ComputeAllegro
+    from pair_allegro_amd.pair import PairAllegro, atom_from_rank_system, list_from_rank_system
+    g = util.load_golden("CuPd-cubic-big_r5")
+    path, cfg, types, names, ref = _model_S_case(model_dir, "cupd_S_cmp", ["Cu", "Pd"], g["symbols"], g["cell"], g["pos"])
+    pair = PairAllegro(me=0, nprocs=1, lib=hip_lib, quiet=True)
+    pair.settings([])
+    pair.coeff(["*", "*", path] + list(names), ntypes=len(names))
+    cf = ComputeAllegro(["f", "all", "allegro/atom", "forces", "3", "1"], pair)
+    ce = ComputeAllegro(["e", "all", "allegro/atom", "atomic_energy", "1", "0"], pair)
+    cv = ComputeAllegro(["v", "all", "allegro", "virial", "9"], pair)
+    pair.model.set_option("path", "fused")
+    rs = lmp_like.build_rank_system(g["cell"], g["pos"], types, 6.0)
+    atom = atom_from_rank_system(rs, len(names))
+    pair.compute(atom, list_from_rank_system(rs))
+    assert pair.model.last_path == "fused_f32"
+    arr = cf.compute_peratom(rs.nlocal, rs.nall).copy()
+    np.add.at(arr, rs.tag[rs.nlocal:] - 1, cf.pack_reverse_comm(rs.nghost, rs.nlocal).reshape(-1, 3))
+    forces = np.zeros_like(ref["forces"])
+    forces[rs.tag[: rs.nlocal] - 1] = arr[: rs.nlocal]
+    assert np.abs(forces - ref["forces"]).max() < pc.NORTH_STAR_DF
+    e = ce.compute_peratom(rs.nlocal, rs.nall)[: rs.nlocal, 0]
+    np.testing.assert_allclose(e, ref["eatom"][rs.tag[: rs.nlocal] - 1], atol=5e-4)
+    xx, yy, zz, xy, xz, yz = ref["virial"]
+    np.testing.assert_allclose(cv.compute_vector(rs.nlocal).reshape(3, 3), [[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]],
+                               atol=20 * 5e-4 * len(g["pos"]) ** 0.5)
+    pair.model.close()
+
+
 def test_fused_multi_rank_and_ragged_tiles(hip_lib, model_dir):
     """2x2x1 ranks; Cu2AgO4 (7 atoms, ragged degrees, 3 types, triclinic) exercises partial tiles."""
     g = util.load_golden("Cu2AgO4_r5")

@@ -43,7 +43,8 @@ def test_cpp_pair_style_matches_oracle(driver, tmp_path, model_dir):
     rs = lmp_like.build_rank_system(g["cell"], g["pos"], types, 6.0)
     sysf, outf = str(tmp_path / "sys.bin"), str(tmp_path / "out.bin")
     _write_system(sysf, rs, len(names))
-    r = subprocess.run([driver, sysf, outf, mpath] + names, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    r = subprocess.run([driver, sysf, outf, mpath] + names, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       env=dict(os.environ, DRIVER_COMPUTES="1"))
     text = r.stdout.decode()
     assert r.returncode == 0, text
     assert "restartinfo=0 manybody=1 no_fdotr=1 setflag11=1" in text
@@ -51,7 +52,9 @@ def test_cpp_pair_style_matches_oracle(driver, tmp_path, model_dir):
     out = np.fromfile(outf, dtype=np.float64)
     cut, eng, vir = out[0], out[1], out[2:8]
     f = out[8:8 + 3 * rs.nall].reshape(-1, 3)
-    eatom = out[8 + 3 * rs.nall:]
+    eatom = out[8 + 3 * rs.nall: 8 + 4 * rs.nall]
+    extra = out[8 + 4 * rs.nall:]                              # the three `compute allegro` results (C++ ComputeAllegroHIP)
+    c_vir, c_f, c_e = extra[:9].reshape(3, 3), extra[9:9 + 3 * rs.nlocal].reshape(-1, 3), extra[9 + 3 * rs.nlocal:]
     ref = util.oracle_run(cfg, w, g["cell"], g["pos"], types, names)
     forces = np.zeros_like(ref["forces"])
     np.add.at(forces, rs.tag - 1, f)
@@ -60,6 +63,10 @@ def test_cpp_pair_style_matches_oracle(driver, tmp_path, model_dir):
     np.testing.assert_allclose(eng, ref["pe"], rtol=1e-10)
     np.testing.assert_allclose(vir, ref["virial"], atol=1e-8)
     np.testing.assert_allclose(eatom[: rs.nlocal], ref["eatom"][rs.tag[: rs.nlocal] - 1], atol=1e-10)
+    xx, yy, zz, xy, xz, yz = ref["virial"]
+    np.testing.assert_allclose(c_vir, [[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]], atol=1e-8)      # compute allegro virial 9
+    np.testing.assert_allclose(c_f, ref["forces"][rs.tag[: rs.nlocal] - 1], atol=1e-9)             # allegro/atom forces 3 1
+    np.testing.assert_allclose(c_e, ref["eatom"][rs.tag[: rs.nlocal] - 1], atol=1e-10)             # allegro/atom atomic_energy 1 0
 
 
 def test_cpp_pair_style_deck_errors(driver, tmp_path, model_dir):

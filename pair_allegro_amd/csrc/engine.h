@@ -181,6 +181,16 @@ void fused_free(Model &m);
 bool edges_build_f32(Model &m, const ComputeArgs &a);
 void edges_free(Model &m);
 
+// ---- float32 dense layers of the generic path on the matrix cores (gemm.hip; the host-emulation build links a stub
+// returning false and keeps the one-thread-per-output kernels) ----
+// C[e][n] (+)= sum_k A[e][k] * (transB ? W[n][k] : W[k][n])
+bool gemm_f32(hipStream_t s, long long E, int K, int N, const float *A, int lda, const float *W, int ldw, bool transB, float *C,
+              int ldc, bool accumulate);
+// wave-per-row versions of k_latent_update_bwd / k_embed_bwd_Y (same stubs in the emulation build)
+bool latent_update_bwd_f32(hipStream_t s, long long E, int S, const float *dx, const float *u, const float *fc, const float *res,
+                           float *du, float *dfc, float *dxprev);
+bool embed_bwd_Y_f32(hipStream_t s, long long E, int D, int U, const float *dV, const float *w, float *dY);
+
 // ---- neighbor builder (neigh.hip; stubbed in the host-emulation build) -------------------------
 void neigh_build(Model &m, int nlocal, int nall, const double *x_dev, const double *lo, const double *hi,
                  double rc_list, hipStream_t s);

@@ -1,0 +1,133 @@
+// Dense layers of the generic (any model shape) float32 path on the matrix cores:
+//   C[e][n] (+)= sum_k A[e][k] * B(k, n),   B(k, n) = W[k][n]  (forward, x @ W)   or  W[n][k]  (backward, dy @ W^T).
+// E is the edge count of a chunk (10^5..10^6), K and N are model widths (8..300), so this is a tall-skinny GEMM
+// whose traffic is the activations: 4 E (K + N) bytes -- HBM-bound (intensity K N / (2 (K + N)) = 16 FLOP/B at 64x64).
+// One workgroup = 64 rows x 64 columns, four waves of 16 rows each; K is walked in steps of 16 through LDS
+// (A tile 64x16, B tile 16x64, padded rows: conflict-free operand reads); v_mfma_f32_16x16x4_f32, exact f32.
+// Replaces the one-thread-per-output kernels k_linear / k_linear_bwd (generic_kernels.h), which stay for the float64
+// debug build and the CPU-emulated tests: they ran at 80-400 GB/s (78 % of the generic path's time).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "engine.h"
+
+namespace ahip {
+
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+
+template <bool TRANSB>
+__global__ void __launch_bounds__(256) k_gemm_f32(long long E, int K, int N, const float *__restrict__ A, int lda,
+                                                   const float *__restrict__ W, int ldw, float *__restrict__ C, int ldc,
+                                                   int accumulate) {
+  __shared__ float sA[64][17];
+  __shared__ float sB[16][65];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const long long e0 = (long long)blockIdx.x * 64;
+  const int n0 = blockIdx.y * 64;
+  f32x4g acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4g{0.f, 0.f, 0.f, 0.f};
+  const int ar = tid >> 2, ac = (tid & 3) * 4;          // A tile: row, first of 4 columns
+  const int bk = tid >> 4, bn = (tid & 15) * 4;         // B tile: k row, first of 4 columns
+  const long long arow = e0 + ar;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + ac + i;
+      sA[ar][ac + i] = (arow < E && k < K) ? A[arow * lda + k] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + bk, n = n0 + bn + i;
+      float v = 0.f;
+      if (k < K && n < N) v = TRANSB ? W[(long long)n * ldw + k] : W[(long long)k * ldw + n];
+      sB[bk][bn + i] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const float a = sA[16 * wave + j][4 * ks + g];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sB[4 * ks + g][16 * t + j], acc[t], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int n = n0 + 16 * t + j;
+    if (n >= N) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long e = e0 + 16 * wave + 4 * g + r;
+      if (e < E) {
+        float *p = C + e * ldc + n;
+        *p = accumulate ? *p + acc[t][r] : acc[t][r];
+      }
+    }
+  }
+}
+
+bool gemm_f32(hipStream_t s, long long E, int K, int N, const float *A, int lda, const float *W, int ldw, bool transB, float *C,
+              int ldc, bool accumulate) {
+  if (E <= 0 || N <= 0) return true;
+  const dim3 grid((unsigned)((E + 63) / 64), (unsigned)((N + 63) / 64));
+  if (transB) hipLaunchKernelGGL(k_gemm_f32<true>, grid, dim3(256), 0, s, E, K, N, A, lda, W, ldw, C, ldc, accumulate ? 1 : 0);
+  else hipLaunchKernelGGL(k_gemm_f32<false>, grid, dim3(256), 0, s, E, K, N, A, lda, W, ldw, C, ldc, accumulate ? 1 : 0);
+  return true;
+}
+
+// ---- row-reduction kernels (one wave per edge row, coalesced, shuffle reduce) for the two element-wise backward steps
+// that the one-thread-per-edge versions did with 256-byte strides (300 GB/s) ------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+// du = b fc dx ; dfc[e] += b sum_s u dx ; dxprev = a dx     (k_latent_update_bwd)
+__global__ void __launch_bounds__(256) k_latent_update_bwd_rows(long long E, int S, const float *dx, const float *u, const float *fc,
+                                                                 const float *res, float *du, float *dfc, float *dxprev) {
+  const int lane = threadIdx.x & 63;
+  const long long nw = (long long)gridDim.x * 4;
+  const float a = res[0], b = res[1];
+  for (long long e = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); e < E; e += nw) {
+    const float f = fc[e];
+    float acc = 0.f;
+    for (int s = lane; s < S; s += 64) {
+      const float dxv = dx[e * S + s];
+      acc += u[e * S + s] * dxv;
+      du[e * S + s] = b * f * dxv;
+      if (dxprev) dxprev[e * S + s] = a * dxv;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) dfc[e] += b * acc;
+  }
+}
+// dY[e][lm] += sum_u dV[e][lm][u] w[e][l(lm)][u]            (k_embed_bwd_Y)
+__global__ void __launch_bounds__(256) k_embed_bwd_Y_rows(long long E, int D, int U, const float *dV, const float *w, float *dY) {
+  const int lane = threadIdx.x & 63;
+  const long long nw = (long long)gridDim.x * 4;
+  const int nl = (D == 1) ? 1 : (D == 4 ? 2 : 3);
+  for (long long e = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); e < E; e += nw) {
+    for (int lm = 0; lm < D; ++lm) {
+      const int l = lm == 0 ? 0 : (lm < 4 ? 1 : 2);
+      float acc = 0.f;
+      for (int q = lane; q < U; q += 64) acc += dV[(e * D + lm) * U + q] * w[e * nl * U + l * U + q];
+      acc = wave_sum(acc);
+      if (lane == 0) dY[e * D + lm] += acc;
+    }
+  }
+}
+static unsigned row_grid(long long E) { return (unsigned)std::min<long long>((E + 3) / 4, 256LL * 64); }
+
+bool latent_update_bwd_f32(hipStream_t s, long long E, int S, const float *dx, const float *u, const float *fc, const float *res,
+                           float *du, float *dfc, float *dxprev) {
+  if (E > 0) hipLaunchKernelGGL(k_latent_update_bwd_rows, dim3(row_grid(E)), dim3(256), 0, s, E, S, dx, u, fc, res, du, dfc, dxprev);
+  return true;
+}
+bool embed_bwd_Y_f32(hipStream_t s, long long E, int D, int U, const float *dV, const float *w, float *dY) {
+  if (E > 0) hipLaunchKernelGGL(k_embed_bwd_Y_rows, dim3(row_grid(E)), dim3(256), 0, s, E, D, U, dV, w, dY);
+  return true;
+}
+
+}  // namespace ahip

@@ -1,6 +1,8 @@
 // Generic path orchestration: edge build (shared with the fused path) and the layer-at-a-time
 // forward / backward over chunks of centre atoms.
 #pragma once
+#include <type_traits>
+
 #include "engine.h"
 #include "generic_kernels.h"
 #include "prims.h"
@@ -88,6 +90,59 @@ static void generic_chunk(Model &m, const ComputeArgs &a, Arena &A, int c0, int 
   const size_t E = (size_t)Ec;
 
 #define RUN(...) do { if (go) { launch(__VA_ARGS__); } } while (0)
+  // dense layers: MFMA GEMM for float32 (gemm.hip), the portable kernels otherwise
+  auto linear_fwd = [&](int K, int N, const T *in, int ldin, const T *Wp, T *out, int ldout) {
+    if (!go) return;
+    if constexpr (std::is_same<T, float>::value)
+      if (gemm_f32(s, Ec, K, N, in, ldin, Wp, N, false, out, ldout, false)) return;
+    launch(k_linear<T>, Ec * N, s, Ec, K, N, in, ldin, Wp, out, ldout);
+  };
+  auto linear_bwd = [&](int K, int N, const T *dout, int lddout, const T *Wp, T *din, int lddin, int accumulate) {
+    if (!go) return;
+    if constexpr (std::is_same<T, float>::value)
+      if (gemm_f32(s, Ec, N, K, dout, lddout, Wp, N, true, din, lddin, accumulate != 0)) return;
+    launch(k_linear_bwd<T>, Ec * K, s, Ec, K, N, dout, lddout, Wp, din, lddin, accumulate);
+  };
+  auto lofl = [](int lm) { return lm == 0 ? 0 : (lm < 4 ? 1 : 2); };
+  // channel mixing V[e][lm][:] = Vp[e][lm][:] @ mix[l]: one GEMM per lm with row stride D*U (float32), else k_mix
+  auto mix_fwd = [&](int Dm, const T *Vp_, const T *mixw, T *Vout) {
+    if (!go) return;
+    if constexpr (std::is_same<T, float>::value) {
+      bool ok = true;
+      for (int lm = 0; lm < Dm && ok; ++lm)
+        ok = gemm_f32(s, Ec, U, U, Vp_ + lm * U, Dm * U, mixw + (size_t)lofl(lm) * U * U, U, false, Vout + lm * U, Dm * U, false);
+      if (ok) return;
+    }
+    launch(k_mix<T>, Ec * Dm * U, s, Ec, Dm, U, Vp_, mixw, Vout);
+  };
+  // dVp[e][lm][:] = dV[e][lm][:] @ mix[l]^T (+ ds on lm = 0)
+  auto mix_bwd = [&](int Dm, const T *dV_, const T *mixw, const T *ds, int ldds, T *dVp_) {
+    if (!go) return;
+    if constexpr (std::is_same<T, float>::value) {
+      if (dV_) {
+        bool ok = true;
+        for (int lm = 0; lm < Dm && ok; ++lm)
+          ok = gemm_f32(s, Ec, U, U, dV_ + lm * U, Dm * U, mixw + (size_t)lofl(lm) * U * U, U, true, dVp_ + lm * U, Dm * U, false);
+        if (ok) {
+          if (ds) launch(k_add_cols<T>, Ec * U, s, Ec, U, ds, ldds, dVp_, Dm * U);
+          return;
+        }
+      }
+    }
+    launch(k_mix_bwd<T>, Ec * Dm * U, s, Ec, Dm, U, dV_, mixw, ds, ldds, dVp_);
+  };
+  auto latent_bwd = [&](const T *dx_, const T *u_, const T *fc_, const T *resw, T *du_, T *dfc_, T *dxprev_) {
+    if (!go) return;
+    if constexpr (std::is_same<T, float>::value)
+      if (latent_update_bwd_f32(s, Ec, S, dx_, u_, fc_, resw, du_, dfc_, dxprev_)) return;
+    launch(k_latent_update_bwd<T>, Ec, s, Ec, S, dx_, u_, fc_, resw, du_, dfc_, dxprev_);
+  };
+  auto embed_bwd_Y = [&](const T *dV_, const T *w_, T *dY_) {
+    if (!go) return;
+    if constexpr (std::is_same<T, float>::value)
+      if (embed_bwd_Y_f32(s, Ec, D, U, dV_, w_, dY_)) return;
+    launch(k_embed_bwd_Y<T>, Ec * D, s, Ec, D, U, dV_, w_, dY_);
+  };
 
   // ---------------- forward ----------------
   T *fc = A.get<T>(E), *Y = A.get<T>(E * D), *a_in = A.get<T>(E * Ka);
@@ -98,12 +153,12 @@ static void generic_chunk(Model &m, const ComputeArgs &a, Arena &A, int c0, int 
     const T *cur = in; int K = din;
     for (int k = 0; k < nhidden; ++k) {
       T *z = A.get<T>(E * width), *hh = A.get<T>(E * width);
-      RUN(k_linear<T>, Ec * width, s, Ec, K, width, cur, K, go ? W.get(pre + ".w" + std::to_string(k)) : nullptr, z, width);
+      linear_fwd(K, width, cur, K, go ? W.get(pre + ".w" + std::to_string(k)) : nullptr, z, width);
       RUN(k_silu<T>, Ec * width, s, Ec * width, z, hh);
       zs.push_back(z); cur = hh; K = width;
     }
     out = A.get<T>(E * dout);
-    RUN(k_linear<T>, Ec * dout, s, Ec, K, dout, cur, K, go ? W.get(pre + ".w" + std::to_string(nhidden)) : nullptr, out, dout);
+    linear_fwd(K, dout, cur, K, go ? W.get(pre + ".w" + std::to_string(nhidden)) : nullptr, out, dout);
   };
   // backward of mlp: dout [E][dout] -> din [E][din]; returns pointer to din
   auto mlp_bwd = [&](const std::string &pre, int nhidden, int din, int width, int dout, const std::vector<T *> &zs,
@@ -112,7 +167,7 @@ static void generic_chunk(Model &m, const ComputeArgs &a, Arena &A, int c0, int 
     for (int k = nhidden; k >= 0; --k) {
       int K = (k == 0) ? din : width;
       T *dprev = A.get<T>(E * K);
-      RUN(k_linear_bwd<T>, Ec * K, s, Ec, K, N, d, N, go ? W.get(pre + ".w" + std::to_string(k)) : nullptr, dprev, K, 0);
+      linear_bwd(K, N, d, N, go ? W.get(pre + ".w" + std::to_string(k)) : nullptr, dprev, K, 0);
       if (k > 0) RUN(k_silu_bwd<T>, Ec * K, s, Ec * K, zs[k - 1], dprev, dprev);
       d = dprev; N = K;
     }
@@ -127,7 +182,7 @@ static void generic_chunk(Model &m, const ComputeArgs &a, Arena &A, int c0, int 
   x[0] = A.get<T>(E * S);
   RUN(k_latent_update<T>, Ec * S, s, Ec, S, (const T *)nullptr, u0, fc, go ? W.get("res.identity") : nullptr, x[0]);
   T *w0 = A.get<T>(E * nl * U);
-  RUN(k_linear<T>, Ec * nl * U, s, Ec, S, nl * U, x[0], S, go ? W.get("emb.w") : nullptr, w0, nl * U);
+  linear_fwd(S, nl * U, x[0], S, go ? W.get("emb.w") : nullptr, w0, nl * U);
   V[0] = A.get<T>(E * D * U);
   RUN(k_embed<T>, Ec * D * U, s, Ec, D, U, w0, Y, V[0]);
 
@@ -137,7 +192,7 @@ static void generic_chunk(Model &m, const ComputeArgs &a, Arena &A, int c0, int 
     const int Dout = last ? 1 : D;
     const int ncg = last ? m.ncg_scalar : m.ncg_full;
     om[k] = A.get<T>(E * nl * U);
-    RUN(k_linear<T>, Ec * nl * U, s, Ec, S, nl * U, x[k - 1], S, go ? W.get(lk + ".env") : nullptr, om[k], nl * U);
+    linear_fwd(S, nl * U, x[k - 1], S, go ? W.get(lk + ".env") : nullptr, om[k], nl * U);
     env[k] = A.get<T>((size_t)nc * D * U);
     RUN(k_env_reduce<T>, (long long)nc * D * U, s, nc, c0, eoff, e0, D, U, om[k], Y, cenv, env[k]);
     T *Vp = A.get<T>(E * Dout * U);
@@ -149,7 +204,7 @@ static void generic_chunk(Model &m, const ComputeArgs &a, Arena &A, int c0, int 
     RUN(k_latent_update<T>, Ec * S, s, Ec, S, x[k - 1], u[k], fc, go ? W.get(lk + ".res") : nullptr, x[k]);
     if (!last) {
       V[k] = A.get<T>(E * D * U);
-      RUN(k_mix<T>, Ec * D * U, s, Ec, D, U, Vp, go ? W.get(lk + ".mix") : nullptr, V[k]);
+      mix_fwd(D, Vp, go ? W.get(lk + ".mix") : nullptr, V[k]);
     }
   }
   std::vector<T *> z_out;
@@ -170,12 +225,12 @@ static void generic_chunk(Model &m, const ComputeArgs &a, Arena &A, int c0, int 
     const int Dout = last ? 1 : D;
     const int ncg = last ? m.ncg_scalar : m.ncg_full;
     T *du = A.get<T>(E * S), *dxprev = A.get<T>(E * S);
-    RUN(k_latent_update_bwd<T>, Ec, s, Ec, S, dx, u[k], fc, go ? W.get(lk + ".res") : nullptr, du, dfc, dxprev);
+    latent_bwd(dx, u[k], fc, go ? W.get(lk + ".res") : nullptr, du, dfc, dxprev);
     T *dcat = mlp_bwd(lk + ".lat", depth, S + U, Wd, S, z_lat[k], du);
     RUN(k_add_cols<T>, Ec * S, s, Ec, S, dcat, S + U, dxprev, S);
     T *dVp = A.get<T>(E * Dout * U);
-    RUN(k_mix_bwd<T>, Ec * Dout * U, s, Ec, Dout, U, (const T *)(last ? nullptr : dV),
-        (const T *)((last || !go) ? nullptr : W.get(lk + ".mix")), (const T *)(dcat + S), S + U, dVp);
+    mix_bwd(Dout, (const T *)(last ? nullptr : dV), (const T *)((last || !go) ? nullptr : W.get(lk + ".mix")), (const T *)(dcat + S),
+            S + U, dVp);
     T *dVprev = A.get<T>(E * D * U), *denv_e = A.get<T>(E * D * U);
     RUN(k_tp_bwd<T>, Ec * U, s, Ec, D, Dout, U, cg, ncg, go ? W.get(lk + ".tp") : nullptr, V[k - 1], env[k], e_ii, c0, dVp,
         dVprev, denv_e);
@@ -184,15 +239,15 @@ static void generic_chunk(Model &m, const ComputeArgs &a, Arena &A, int c0, int 
     T *dom = A.get<T>(E * nl * U);
     RUN(k_env_bwd_om<T>, Ec * nl * U, s, Ec, D, U, denv, e_ii, c0, Y, dom);
     RUN(k_env_bwd_Y<T>, Ec * D, s, Ec, D, U, denv, e_ii, c0, om[k], dY);
-    RUN(k_linear_bwd<T>, Ec * S, s, Ec, S, nl * U, dom, nl * U, go ? W.get(lk + ".env") : nullptr, dxprev, S, 1);
+    linear_bwd(S, nl * U, dom, nl * U, go ? W.get(lk + ".env") : nullptr, dxprev, S, 1);
     dx = dxprev; dV = dVprev;
   }
   T *dw0 = A.get<T>(E * nl * U);
   RUN(k_embed_bwd_w<T>, Ec * nl * U, s, Ec, D, U, dV, Y, dw0);
-  RUN(k_embed_bwd_Y<T>, Ec * D, s, Ec, D, U, dV, w0, dY);
-  RUN(k_linear_bwd<T>, Ec * S, s, Ec, S, nl * U, dw0, nl * U, go ? W.get("emb.w") : nullptr, dx, S, 1);
+  embed_bwd_Y(dV, w0, dY);
+  linear_bwd(S, nl * U, dw0, nl * U, go ? W.get("emb.w") : nullptr, dx, S, 1);
   T *du0 = A.get<T>(E * S);
-  RUN(k_latent_update_bwd<T>, Ec, s, Ec, S, dx, u0, fc, go ? W.get("res.identity") : nullptr, du0, dfc, (T *)nullptr);
+  latent_bwd(dx, u0, fc, go ? W.get("res.identity") : nullptr, du0, dfc, (T *)nullptr);
   T *da = mlp_bwd("tb", depth, Ka, Wd, S, z_tb, du0);
   T *g = A.get<T>(E * 3);
   RUN(k_geom_bwd<T>, Ec, s, Ec, gp, rvec, e_ii, e_j, m.d_ilist, a.mtype, m.rcut_model_dev, da, dfc, dY, g);

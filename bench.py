@@ -34,14 +34,16 @@ SI_MASS = 28.0855
 
 # Algorithmic work per edge of model S (DESIGN.md "Roofline accounting"): MACs of every dense
 # contraction, forward; the backward pass needs input gradients only, i.e. the same MAC count again.
-def model_macs_per_edge(cfg):
+def model_macs_per_edge(cfg, two_body_tabulated=False):
+    """Dense multiply-accumulates per edge of one forward pass.  With the fused kernel's tabulated two-body embedding
+    (default) the two-body MLP is not executed per edge and is left out of the count."""
     T = len(cfg["type_names"]); B = cfg["num_bessels"]; S = cfg["num_scalar_features"]
     U = cfg["num_tensor_features"]; L = cfg["l_max"]; W = cfg["mlp_width"]; R = cfg["readout_width"]
     NL = cfg["num_layers"]; D = (L + 1) ** 2; dep = cfg["mlp_depth"]
     def mlp(din, depth, width, dout):
         dims = [din] + [width] * depth + [dout]
         return sum(a * b for a, b in zip(dims[:-1], dims[1:]))
-    fwd = mlp(2 * T + B, dep, W, S) + S * U * (L + 1)
+    fwd = (0 if two_body_tabulated else mlp(2 * T + B, dep, W, S)) + S * U * (L + 1)
     for k in range(1, NL + 1):
         fwd += S * U * (L + 1) + mlp(S + U, dep, W, S)
         if k < NL:
@@ -131,8 +133,11 @@ def main():
         value = natoms * args.steps / dt
         used_path = model.last_path
         # ---- roofline of the dominant kernel -------------------------------------------------
-        macs_fwd = model_macs_per_edge(cfg)
-        flops_per_edge = 2.0 * macs_fwd * 2.0          # 2 flop per MAC x (forward + input-gradient backward)
+        tb_tab = used_path == "fused_f32" and os.environ.get("AHIP_FUSED_TB", "table") != "mlp"
+        # ALGORITHMIC flops = the model's dense contractions (SURVEY 8d / DESIGN 4.2), whatever the kernel does with them;
+        # the fused kernel's tabulated two-body embedding executes fewer: reported next to it as executed_flops_per_edge.
+        flops_per_edge = 2.0 * model_macs_per_edge(cfg) * 2.0       # 2 flop per MAC x (forward + input-gradient backward)
+        executed_flops_per_edge = 2.0 * model_macs_per_edge(cfg, two_body_tabulated=tb_tab) * 2.0
         import ctypes as C
         ne = C.c_longlong(0)
         lib.check(lib.lib.ahip_get_edges(model.h, C.byref(ne), None, None))
@@ -149,7 +154,8 @@ def main():
             roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": 157.3, "unit": "TFLOP/s",
                     "frac": round(ach / 157.3, 4), "traffic": traffic, "kernel": dom,
                     "avg_ms": round(stage_avg[dom], 3), "edges_per_launch": edges_rank0,
-                    "flops_per_edge": flops_per_edge}
+                    "flops_per_edge": flops_per_edge, "executed_flops_per_edge": executed_flops_per_edge,
+                    "two_body": "table" if tb_tab else "mlp"}
         # ---- CPU baseline + max|dF| on a bounded sample --------------------------------------
         cpu = None
         max_df = None

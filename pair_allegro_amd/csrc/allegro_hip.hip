@@ -171,6 +171,9 @@ int ahip_set_option(ahip_model *m, const char *key, const char *value) {
     } else if (k == "fused_arith") {
       if (v != "bf16x3" && v != "f32") throw ArgError("option fused_arith: expected bf16x3|f32");
       if (v != m->opt_fused_arith) { m->opt_fused_arith = v; fused_free(*m); }     // weight stream is rebuilt on the next compute
+    } else if (k == "fused_tb") {
+      if (v != "table" && v != "mlp") throw ArgError("option fused_tb: expected table|mlp");
+      if (v != m->opt_fused_tb) { m->opt_fused_tb = v; fused_free(*m); }
     } else if (k == "chunk_edges") {
       long long n = std::atoll(value);
       if (n < 1) throw ArgError("option chunk_edges: expected a positive integer");

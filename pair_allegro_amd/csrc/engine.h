@@ -84,6 +84,7 @@ struct Model {
   // options
   std::string opt_path = "auto";            // auto | fused | generic
   std::string opt_precision = "model";      // model | float64
+  std::string opt_fused_tb = "table";       // table | mlp: two-body embedding of the fused kernel from the spline table or as an MLP
   std::string opt_fused_arith = "f32";      // f32 | bf16x3: arithmetic of the fused kernel's linears (fused.hip)
   long long chunk_edges = 2000000;
   bool timing = false;

@@ -71,6 +71,7 @@ struct FusedArgs {
   const float *wbase;
   int wbytes;
   int o_stream;                  // the per-tile weight-fragment stream (consumption order)
+  int o_tbtab, tb_nk;            // tabulated two-body embedding: [pair][tb_nk intervals][tile 4][coef 4][16] cubic coefficients
   int o_tpl, o_pair, o_out1, o_scale, o_shift;
   int o_res[MAXNL];
   // scratch
@@ -413,7 +414,7 @@ __device__ __forceinline__ void lin(__amdgpu_buffer_rsrc_t W, int &wp, const f32
   }
 }
 
-template <int NW, bool PROF, bool B3>
+template <int NW, bool PROF, bool B3, bool TBT>
 __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
   constexpr int NTHREADS = NW * 64, MAXA = Lds<NW>::MAXA;
   __shared__ Lds<NW> lds;
@@ -504,9 +505,28 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     const float *const denvrow = lds.denv + aloc * ENV_LD;
     PHASE(PH_GEOM);
 
-    // ---------------- two-body MLP ----------------
+    // ---------------- two-body embedding x0(d; type pair) ----------------
     f32x4 x[4];
-    {
+    float tb_t = 0.f, tb_invh = 0.f;
+    const float *tb_ent = nullptr;
+    if constexpr (TBT) {
+      // x0 depends on the edge only through (d, t_i, t_j): the MLP [one-hots, Bessel * cutoff] -> 64 -> 64 -> 64, times the
+      // cutoff, is tabulated per type pair as piecewise cubics in d (Hermite data from the float64 MLP and its exact
+      // derivative, host side: fused_prepare).  Interpolation error (h^4 |4th derivative| / 384 at 512 intervals) is below
+      // float32 rounding; it replaces 3 + 3 linears (18 % of the MFMAs), their SiLU epilogues and 12 saved rows per wave-tile.
+      tb_invh = (float)A.tb_nk / rc;
+      const float sft = d * tb_invh;
+      const int kq = min((int)sft, A.tb_nk - 1);
+      tb_t = sft - (float)kq;
+      tb_ent = Wb + A.o_tbtab + ((size_t)(ti * A.T + tj) * A.tb_nk + kq) * 256 + 4 * g;
+      const float vm = (valid && xx < 1.f) ? 1.f : 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 c0 = *(const f32x4 *)(tb_ent + (t * 4 + 0) * 16), c1 = *(const f32x4 *)(tb_ent + (t * 4 + 1) * 16);
+        const f32x4 c2 = *(const f32x4 *)(tb_ent + (t * 4 + 2) * 16), c3 = *(const f32x4 *)(tb_ent + (t * 4 + 3) * 16);
+        x[t] = (c0 + tb_t * (c1 + tb_t * (c2 + tb_t * c3))) * vm;
+      }
+    } else {
       f32x4 z[4], z2[4];
       {
         const float *pt = Wb + A.o_pair + (size_t)(ti * A.T + tj) * 64;
@@ -777,8 +797,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
           load_rows<4>(SB, R_LAYER(kk - 1) + 12, upre, v16);
           load_rows<4>(SB, R_LAYER(kk - 1) + 8, zt, v16);
         } else {                                                           // two-body u and z2 rows, l=1 embedding weights
-          load_rows<4>(SB, R_U0(), upre, v16);
-          load_rows<4>(SB, R_Z2TB(), zt, v16);
+          if constexpr (!TBT) {
+            load_rows<4>(SB, R_U0(), upre, v16);
+            load_rows<4>(SB, R_Z2TB(), zt, v16);
+          }
           load_rows<2>(SB, R_W0() + 2, w0h, v16);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -788,7 +810,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     }
     // ---------------- embedding backward ----------------
     f32x4 zt1b[4];
-    load_rows<4>(SB, R_Z1TB(), zt1b, v16);
+    if constexpr (!TBT) load_rows<4>(SB, R_Z1TB(), zt1b, v16);
     __builtin_amdgcn_sched_barrier(0);
     {
       f32x4 dw0[4];
@@ -801,11 +823,24 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         for (int r = 0; r < 4; ++r) { dY1 += d1[r] * w0h[t][r]; dY2 += d2[r] * w0h[t][r]; dY3 += d3[r] * w0h[t][r]; }
       }
       lin<B3, 4, 4, true, 0>(WB, wp, dw0, dx, v16, ring, EpiNone{});
+      if constexpr (TBT) wp = A.o_stream;                                 // last linear of the tile
     }
     PHASE(PH_BEMB);
-    // ---------------- two-body MLP backward ----------------
+    // ---------------- two-body embedding backward ----------------
     float dd_part = 0.f;
-    {
+    if constexpr (TBT) {
+      // dE/dd through x0 = sum_f dE/dx0_f * d x0_f / dd: the derivative of the interval's cubic (cutoff included)
+      const float vm = (valid && xx < 1.f) ? tb_invh : 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 c1 = *(const f32x4 *)(tb_ent + (t * 4 + 1) * 16), c2 = *(const f32x4 *)(tb_ent + (t * 4 + 2) * 16);
+        const f32x4 c3 = *(const f32x4 *)(tb_ent + (t * 4 + 3) * 16);
+        const f32x4 der = c1 + tb_t * (2.f * c2 + (3.f * tb_t) * c3);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dd_part += dx[t][r] * der[r];
+      }
+      dd_part *= vm;
+    } else {
       f32x4 du[4], dh[4];
       float acc = 0.f;
 #pragma unroll
@@ -961,6 +996,7 @@ struct FusedState {
   DevBuf wbuf, scratch, seg_count, seg_base, tile_a0, tile_e0, centre, ntiles, partial;
   FusedArgs args;
   bool ready = false, prof_on = false, dbg_on = false, clk_on = false;
+  bool tbt = true;             // two-body embedding from the spline table (default) or evaluated as an MLP (option fused_tb=mlp)
   bool b3 = false;             // f32-input MFMA (default) or bf16x3 arithmetic (option fused_arith=bf16x3 / AHIP_FUSED_ARITH=b3)
   DevBuf prof, dbg;
   int ncu = 256;
@@ -1072,7 +1108,12 @@ static void fused_prepare(Model &m) {
     std::string arith = ar ? ar : m.opt_fused_arith;
     st.b3 = arith == "b3" || arith == "bf16x3";
   }
-  const bool b3 = st.b3;
+  {
+    const char *tb = std::getenv("AHIP_FUSED_TB");
+    std::string mode = tb ? tb : m.opt_fused_tb;
+    st.tbt = mode != "mlp";
+  }
+  const bool b3 = st.b3, tbt = st.tbt;
   auto fwd = [&](const double *W, int K, int N) { if (b3) append_frag_b(w, W, K, N, N); else append_frag(w, W, K, N, N); };
   auto bwd = [&](const double *W, int K, int N) {
     auto t = transpose(W, K, N);
@@ -1080,9 +1121,11 @@ static void fused_prepare(Model &m) {
   };
   auto T_ = [&](const std::string &name) -> const double * { return h.get(name).data.data(); };
   const double *wc = w0.data.data() + (size_t)2 * T * 64;       // Bessel block [8][64]
-  fwd(wc, 8, 64);
-  fwd(T_("tb.w1"), 64, 64);
-  fwd(T_("tb.w2"), 64, 64);
+  if (!tbt) {
+    fwd(wc, 8, 64);
+    fwd(T_("tb.w1"), 64, 64);
+    fwd(T_("tb.w2"), 64, 64);
+  }
   fwd(T_("emb.w"), 64, 64);
   for (int k = 0; k < NL; ++k) {
     const std::string lk = "l" + std::to_string(k + 1);
@@ -1111,12 +1154,71 @@ static void fused_prepare(Model &m) {
     bwd(T_(lk + ".env"), 64, 64);
   }
   bwd(T_("emb.w"), 64, 64);
-  bwd(T_("tb.w2"), 64, 64);
-  bwd(T_("tb.w1"), 64, 64);
-  bwd(wc, 8, 64);
+  if (!tbt) {
+    bwd(T_("tb.w2"), 64, 64);
+    bwd(T_("tb.w1"), 64, 64);
+    bwd(wc, 8, 64);
+  }
   {   // wrap-around copy: the last linear of a tile prefetches the first fragments of the next tile
     const size_t n = (size_t)(b3 ? RINGB : RING) * 256;
     for (size_t i = 0; i < n; ++i) w.push_back(w[stream0 + i]);
+  }
+  // two-body embedding table (see k_fused): per type pair, cubic Hermite in d on [0, r_c(pair)] from the float64 MLP
+  A.tb_nk = 512;
+  A.o_tbtab = mark();
+  if (tbt) {
+    const int NK = A.tb_nk;
+    const double PI = 3.14159265358979323846;
+    const double *W1 = T_("tb.w1"), *W2 = T_("tb.w2");
+    auto silu = [](double z) { return z / (1.0 + std::exp(-z)); };
+    auto dsilu = [](double z) { const double sg = 1.0 / (1.0 + std::exp(-z)); return sg * (1.0 + z * (1.0 - sg)); };
+    std::vector<double> y((size_t)(NK + 1) * 64), dy((size_t)(NK + 1) * 64);
+    for (int ti = 0; ti < T; ++ti)
+      for (int tj = 0; tj < T; ++tj) {
+        const double rc = m.rcut_model_host[(size_t)ti * T + tj];
+        const double hstep = rc / NK;
+        for (int k = 0; k <= NK; ++k) {
+          const double d = k * hstep, xq = d / rc;
+          double fcv = 0, dfc = 0;                       // cutoff envelope and d/dx
+          if (xq < 1.0) {
+            const int p = h.poly_p;
+            const double xp1 = std::pow(xq, p - 1), xp = xp1 * xq;
+            const double ca = 0.5 * (p + 1) * (p + 2), cb = (double)p * (p + 2), cc = 0.5 * p * (p + 1);
+            fcv = 1.0 - ca * xp + cb * xp * xq - cc * xp * xq * xq;
+            dfc = -ca * p * xp1 + cb * (p + 1) * xp - cc * (p + 2) * xp * xq;
+          }
+          double z1[64], dz1[64], h1[64], dh1[64], z2[64], dz2[64], h2[64], dh2[64];
+          for (int n = 0; n < 64; ++n) { z1[n] = w0.data[(size_t)ti * 64 + n] + w0.data[(size_t)(T + tj) * 64 + n]; dz1[n] = 0; }
+          for (int b = 1; b <= 8; ++b) {
+            const double a = b * PI / rc;
+            double sv, ds;                                // s = sin(a d)/d and ds/dd, series near 0
+            if (a * d < 1e-4) { sv = a * (1.0 - a * a * d * d / 6.0); ds = -a * a * a * d / 3.0; }
+            else { sv = std::sin(a * d) / d; ds = (a * d * std::cos(a * d) - std::sin(a * d)) / (d * d); }
+            const double bf = 2.0 / rc * sv * fcv, dbf = 2.0 / rc * (ds * fcv + sv * dfc / rc);
+            for (int n = 0; n < 64; ++n) { z1[n] += wc[(size_t)(b - 1) * 64 + n] * bf; dz1[n] += wc[(size_t)(b - 1) * 64 + n] * dbf; }
+          }
+          for (int n = 0; n < 64; ++n) { h1[n] = silu(z1[n]); dh1[n] = dsilu(z1[n]) * dz1[n]; z2[n] = 0; dz2[n] = 0; }
+          for (int q = 0; q < 64; ++q)
+            for (int n = 0; n < 64; ++n) { z2[n] += h1[q] * W1[(size_t)q * 64 + n]; dz2[n] += dh1[q] * W1[(size_t)q * 64 + n]; }
+          for (int n = 0; n < 64; ++n) { h2[n] = silu(z2[n]); dh2[n] = dsilu(z2[n]) * dz2[n]; }
+          for (int n = 0; n < 64; ++n) {
+            double u = 0, du = 0;
+            for (int q = 0; q < 64; ++q) { u += h2[q] * W2[(size_t)q * 64 + n]; du += dh2[q] * W2[(size_t)q * 64 + n]; }
+            y[(size_t)k * 64 + n] = fcv * u;
+            dy[(size_t)k * 64 + n] = dfc / rc * u + fcv * du;
+          }
+        }
+        for (int k = 0; k < NK; ++k)
+          for (int t = 0; t < 4; ++t)
+            for (int c = 0; c < 4; ++c)
+              for (int q = 0; q < 16; ++q) {
+                const int f = 16 * t + q;               // lane (j, g) reads the 4 floats at 4 g: features 16 t + 4 g + r
+                const double y0 = y[(size_t)k * 64 + f], y1 = y[(size_t)(k + 1) * 64 + f];
+                const double m0 = hstep * dy[(size_t)k * 64 + f], m1 = hstep * dy[(size_t)(k + 1) * 64 + f];
+                const double cf = c == 0 ? y0 : c == 1 ? m0 : c == 2 ? 3.0 * (y1 - y0) - 2.0 * m0 - m1 : 2.0 * (y0 - y1) + m0 + m1;
+                w.push_back((float)cf);
+              }
+      }
   }
   // small tables
   A.o_tpl = mark();
@@ -1213,21 +1315,17 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
       AHIP_CHECK(hipMemsetAsync(st.prof.p, 0, (64 + 4 * (size_t)grid) * sizeof(long long), s));
       A.prof = st.prof.as<long long>();
     }
+#define AHIP_LAUNCH(NWV, PROFV, B3V, TBV) hipLaunchKernelGGL((k_fused<NWV, PROFV, B3V, TBV>), dim3(grid), dim3(NWV * 64), 0, s, A)
+#define AHIP_LAUNCH_TB(NWV, PROFV, B3V) do { if (st.tbt) AHIP_LAUNCH(NWV, PROFV, B3V, true); else AHIP_LAUNCH(NWV, PROFV, B3V, false); } while (0)
+#define AHIP_LAUNCH_NW(PROFV, B3V) do { if (nw == 4) AHIP_LAUNCH_TB(4, PROFV, B3V); else AHIP_LAUNCH_TB(8, PROFV, B3V); } while (0)
     if (st.prof_on) {
-      if (st.b3) {
-        if (nw == 4) hipLaunchKernelGGL((k_fused<4, true, true>), dim3(grid), dim3(256), 0, s, A);
-        else hipLaunchKernelGGL((k_fused<8, true, true>), dim3(grid), dim3(512), 0, s, A);
-      } else {
-        if (nw == 4) hipLaunchKernelGGL((k_fused<4, true, false>), dim3(grid), dim3(256), 0, s, A);
-        else hipLaunchKernelGGL((k_fused<8, true, false>), dim3(grid), dim3(512), 0, s, A);
-      }
-    } else if (st.b3) {
-      if (nw == 4) hipLaunchKernelGGL((k_fused<4, false, true>), dim3(grid), dim3(256), 0, s, A);
-      else hipLaunchKernelGGL((k_fused<8, false, true>), dim3(grid), dim3(512), 0, s, A);
+      if (st.b3) AHIP_LAUNCH_NW(true, true); else AHIP_LAUNCH_NW(true, false);
     } else {
-      if (nw == 4) hipLaunchKernelGGL((k_fused<4, false, false>), dim3(grid), dim3(256), 0, s, A);
-      else hipLaunchKernelGGL((k_fused<8, false, false>), dim3(grid), dim3(512), 0, s, A);
+      if (st.b3) AHIP_LAUNCH_NW(false, true); else AHIP_LAUNCH_NW(false, false);
     }
+#undef AHIP_LAUNCH_NW
+#undef AHIP_LAUNCH_TB
+#undef AHIP_LAUNCH
   }
   AHIP_CHECK(hipGetLastError());
   AHIP_CHECK(prim_sum_columns_f64(st.partial.as<double>(), grid, 7, a.engvir, s));

@@ -72,6 +72,22 @@ def test_fused_bf16x3_arithmetic_matches_f32(hip_lib, model_dir):
     np.testing.assert_allclose(b3["pe"], f32["pe"], rtol=2e-6)
 
 
+def test_fused_two_body_table_matches_mlp(hip_lib, model_dir):
+    """Default: the two-body embedding x0(d; type pair) comes from a per-pair cubic spline table built from the float64 MLP
+    (512 intervals); option fused_tb=mlp evaluates the three linears in the kernel.  Both must sit at the same distance
+    from the float64 oracle (3 types, 9 pair tables, ragged tiles; and the 2-type 256-atom box)."""
+    for tag, tn in (("Cu2AgO4_r5", ["Cu", "Ag", "O"]), ("CuPd-cubic-big_r5", ["Cu", "Pd"])):
+        g = util.load_golden(tag)
+        path, cfg, types, names, ref = _model_S_case(model_dir, f"tb_{tag}", tn, g["symbols"], g["cell"], g["pos"])
+        tab = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused", "fused_tb": "table"})
+        mlp = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused", "fused_tb": "mlp"})
+        util.assert_close_to(tab, ref, 5e-4, what=f"{tag} two-body table vs f64 oracle")
+        et, em = np.abs(tab["forces"] - ref["forces"]).max(), np.abs(mlp["forces"] - ref["forces"]).max()
+        assert et < max(2.0 * em, 1e-5), (et, em)
+        np.testing.assert_allclose(tab["forces"], mlp["forces"], atol=1e-5)
+        np.testing.assert_allclose(tab["eatom"], mlp["eatom"], atol=2e-5)
+
+
 def test_fused_wide_tiles_65_to_128_neighbours(hip_lib, model_dir):
     """fcc Cu with r_max 6.1 A has 78 neighbours per atom: more than the 64-slot tile of the default 4-wave workgroup,
     so the 8-wave / 128-slot kernel instance runs; it must agree with the oracle like the narrow one."""

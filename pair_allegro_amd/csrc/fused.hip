@@ -525,6 +525,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         const f32x4 c0 = *(const f32x4 *)(tb_ent + (t * 4 + 0) * 16), c1 = *(const f32x4 *)(tb_ent + (t * 4 + 1) * 16);
         const f32x4 c2 = *(const f32x4 *)(tb_ent + (t * 4 + 2) * 16), c3 = *(const f32x4 *)(tb_ent + (t * 4 + 3) * 16);
         x[t] = (c0 + tb_t * (c1 + tb_t * (c2 + tb_t * c3))) * vm;
+        // d x0 / dd for the backward pass: one coalesced row now instead of three per-edge gathers then
+        bstore(SB, v16, (R_Z1TB() + t) * ROW * 4, (c1 + tb_t * (2.f * c2 + (3.f * tb_t) * c3)) * (vm * tb_invh));
       }
     } else {
       f32x4 z[4], z2[4];
@@ -800,7 +802,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
           if constexpr (!TBT) {
             load_rows<4>(SB, R_U0(), upre, v16);
             load_rows<4>(SB, R_Z2TB(), zt, v16);
-          }
+          } else load_rows<4>(SB, R_Z1TB(), zt, v16);                      // d x0 / dd rows of the two-body table
           load_rows<2>(SB, R_W0() + 2, w0h, v16);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -829,17 +831,11 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     // ---------------- two-body embedding backward ----------------
     float dd_part = 0.f;
     if constexpr (TBT) {
-      // dE/dd through x0 = sum_f dE/dx0_f * d x0_f / dd: the derivative of the interval's cubic (cutoff included)
-      const float vm = (valid && xx < 1.f) ? tb_invh : 0.f;
+      // dE/dd through x0 = sum_f dE/dx0_f * d x0_f / dd (the derivative rows saved by the forward pass, cutoff included)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const f32x4 c1 = *(const f32x4 *)(tb_ent + (t * 4 + 1) * 16), c2 = *(const f32x4 *)(tb_ent + (t * 4 + 2) * 16);
-        const f32x4 c3 = *(const f32x4 *)(tb_ent + (t * 4 + 3) * 16);
-        const f32x4 der = c1 + tb_t * (2.f * c2 + (3.f * tb_t) * c3);
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dd_part += dx[t][r] * der[r];
-      }
-      dd_part *= vm;
+        for (int r = 0; r < 4; ++r) dd_part += dx[t][r] * zt[t][r];
     } else {
       f32x4 du[4], dh[4];
       float acc = 0.f;

@@ -46,8 +46,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   NW = 8: 128-slot tiles, <= 12 centres, ~159 KB LDS, one workgroup per CU: for lists with 65..128 edges per centre.
 static constexpr int MAX_TILE_SLOTS = 128;
 static constexpr int MAXNL = 3;
-static constexpr int STG_LD = 129;       // staging leading dimension: all 128 features of a slot
-static constexpr int ENV_LD = 129;       // per-atom environment row
+static constexpr int STG_LD = 132;       // staging leading dimension: all 128 features of a slot; 16-byte aligned rows
+static constexpr int ENV_LD = 132;       // per-atom environment row (the tensor product reads it as float4)
 static constexpr int SEG = 512;          // atoms per sequential packing segment
 static constexpr int ROW = 256;          // floats per saved register image of one 16-feature tile (4 regs x 64 lanes)
 static constexpr int RING = 8;           // weight fragments in flight per wave
@@ -429,7 +429,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     WB = __builtin_amdgcn_make_buffer_rsrc((void *)A.wbase, 0, A.wbytes, 0x00020000);
   }
   const float *__restrict__ Wb = A.wbase;
-  for (int k = tid; k < A.NL * 160; k += NTHREADS) lds.tp[k / 160][k % 160] = Wb[A.o_tpl + k];
+  for (int k = tid; k < A.NL * 160; k += NTHREADS) {      // path weights with their CG constants folded in
+    const int pth = (k % 160) / 32;
+    lds.tp[k / 160][k % 160] = Wb[A.o_tpl + k] * (pth == 1 ? C_P1 : pth == 4 ? C_P4 : 1.f);
+  }
   const int ntiles = *A.ntiles;
   const int NL = A.NL;
   double acc_part = 0.0;       // thread 0: energy; threads 64..69: virial components
@@ -569,15 +572,13 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         lin<B3, 4, 4, false, 0>(WB, wp, x, om, v16, ring, EpiSave{SB, RL + 0, v16});
         // environment sum over the centre's edges
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int fidx = feat16(t, r, g);
-            st[fidx] = om[t][r];
-            st[32 + fidx] = om[2 + t][r] * Y1;
-            st[64 + fidx] = om[2 + t][r] * Y2;
-            st[96 + fidx] = om[2 + t][r] * Y3;
-          }
+        for (int t = 0; t < 2; ++t) {
+          float *sp = st + 16 * t + 4 * g;                   // features 16 t + 4 g + (0..3): one 16-byte store per component
+          *(f32x4 *)(sp) = om[t];
+          *(f32x4 *)(sp + 32) = om[2 + t] * Y1;
+          *(f32x4 *)(sp + 64) = om[2 + t] * Y2;
+          *(f32x4 *)(sp + 96) = om[2 + t] * Y3;
+        }
         __syncthreads();
         reduce_stage(lds, aoffp, envk, na, A.cenv, tid);
         __syncthreads();
@@ -604,18 +605,18 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         const float *tp = lds.tp[kk];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int fidx = feat16(t, r, g);
-            const float e0v = en[fidx], e1v = en[32 + fidx], e2v = en[64 + fidx], e3v = en[96 + fidx];
-            const float v0 = V[0][t][r], v1 = V[1][t][r], v2 = V[2][t][r], v3 = V[3][t][r];
-            Vp[0][t][r] = tp[fidx] * v0 * e0v + tp[32 + fidx] * C_P1 * (v1 * e1v + v2 * e2v + v3 * e3v);
-            if (!last) {
-              const float p2 = tp[64 + fidx], p3 = tp[96 + fidx], c4 = tp[128 + fidx] * C_P4;
-              Vp[1][t][r] = p2 * v0 * e1v + p3 * v1 * e0v + c4 * (v2 * e3v - v3 * e2v);
-              Vp[2][t][r] = p2 * v0 * e2v + p3 * v2 * e0v + c4 * (v3 * e1v - v1 * e3v);
-              Vp[3][t][r] = p2 * v0 * e3v + p3 * v3 * e0v + c4 * (v1 * e2v - v2 * e1v);
-            }
+          // float4 arithmetic over the lane's 4 features of this tile: register pairs go to v_pk_* as they are
+          const int b = 16 * t + 4 * g;
+          const f32x4 e0v = *(const f32x4 *)(en + b), e1v = *(const f32x4 *)(en + 32 + b), e2v = *(const f32x4 *)(en + 64 + b),
+                      e3v = *(const f32x4 *)(en + 96 + b);
+          const f32x4 v0 = V[0][t], v1 = V[1][t], v2 = V[2][t], v3 = V[3][t];
+          Vp[0][t] = *(const f32x4 *)(tp + b) * v0 * e0v + *(const f32x4 *)(tp + 32 + b) * (v1 * e1v + v2 * e2v + v3 * e3v);
+          if (!last) {
+            const f32x4 p2 = *(const f32x4 *)(tp + 64 + b), p3 = *(const f32x4 *)(tp + 96 + b), c4 = *(const f32x4 *)(tp + 128 + b);
+            const f32x4 p2v0 = p2 * v0, p3e0 = p3 * e0v;
+            Vp[1][t] = p2v0 * e1v + p3e0 * v1 + c4 * (v2 * e3v - v3 * e2v);
+            Vp[2][t] = p2v0 * e2v + p3e0 * v2 + c4 * (v3 * e1v - v1 * e3v);
+            Vp[3][t] = p2v0 * e3v + p3e0 * v3 + c4 * (v1 * e2v - v2 * e1v);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -685,16 +686,13 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         f32x4 du[4], dh[4];
         {
           const float ra = lds.res[kk][0], rb = lds.res[kk][1];
-          float acc = 0.f;
+          f32x4 accv = upre[0] * dx[0];
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
+          for (int t = 1; t < 4; ++t) accv += upre[t] * dx[t];
+          const float rbfc = rb * fc;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              acc += upre[t][r] * dx[t][r];
-              du[t][r] = rb * fc * dx[t][r];
-              dx[t][r] = ra * dx[t][r];
-            }
-          dfc_part += rb * acc;
+          for (int t = 0; t < 4; ++t) { du[t] = rbfc * dx[t]; dx[t] = ra * dx[t]; }
+          dfc_part += rb * ((accv[0] + accv[1]) + (accv[2] + accv[3]));
         }
         f32x4 zt1[4];
         load_rows<4>(SB, RL + 4, zt1, v16);                  // z1: first used 96 MFMAs from here
@@ -744,35 +742,33 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         const float *tp = lds.tp[kk];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          f32x4 o0, o1, o2, o3;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int fidx = feat16(t, r, g);
-            const float e0v = en[fidx], e1v = en[32 + fidx], e2v = en[64 + fidx], e3v = en[96 + fidx];
-            const float v0 = Vk[0][t][r], v1 = Vk[1][t][r], v2 = Vk[2][t][r], v3 = Vk[3][t][r];
-            const float g0 = dVp[0][t][r];
-            const float q0 = tp[fidx] * g0, q1 = tp[32 + fidx] * C_P1 * g0;
-            float a0v = q0 * e0v, a1v = q1 * e1v, a2v = q1 * e2v, a3v = q1 * e3v;       // dV
-            float b0v = q0 * v0, b1v = q1 * v1, b2v = q1 * v2, b3v = q1 * v3;           // denv_e
-            if (!last) {
-              const float g1 = dVp[1][t][r], g2 = dVp[2][t][r], g3 = dVp[3][t][r];
-              const float q2 = tp[64 + fidx], q3 = tp[96 + fidx], c4 = tp[128 + fidx] * C_P4;
-              a0v += q2 * (e1v * g1 + e2v * g2 + e3v * g3);
-              b0v += q3 * (v1 * g1 + v2 * g2 + v3 * g3);
-              a1v += q3 * e0v * g1 + c4 * (e2v * g3 - e3v * g2);      // (e x g)_1
-              a2v += q3 * e0v * g2 + c4 * (e3v * g1 - e1v * g3);
-              a3v += q3 * e0v * g3 + c4 * (e1v * g2 - e2v * g1);
-              b1v += q2 * v0 * g1 + c4 * (g2 * v3 - g3 * v2);         // (g x v)_1
-              b2v += q2 * v0 * g2 + c4 * (g3 * v1 - g1 * v3);
-              b3v += q2 * v0 * g3 + c4 * (g1 * v2 - g2 * v1);
-            }
-            o0[r] = a0v; o1[r] = a1v; o2[r] = a2v; o3[r] = a3v;
-            st[fidx] = b0v; st[32 + fidx] = b1v; st[64 + fidx] = b2v; st[96 + fidx] = b3v;
+          const int b = 16 * t + 4 * g;
+          const f32x4 e0v = *(const f32x4 *)(en + b), e1v = *(const f32x4 *)(en + 32 + b), e2v = *(const f32x4 *)(en + 64 + b),
+                      e3v = *(const f32x4 *)(en + 96 + b);
+          const f32x4 v0 = Vk[0][t], v1 = Vk[1][t], v2 = Vk[2][t], v3 = Vk[3][t];
+          const f32x4 g0 = dVp[0][t];
+          const f32x4 q0 = *(const f32x4 *)(tp + b) * g0, q1 = *(const f32x4 *)(tp + 32 + b) * g0;
+          f32x4 a0v = q0 * e0v, a1v = q1 * e1v, a2v = q1 * e2v, a3v = q1 * e3v;       // dV
+          f32x4 b0v = q0 * v0, b1v = q1 * v1, b2v = q1 * v2, b3v = q1 * v3;           // denv_e
+          if (!last) {
+            const f32x4 g1 = dVp[1][t], g2 = dVp[2][t], g3 = dVp[3][t];
+            const f32x4 q2 = *(const f32x4 *)(tp + 64 + b), q3 = *(const f32x4 *)(tp + 96 + b), c4 = *(const f32x4 *)(tp + 128 + b);
+            const f32x4 q3e0 = q3 * e0v, q2v0 = q2 * v0;
+            a0v += q2 * (e1v * g1 + e2v * g2 + e3v * g3);
+            b0v += q3 * (v1 * g1 + v2 * g2 + v3 * g3);
+            a1v += q3e0 * g1 + c4 * (e2v * g3 - e3v * g2);      // (e x g)_1
+            a2v += q3e0 * g2 + c4 * (e3v * g1 - e1v * g3);
+            a3v += q3e0 * g3 + c4 * (e1v * g2 - e2v * g1);
+            b1v += q2v0 * g1 + c4 * (g2 * v3 - g3 * v2);         // (g x v)_1
+            b2v += q2v0 * g2 + c4 * (g3 * v1 - g1 * v3);
+            b3v += q2v0 * g3 + c4 * (g1 * v2 - g2 * v1);
           }
-          park_store(pk, 0 + t, o0, lane);
-          park_store(pk, 2 + t, o1, lane);
-          park_store(pk, 4 + t, o2, lane);
-          park_store(pk, 6 + t, o3, lane);
+          float *sp = st + b;
+          *(f32x4 *)(sp) = b0v; *(f32x4 *)(sp + 32) = b1v; *(f32x4 *)(sp + 64) = b2v; *(f32x4 *)(sp + 96) = b3v;
+          park_store(pk, 0 + t, a0v, lane);
+          park_store(pk, 2 + t, a1v, lane);
+          park_store(pk, 4 + t, a2v, lane);
+          park_store(pk, 6 + t, a3v, lane);
           __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
@@ -785,14 +781,13 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         f32x4 dom[4];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int fidx = feat16(t, r, g);
-            const float d0 = denvrow[fidx], d1 = denvrow[32 + fidx], d2 = denvrow[64 + fidx], d3 = denvrow[96 + fidx];
-            dom[t][r] = d0;
-            dom[2 + t][r] = d1 * Y1 + d2 * Y2 + d3 * Y3;
-            dY1 += d1 * om[2 + t][r]; dY2 += d2 * om[2 + t][r]; dY3 += d3 * om[2 + t][r];
-          }
+          const int b = 16 * t + 4 * g;
+          const f32x4 d0 = *(const f32x4 *)(denvrow + b), d1 = *(const f32x4 *)(denvrow + 32 + b), d2 = *(const f32x4 *)(denvrow + 64 + b),
+                      d3 = *(const f32x4 *)(denvrow + 96 + b);
+          dom[t] = d0;
+          dom[2 + t] = d1 * Y1 + d2 * Y2 + d3 * Y3;
+          const f32x4 p1 = d1 * om[2 + t], p2 = d2 * om[2 + t], p3 = d3 * om[2 + t];
+          dY1 += (p1[0] + p1[1]) + (p1[2] + p1[3]); dY2 += (p2[0] + p2[1]) + (p2[2] + p2[3]); dY3 += (p3[0] + p3[1]) + (p3[2] + p3[3]);
           __builtin_amdgcn_sched_barrier(0);
         }
         if (kk > 0) {                                                      // next iteration's u and z2 rows
@@ -832,10 +827,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     float dd_part = 0.f;
     if constexpr (TBT) {
       // dE/dd through x0 = sum_f dE/dx0_f * d x0_f / dd (the derivative rows saved by the forward pass, cutoff included)
+      f32x4 accv = dx[0] * zt[0];
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dd_part += dx[t][r] * zt[t][r];
+      for (int t = 1; t < 4; ++t) accv += dx[t] * zt[t];
+      dd_part = (accv[0] + accv[1]) + (accv[2] + accv[3]);
     } else {
       f32x4 du[4], dh[4];
       float acc = 0.f;

@@ -1,11 +1,11 @@
 // Fused MFMA path: the whole Allegro model (forward + hand-derived backward) for a tile of centre
 // atoms in ONE kernel launch, float32 compute on the gfx950 matrix cores.
 //
-// Mapping (DESIGN.md "Fused kernel"):
-//  * tile  = consecutive centre atoms whose edges (<= 128) fit the 128 edge slots of a 512-thread
-//            workgroup (8 waves = 2 per SIMD, <= 256 registers each, so one wave's MFMA chain runs under the
-//            other's element-wise / LDS / memory phases); wave w owns slots 16w..16w+15;
-//            lane = (slot j = lane & 15, group g = lane >> 4).
+// Mapping:
+//  * tile  = consecutive centre atoms whose edges fit the edge slots of one workgroup: 4 waves / 64 slots (two
+//            independent workgroups per CU, the default) or 8 waves / 128 slots; either way 2 waves per SIMD at
+//            <= 256 registers.  Wave w owns slots 16w..16w+15; lane = (slot j = lane & 15, group g = lane >> 4).
+//            Persistent workgroups claim chunks of consecutive tiles from a global counter (dynamic schedule).
 //  * every per-edge feature vector lives in registers in the v_mfma_f32_16x16x4_f32 C/D layout:
 //            tile t, register r of lane (j, g)  <->  feature 16 t + 4 g + r   (4 lanes share one edge).
 //            With D = W^T-tile (rows = output features) x activations (cols = edges), register r of an
@@ -14,11 +14,14 @@
 //  * weights are pre-swizzled on the host into A-operand fragments (one coalesced 1 KiB dwordx4 load
 //            feeds 4 MFMAs) and laid out as ONE stream in the exact order a tile consumes them (forward
 //            weights, then the transposed copies in backward order), so the prefetch ring is a running pointer.
+//  * the two-body embedding x0(d; type pair) is read from a per-pair cubic spline table built from the float64
+//            MLP and its exact derivative (fused_prepare); option fused_tb=mlp evaluates it in the kernel.
 //  * the only cross-edge coupling -- the per-centre environment sum and its gradient -- goes through
-//            an LDS staging tile [128 slots][128 features] and a deterministic per-atom reduction.
-//  * activations needed by the backward pass are spilled as raw register images to a per-wave
-//            private scratch (written and re-read by the same wave within the same tile, so it lives
-//            in L2 / Infinity Cache, not HBM).
+//            an LDS staging tile [slots][128 features] and a deterministic per-atom reduction.
+//  * activations needed by the backward pass are stored as raw register images in a per-wave
+//            private scratch (written and re-read by the same wave within the same tile: Infinity-Cache traffic).
+//  * arithmetic of the linears: f32-input MFMA (default) or bf16x3 (exact 3-way bf16 split, six bf16-MFMA
+//            terms, f32 accumulate; option fused_arith).
 //
 // Supported model shape (others run the generic path): l_max = 1, 32 tensor features, 64 scalars,
 // MLP 2 x 64, read-out 1 x 32, 8 Bessels, <= 3 layers, <= 4 types.  Reference graph:

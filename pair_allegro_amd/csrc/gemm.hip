@@ -10,6 +10,7 @@
 
 #include <algorithm>
 
+#include "cg_tables.h"
 #include "engine.h"
 
 namespace ahip {
@@ -118,6 +119,91 @@ __global__ void __launch_bounds__(256) k_embed_bwd_Y_rows(long long E, int D, in
     }
   }
 }
+// ---- tensor product with the Clebsch-Gordan table unrolled at compile time (cg_tables.h is constexpr): every index is a
+// constant, so V, env and the outputs stay in registers.  The portable kernels (k_tp_fwd / k_tp_bwd) index private arrays
+// with table entries read at run time (scratch memory) and re-load V / env per entry: 45 % of the l_max = 2 path's time.
+template <int L> struct CgTab;
+template <> struct CgTab<1> { static constexpr const AhipCgEntry *tab = ahip_cg_l1; static constexpr int N = AHIP_CG_L1_N, NS = AHIP_CG_L1_NSCALAR, NP = AHIP_CG_L1_NPATHS; };
+template <> struct CgTab<2> { static constexpr const AhipCgEntry *tab = ahip_cg_l2; static constexpr int N = AHIP_CG_L2_N, NS = AHIP_CG_L2_NSCALAR, NP = AHIP_CG_L2_NPATHS; };
+
+template <int L, bool SCALAR>
+__global__ void __launch_bounds__(256) k_tp_fwd_unrolled(long long E, int U, const float *__restrict__ pw, const float *__restrict__ V,
+                                                          const float *__restrict__ env, const int *__restrict__ e_ii, int c0,
+                                                          float *__restrict__ Vp) {
+  constexpr int D = (L + 1) * (L + 1), DOUT = SCALAR ? 1 : D, N = SCALAR ? CgTab<L>::NS : CgTab<L>::N, NP = CgTab<L>::NP;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= E * U) return;
+  const long long e = t / U;
+  const int u = (int)(t - e * U);
+  const float *v = V + e * D * U + u;
+  const float *en = env + (long long)(e_ii[e] - c0) * D * U + u;
+  float vv[D], ee[D], pp[NP], out[DOUT];
+#pragma unroll
+  for (int k = 0; k < D; ++k) { vv[k] = v[k * U]; ee[k] = en[k * U]; }
+#pragma unroll
+  for (int k = 0; k < NP; ++k) pp[k] = pw[k * U + u];
+#pragma unroll
+  for (int k = 0; k < DOUT; ++k) out[k] = 0.f;
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    constexpr const AhipCgEntry *tab = CgTab<L>::tab;
+    out[tab[q].i3] += pp[tab[q].path] * (float)tab[q].c * vv[tab[q].i1] * ee[tab[q].i2];
+  }
+#pragma unroll
+  for (int k = 0; k < DOUT; ++k) Vp[(e * DOUT + k) * U + u] = out[k];
+}
+template <int L, bool SCALAR>
+__global__ void __launch_bounds__(256) k_tp_bwd_unrolled(long long E, int U, const float *__restrict__ pw, const float *__restrict__ V,
+                                                          const float *__restrict__ env, const int *__restrict__ e_ii, int c0,
+                                                          const float *__restrict__ dVp, float *__restrict__ dV, float *__restrict__ denv_e) {
+  constexpr int D = (L + 1) * (L + 1), DOUT = SCALAR ? 1 : D, N = SCALAR ? CgTab<L>::NS : CgTab<L>::N, NP = CgTab<L>::NP;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= E * U) return;
+  const long long e = t / U;
+  const int u = (int)(t - e * U);
+  const float *v = V + e * D * U + u;
+  const float *en = env + (long long)(e_ii[e] - c0) * D * U + u;
+  float vv[D], ee[D], pp[NP], gg[DOUT], a[D], b[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) { vv[k] = v[k * U]; ee[k] = en[k * U]; a[k] = 0.f; b[k] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < NP; ++k) pp[k] = pw[k * U + u];
+#pragma unroll
+  for (int k = 0; k < DOUT; ++k) gg[k] = dVp[(e * DOUT + k) * U + u];
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    constexpr const AhipCgEntry *tab = CgTab<L>::tab;
+    const float wv = pp[tab[q].path] * (float)tab[q].c * gg[tab[q].i3];
+    a[tab[q].i1] += wv * ee[tab[q].i2];
+    b[tab[q].i2] += wv * vv[tab[q].i1];
+  }
+#pragma unroll
+  for (int k = 0; k < D; ++k) { dV[(e * D + k) * U + u] = a[k]; denv_e[(e * D + k) * U + u] = b[k]; }
+}
+
+bool tp_fwd_f32(hipStream_t s, long long E, int L, bool scalar_only, int U, const float *pw, const float *V, const float *env,
+                const int *e_ii, int c0, float *Vp) {
+  if (L != 1 && L != 2) return false;
+  if (E <= 0) return true;
+  const dim3 grid((unsigned)((E * U + 255) / 256));
+#define TPF(LV, SV) hipLaunchKernelGGL((k_tp_fwd_unrolled<LV, SV>), grid, dim3(256), 0, s, E, U, pw, V, env, e_ii, c0, Vp)
+  if (L == 1) { if (scalar_only) TPF(1, true); else TPF(1, false); }
+  else { if (scalar_only) TPF(2, true); else TPF(2, false); }
+#undef TPF
+  return true;
+}
+bool tp_bwd_f32(hipStream_t s, long long E, int L, bool scalar_only, int U, const float *pw, const float *V, const float *env,
+                const int *e_ii, int c0, const float *dVp, float *dV, float *denv_e) {
+  if (L != 1 && L != 2) return false;
+  if (E <= 0) return true;
+  const dim3 grid((unsigned)((E * U + 255) / 256));
+#define TPB(LV, SV) hipLaunchKernelGGL((k_tp_bwd_unrolled<LV, SV>), grid, dim3(256), 0, s, E, U, pw, V, env, e_ii, c0, dVp, dV, denv_e)
+  if (L == 1) { if (scalar_only) TPB(1, true); else TPB(1, false); }
+  else { if (scalar_only) TPB(2, true); else TPB(2, false); }
+#undef TPB
+  return true;
+}
+
 static unsigned row_grid(long long E) { return (unsigned)std::min<long long>((E + 3) / 4, 256LL * 64); }
 
 bool latent_update_bwd_f32(hipStream_t s, long long E, int S, const float *dx, const float *u, const float *fc, const float *res,

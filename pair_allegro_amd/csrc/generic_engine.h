@@ -196,7 +196,12 @@ static void generic_chunk(Model &m, const ComputeArgs &a, Arena &A, int c0, int 
     env[k] = A.get<T>((size_t)nc * D * U);
     RUN(k_env_reduce<T>, (long long)nc * D * U, s, nc, c0, eoff, e0, D, U, om[k], Y, cenv, env[k]);
     T *Vp = A.get<T>(E * Dout * U);
-    RUN(k_tp_fwd<T>, Ec * U, s, Ec, D, Dout, U, cg, ncg, go ? W.get(lk + ".tp") : nullptr, V[k - 1], env[k], e_ii, c0, Vp);
+    {
+      bool done = !go;
+      if constexpr (std::is_same<T, float>::value)
+        if (go) done = tp_fwd_f32(s, Ec, m.hm.l_max, last, U, W.get(lk + ".tp"), V[k - 1], env[k], e_ii, c0, Vp);
+      if (!done) launch(k_tp_fwd<T>, Ec * U, s, Ec, D, Dout, U, cg, ncg, W.get(lk + ".tp"), V[k - 1], env[k], e_ii, c0, Vp);
+    }
     T *cat = A.get<T>(E * (S + U));
     RUN(k_concat<T>, Ec * (S + U), s, Ec, S, U, x[k - 1], Vp, Dout * U, cat);
     mlp_fwd(lk + ".lat", depth, cat, S + U, Wd, S, z_lat[k], u[k]);
@@ -232,8 +237,12 @@ static void generic_chunk(Model &m, const ComputeArgs &a, Arena &A, int c0, int 
     mix_bwd(Dout, (const T *)(last ? nullptr : dV), (const T *)((last || !go) ? nullptr : W.get(lk + ".mix")), (const T *)(dcat + S),
             S + U, dVp);
     T *dVprev = A.get<T>(E * D * U), *denv_e = A.get<T>(E * D * U);
-    RUN(k_tp_bwd<T>, Ec * U, s, Ec, D, Dout, U, cg, ncg, go ? W.get(lk + ".tp") : nullptr, V[k - 1], env[k], e_ii, c0, dVp,
-        dVprev, denv_e);
+    {
+      bool done = !go;
+      if constexpr (std::is_same<T, float>::value)
+        if (go) done = tp_bwd_f32(s, Ec, m.hm.l_max, last, U, W.get(lk + ".tp"), V[k - 1], env[k], e_ii, c0, dVp, dVprev, denv_e);
+      if (!done) launch(k_tp_bwd<T>, Ec * U, s, Ec, D, Dout, U, cg, ncg, W.get(lk + ".tp"), V[k - 1], env[k], e_ii, c0, dVp, dVprev, denv_e);
+    }
     T *denv = A.get<T>((size_t)nc * D * U);
     RUN(k_segment_sum<T>, (long long)nc * D * U, s, nc, c0, eoff, e0, D * U, denv_e, cenv, denv);
     T *dom = A.get<T>(E * nl * U);

@@ -191,6 +191,7 @@ bool gemm_f32(hipStream_t s, long long E, int K, int N, const float *A, int lda,
 bool latent_update_bwd_f32(hipStream_t s, long long E, int S, const float *dx, const float *u, const float *fc, const float *res,
                            float *du, float *dfc, float *dxprev);
 bool embed_bwd_Y_f32(hipStream_t s, long long E, int D, int U, const float *dV, const float *w, float *dY);
+bool env_bwd_Y_f32(hipStream_t s, long long E, int D, int U, const float *denv, const int *e_ii, int c0, const float *om, float *dY);
 // tensor product with the CG table unrolled at compile time (l_max 1, 2); scalar_only = last layer (l3 = 0 outputs)
 bool tp_fwd_f32(hipStream_t s, long long E, int L, bool scalar_only, int U, const float *pw, const float *V, const float *env,
                 const int *e_ii, int c0, float *Vp);

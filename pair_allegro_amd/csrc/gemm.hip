@@ -17,7 +17,7 @@ namespace ahip {
 
 typedef float f32x4g __attribute__((ext_vector_type(4)));
 
-template <bool TRANSB>
+template <bool TRANSB, bool VECA>
 __global__ void __launch_bounds__(256) k_gemm_f32(long long E, int K, int N, const float *__restrict__ A, int lda,
                                                    const float *__restrict__ W, int ldw, float *__restrict__ C, int ldc,
                                                    int accumulate) {
@@ -33,10 +33,16 @@ __global__ void __launch_bounds__(256) k_gemm_f32(long long E, int K, int N, con
   const int bk = tid >> 4, bn = (tid & 15) * 4;         // B tile: k row, first of 4 columns
   const long long arow = e0 + ar;
   for (int k0 = 0; k0 < K; k0 += 16) {
+    if (VECA) {      // rows and K are multiples of 4 floats and 16-byte aligned: one 16-byte load per thread
+      f32x4g v = {0.f, 0.f, 0.f, 0.f};
+      if (arow < E && k0 + ac < K) v = *(const f32x4g *)(A + arow * lda + k0 + ac);
+      sA[ar][ac] = v[0]; sA[ar][ac + 1] = v[1]; sA[ar][ac + 2] = v[2]; sA[ar][ac + 3] = v[3];
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = k0 + ac + i;
-      sA[ar][ac + i] = (arow < E && k < K) ? A[arow * lda + k] : 0.f;
+      for (int i = 0; i < 4; ++i) {
+        const int k = k0 + ac + i;
+        sA[ar][ac + i] = (arow < E && k < K) ? A[arow * lda + k] : 0.f;
+      }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -73,8 +79,11 @@ bool gemm_f32(hipStream_t s, long long E, int K, int N, const float *A, int lda,
               int ldc, bool accumulate) {
   if (E <= 0 || N <= 0) return true;
   const dim3 grid((unsigned)((E + 63) / 64), (unsigned)((N + 63) / 64));
-  if (transB) hipLaunchKernelGGL(k_gemm_f32<true>, grid, dim3(256), 0, s, E, K, N, A, lda, W, ldw, C, ldc, accumulate ? 1 : 0);
-  else hipLaunchKernelGGL(k_gemm_f32<false>, grid, dim3(256), 0, s, E, K, N, A, lda, W, ldw, C, ldc, accumulate ? 1 : 0);
+  const bool veca = (lda % 4 == 0) && (K % 4 == 0) && (((size_t)A) % 16 == 0);
+#define GEMM(TB, VA) hipLaunchKernelGGL((k_gemm_f32<TB, VA>), grid, dim3(256), 0, s, E, K, N, A, lda, W, ldw, C, ldc, accumulate ? 1 : 0)
+  if (transB) { if (veca) GEMM(true, true); else GEMM(true, false); }
+  else { if (veca) GEMM(false, true); else GEMM(false, false); }
+#undef GEMM
   return true;
 }
 
@@ -205,6 +214,27 @@ bool tp_bwd_f32(hipStream_t s, long long E, int L, bool scalar_only, int U, cons
 }
 
 static unsigned row_grid(long long E) { return (unsigned)std::min<long long>((E + 3) / 4, 256LL * 64); }
+// dY[e][lm] += sum_u denv[centre(e)][lm][u] om[e][l(lm)][u]                     (k_env_bwd_Y)
+__global__ void __launch_bounds__(256) k_env_bwd_Y_rows(long long E, int D, int U, const float *denv, const int *e_ii, int c0,
+                                                         const float *om, float *dY) {
+  const int lane = threadIdx.x & 63;
+  const long long nw = (long long)gridDim.x * 4;
+  const int nl = (D == 1) ? 1 : (D == 4 ? 2 : 3);
+  for (long long e = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); e < E; e += nw) {
+    const float *de = denv + (long long)(e_ii[e] - c0) * D * U;
+    for (int lm = 0; lm < D; ++lm) {
+      const int l = lm == 0 ? 0 : (lm < 4 ? 1 : 2);
+      float acc = 0.f;
+      for (int q = lane; q < U; q += 64) acc += de[lm * U + q] * om[e * nl * U + l * U + q];
+      acc = wave_sum(acc);
+      if (lane == 0) dY[e * D + lm] += acc;
+    }
+  }
+}
+bool env_bwd_Y_f32(hipStream_t s, long long E, int D, int U, const float *denv, const int *e_ii, int c0, const float *om, float *dY) {
+  if (E > 0) hipLaunchKernelGGL(k_env_bwd_Y_rows, dim3(row_grid(E)), dim3(256), 0, s, E, D, U, denv, e_ii, c0, om, dY);
+  return true;
+}
 
 bool latent_update_bwd_f32(hipStream_t s, long long E, int S, const float *dx, const float *u, const float *fc, const float *res,
                            float *du, float *dfc, float *dxprev) {

@@ -247,7 +247,12 @@ static void generic_chunk(Model &m, const ComputeArgs &a, Arena &A, int c0, int 
     RUN(k_segment_sum<T>, (long long)nc * D * U, s, nc, c0, eoff, e0, D * U, denv_e, cenv, denv);
     T *dom = A.get<T>(E * nl * U);
     RUN(k_env_bwd_om<T>, Ec * nl * U, s, Ec, D, U, denv, e_ii, c0, Y, dom);
-    RUN(k_env_bwd_Y<T>, Ec * D, s, Ec, D, U, denv, e_ii, c0, om[k], dY);
+    {
+      bool done = !go;
+      if constexpr (std::is_same<T, float>::value)
+        if (go) done = env_bwd_Y_f32(s, Ec, D, U, denv, e_ii, c0, om[k], dY);
+      if (!done) launch(k_env_bwd_Y<T>, Ec * D, s, Ec, D, U, denv, e_ii, c0, om[k], dY);
+    }
     linear_bwd(S, nl * U, dom, nl * U, go ? W.get(lk + ".env") : nullptr, dxprev, S, 1);
     dx = dxprev; dV = dVprev;
   }

@@ -36,6 +36,7 @@ void edges_free(Model &) {}
 bool gemm_f32(hipStream_t, long long, int, int, const float *, int, const float *, int, bool, float *, int, bool) { return false; }
 bool latent_update_bwd_f32(hipStream_t, long long, int, const float *, const float *, const float *, const float *, float *, float *, float *) { return false; }
 bool embed_bwd_Y_f32(hipStream_t, long long, int, int, const float *, const float *, float *) { return false; }
+bool env_bwd_Y_f32(hipStream_t, long long, int, int, const float *, const int *, int, const float *, float *) { return false; }
 bool tp_fwd_f32(hipStream_t, long long, int, bool, int, const float *, const float *, const float *, const int *, int, float *) { return false; }
 bool tp_bwd_f32(hipStream_t, long long, int, bool, int, const float *, const float *, const float *, const int *, int, const float *, float *, float *) { return false; }
 }  // namespace ahip

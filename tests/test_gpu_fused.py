@@ -88,6 +88,24 @@ def test_fused_two_body_table_matches_mlp(hip_lib, model_dir):
         np.testing.assert_allclose(tab["eatom"], mlp["eatom"], atol=2e-5)
 
 
+def test_fused_two_lammps_types_share_a_model_type(hip_lib, model_dir):
+    """BASELINE config 3 style deck (`pair_coeff * * f Li P O O`): two LAMMPS types mapped onto one model type
+    (pair_nequip_allegro.cpp:284-294) must give the forces of the plain 3-type run."""
+    g = util.load_golden("Cu2AgO4_r5")
+    path, cfg, types, names, ref = _model_S_case(model_dir, "cu2ago4_S_4t", ["Cu", "Ag", "O"], g["symbols"], g["cell"], g["pos"])
+    base = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused"})
+    o_type = names.index("O") + 1
+    types4 = types.copy()
+    o_atoms = np.where(types == o_type)[0]
+    types4[o_atoms[::2]] = len(names) + 1                    # every second oxygen becomes LAMMPS type 4, also named O
+    split = util.run_pair(hip_lib, path, g["cell"], g["pos"], types4, names + ["O"], options={"path": "fused"})
+    assert split["info"]["path"] == "fused_f32"
+    np.testing.assert_allclose(split["forces"], base["forces"], atol=1e-6)
+    np.testing.assert_allclose(split["eatom"], base["eatom"], atol=1e-6)
+    np.testing.assert_allclose(split["pe"], base["pe"], rtol=1e-7)
+    assert np.abs(split["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
+
+
 def test_fused_wide_tiles_65_to_128_neighbours(hip_lib, model_dir):
     """fcc Cu with r_max 6.1 A has 78 neighbours per atom: more than the 64-slot tile of the default 4-wave workgroup,
     so the 8-wave / 128-slot kernel instance runs; it must agree with the oracle like the narrow one."""

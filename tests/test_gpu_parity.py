@@ -29,3 +29,24 @@ def test_chunked_equals_unchunked(hip_lib, model_dir):
     a, _ = pc.check_golden(hip_lib, model_dir, "CuPd-cubic-big_r5", "float64", options={"path": "generic"})
     b, _ = pc.check_golden(hip_lib, model_dir, "CuPd-cubic-big_r5", "float64", options={"path": "generic", "chunk_edges": 1500})
     np.testing.assert_allclose(a["forces"], b["forces"], atol=1e-12)
+
+
+def test_model_L_shape_config5(hip_lib, model_dir):
+    """BASELINE config 5's model shape (l_max = 2, 64 tensor features, 3 layers, two types O/H) on the generic float32 path
+    (MFMA GEMMs, unrolled tensor product) against the float64 oracle; the CuPd 256-atom box stands in for the geometry."""
+    from oracle import allegro_torch
+    from pair_allegro_amd import model_file
+    g = util.load_golden("CuPd-cubic-big_r5")
+    symbols = ["O" if s == "Cu" else "H" for s in g["symbols"]]
+    nb = float(len(util.glue.brute_force_edges(g["cell"], g["pos"], 5.0)[0])) / len(g["pos"])
+    cfg = model_file.model_L(avg_num_neighbors=nb)
+    w = model_file.init_weights(cfg)
+    path = f"{model_dir}/modelL.nequip.pth"
+    allegro_torch.export_nequip_pth(path, cfg, w)
+    names = sorted(set(symbols))
+    types = np.array([names.index(s) + 1 for s in symbols], dtype=np.int32)
+    ref = util.oracle_run(dict(cfg, model_dtype="float64"), w, g["cell"], g["pos"], types, names)
+    res = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names)
+    assert res["info"]["path"] == "generic_f32"
+    util.assert_close_to(res, ref, 5e-4, what="model L generic f32 vs f64 oracle")
+    assert np.abs(res["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF

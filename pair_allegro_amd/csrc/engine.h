@@ -186,7 +186,7 @@ void edges_free(Model &m);
 // returning false and keeps the one-thread-per-output kernels) ----
 // C[e][n] (+)= sum_k A[e][k] * (transB ? W[n][k] : W[k][n])
 bool gemm_f32(hipStream_t s, long long E, int K, int N, const float *A, int lda, const float *W, int ldw, bool transB, float *C,
-              int ldc, bool accumulate);
+              int ldc, bool accumulate, float *silu_out = nullptr, const float *dsilu_z = nullptr);
 // wave-per-row versions of k_latent_update_bwd / k_embed_bwd_Y (same stubs in the emulation build)
 bool latent_update_bwd_f32(hipStream_t s, long long E, int S, const float *dx, const float *u, const float *fc, const float *res,
                            float *du, float *dfc, float *dxprev);

@@ -4,6 +4,7 @@
 // whose traffic is the activations: 4 E (K + N) bytes -- HBM-bound (intensity K N / (2 (K + N)) = 16 FLOP/B at 64x64).
 // One workgroup = 64 rows x 64 columns, four waves of 16 rows each; K is walked in steps of 16 through LDS
 // (A tile 64x16, B tile 16x64, padded rows: conflict-free operand reads); v_mfma_f32_16x16x4_f32, exact f32.
+// Optional fused epilogues: silu_out (forward: also store h = silu(C)), dsilu_z (backward: C *= silu'(z), z with C's layout).
 // Replaces the one-thread-per-output kernels k_linear / k_linear_bwd (generic_kernels.h), which stay for the float64
 // debug build and the CPU-emulated tests: they ran at 80-400 GB/s (78 % of the generic path's time).
 #include <hip/hip_runtime.h>
@@ -20,7 +21,7 @@ typedef float f32x4g __attribute__((ext_vector_type(4)));
 template <bool TRANSB, bool VECA>
 __global__ void __launch_bounds__(256) k_gemm_f32(long long E, int K, int N, const float *__restrict__ A, int lda,
                                                    const float *__restrict__ W, int ldw, float *__restrict__ C, int ldc,
-                                                   int accumulate) {
+                                                   int accumulate, float *__restrict__ silu_out, const float *__restrict__ dsilu_z) {
   __shared__ float sA[64][17];
   __shared__ float sB[16][65];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
@@ -69,18 +70,24 @@ __global__ void __launch_bounds__(256) k_gemm_f32(long long E, int K, int N, con
       const long long e = e0 + 16 * wave + 4 * g + r;
       if (e < E) {
         float *p = C + e * ldc + n;
-        *p = accumulate ? *p + acc[t][r] : acc[t][r];
+        float v = accumulate ? *p + acc[t][r] : acc[t][r];
+        if (dsilu_z) {                                  // backward through the SiLU that produced this layer's input
+          const float z = dsilu_z[e * ldc + n], sg = 1.f / (1.f + __expf(-z));
+          v *= sg * (1.f + z * (1.f - sg));
+        }
+        *p = v;
+        if (silu_out) silu_out[e * ldc + n] = v / (1.f + __expf(-v));     // forward: also h = silu(z)
       }
     }
   }
 }
 
 bool gemm_f32(hipStream_t s, long long E, int K, int N, const float *A, int lda, const float *W, int ldw, bool transB, float *C,
-              int ldc, bool accumulate) {
+              int ldc, bool accumulate, float *silu_out, const float *dsilu_z) {
   if (E <= 0 || N <= 0) return true;
   const dim3 grid((unsigned)((E + 63) / 64), (unsigned)((N + 63) / 64));
   const bool veca = (lda % 4 == 0) && (K % 4 == 0) && (((size_t)A) % 16 == 0);
-#define GEMM(TB, VA) hipLaunchKernelGGL((k_gemm_f32<TB, VA>), grid, dim3(256), 0, s, E, K, N, A, lda, W, ldw, C, ldc, accumulate ? 1 : 0)
+#define GEMM(TB, VA) hipLaunchKernelGGL((k_gemm_f32<TB, VA>), grid, dim3(256), 0, s, E, K, N, A, lda, W, ldw, C, ldc, accumulate ? 1 : 0, silu_out, dsilu_z)
   if (transB) { if (veca) GEMM(true, true); else GEMM(true, false); }
   else { if (veca) GEMM(false, true); else GEMM(false, false); }
 #undef GEMM

@@ -153,8 +153,13 @@ static void generic_chunk(Model &m, const ComputeArgs &a, Arena &A, int c0, int 
     const T *cur = in; int K = din;
     for (int k = 0; k < nhidden; ++k) {
       T *z = A.get<T>(E * width), *hh = A.get<T>(E * width);
-      linear_fwd(K, width, cur, K, go ? W.get(pre + ".w" + std::to_string(k)) : nullptr, z, width);
-      RUN(k_silu<T>, Ec * width, s, Ec * width, z, hh);
+      bool fusedsilu = false;                       // float32: the GEMM epilogue also writes h = silu(z)
+      if constexpr (std::is_same<T, float>::value)
+        if (go) fusedsilu = gemm_f32(s, Ec, K, width, cur, K, W.get(pre + ".w" + std::to_string(k)), width, false, z, width, false, hh, nullptr);
+      if (!fusedsilu) {
+        linear_fwd(K, width, cur, K, go ? W.get(pre + ".w" + std::to_string(k)) : nullptr, z, width);
+        RUN(k_silu<T>, Ec * width, s, Ec * width, z, hh);
+      }
       zs.push_back(z); cur = hh; K = width;
     }
     out = A.get<T>(E * dout);
@@ -167,8 +172,13 @@ static void generic_chunk(Model &m, const ComputeArgs &a, Arena &A, int c0, int 
     for (int k = nhidden; k >= 0; --k) {
       int K = (k == 0) ? din : width;
       T *dprev = A.get<T>(E * K);
-      linear_bwd(K, N, d, N, go ? W.get(pre + ".w" + std::to_string(k)) : nullptr, dprev, K, 0);
-      if (k > 0) RUN(k_silu_bwd<T>, Ec * K, s, Ec * K, zs[k - 1], dprev, dprev);
+      bool fusedsilu = false;                       // float32: the GEMM epilogue multiplies by silu'(z) of the layer below
+      if constexpr (std::is_same<T, float>::value)
+        if (go && k > 0) fusedsilu = gemm_f32(s, Ec, N, K, d, N, W.get(pre + ".w" + std::to_string(k)), N, true, dprev, K, false, nullptr, zs[k - 1]);
+      if (!fusedsilu) {
+        linear_bwd(K, N, d, N, go ? W.get(pre + ".w" + std::to_string(k)) : nullptr, dprev, K, 0);
+        if (k > 0) RUN(k_silu_bwd<T>, Ec * K, s, Ec * K, zs[k - 1], dprev, dprev);
+      }
       d = dprev; N = K;
     }
     return d;

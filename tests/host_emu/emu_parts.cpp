@@ -33,7 +33,7 @@ bool fused_run(Model &, const ComputeArgs &, std::string *why) { if (why) *why =
 void fused_free(Model &) {}
 bool edges_build_f32(Model &, const ComputeArgs &) { return false; }   // emulation runs the two-pass kernels
 void edges_free(Model &) {}
-bool gemm_f32(hipStream_t, long long, int, int, const float *, int, const float *, int, bool, float *, int, bool) { return false; }
+bool gemm_f32(hipStream_t, long long, int, int, const float *, int, const float *, int, bool, float *, int, bool, float *, const float *) { return false; }
 bool latent_update_bwd_f32(hipStream_t, long long, int, const float *, const float *, const float *, const float *, float *, float *, float *) { return false; }
 bool embed_bwd_Y_f32(hipStream_t, long long, int, int, const float *, const float *, float *) { return false; }
 bool env_bwd_Y_f32(hipStream_t, long long, int, int, const float *, const int *, int, const float *, float *) { return false; }

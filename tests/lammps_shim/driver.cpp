@@ -13,7 +13,28 @@ using namespace LAMMPS_NS;
 
 template <typename T> static std::vector<T> rd(FILE *f, size_t n) { std::vector<T> v(n); if (n && fread(v.data(), sizeof(T), n, f) != n) { perror("read"); exit(3); } return v; }
 
+// `plugin load` path: lammpsplugin_init must register pair allegro, compute allegro, compute allegro/atom
+#include "lammpsplugin.h"
+#include <string>
+static std::vector<std::string> g_registered;
+static lammpsplugin_factory1 *g_pair_factory = nullptr;
+static void collect_plugin(lammpsplugin_t *p, void *) {
+  g_registered.push_back(std::string(p->style) + ":" + p->name);
+  if (std::string(p->style) == "pair") g_pair_factory = p->creator.v1;
+}
+
 int main(int argc, char **argv) {
+  if (argc == 2 && std::string(argv[1]) == "--plugin") {
+    Atom atom; Comm comm; Force force; Neighbor neighbor; Error error; Memory memory; Update update;
+    LAMMPS lmp{&atom, &comm, &force, &neighbor, &error, &memory};
+    lmp.update = &update;
+    lammpsplugin_init(&lmp, nullptr, (void *) &collect_plugin);
+    for (auto &r : g_registered) printf("registered %s\n", r.c_str());
+    Pair *p = g_pair_factory ? (Pair *) g_pair_factory(&lmp) : nullptr;      // the factory builds a working pair style object
+    printf("pair object %s restartinfo=%d manybody=%d\n", p ? "ok" : "null", p ? p->restartinfo : -1, p ? p->manybody_flag : -1);
+    delete p;
+    return g_registered.size() == 3 && p ? 0 : 1;
+  }
   if (argc < 5) { fprintf(stderr, "usage: driver system.bin out.bin model names...\n"); return 2; }
   FILE *f = fopen(argv[1], "rb");
   int hdr[4];

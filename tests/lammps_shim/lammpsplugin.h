@@ -1,0 +1,21 @@
+// TEST INFRASTRUCTURE ONLY: the plugin registration types of LAMMPS' src/PLUGIN/lammpsplugin.h, as used by
+// pair_allegro_amd/lammps/allegro_hip_plugin.cpp.
+#pragma once
+extern "C" {
+typedef void *(lammpsplugin_factory1)(void *);
+typedef void *(lammpsplugin_factory2)(void *, int, char **);
+typedef struct {
+  const char *version;
+  const char *style;
+  const char *name;
+  const char *info;
+  const char *author;
+  union {
+    lammpsplugin_factory1 *v1;
+    lammpsplugin_factory2 *v2;
+  } creator;
+  void *handle;
+} lammpsplugin_t;
+typedef void (*lammpsplugin_regfunc)(lammpsplugin_t *, void *);
+void lammpsplugin_init(void *, void *, void *);
+}

@@ -84,3 +84,14 @@ def test_cpp_pair_style_deck_errors(driver, tmp_path, model_dir):
     assert r.returncode == 11 and b"Only accepts model paths with extension" in r.stdout
     r = run(mpath, "Ge")                                       # type name not in the model -> unmapped -> compute error
     assert r.returncode == 10 and b"not mapped" in r.stdout
+
+
+def test_cpp_plugin_registers_the_three_styles(driver):
+    """`plugin load` packaging: lammpsplugin_init registers pair allegro, compute allegro and compute allegro/atom, and the
+    pair factory returns a usable object (no LAMMPS rebuild needed)."""
+    r = subprocess.run([driver, "--plugin"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    text = r.stdout.decode()
+    assert r.returncode == 0, text
+    for name in ("registered pair:allegro", "registered compute:allegro", "registered compute:allegro/atom"):
+        assert name in text
+    assert "pair object ok restartinfo=0 manybody=1" in text

@@ -159,8 +159,10 @@ def main():
         # ---- CPU baseline + max|dF| on a bounded sample --------------------------------------
         cpu = None
         max_df = None
+        parity = None
         if not args.no_cpu_baseline:
-            cpu, max_df = cpu_baseline_and_parity(lib, cfg, weights, model_path, local_rank, args.cpu_sample_ncell, args.path)
+            cpu, parity = cpu_baseline_and_parity(lib, cfg, weights, model_path, local_rank, args.cpu_sample_ncell, args.path)
+            max_df = parity["max_abs_dF"]
         out = {
             "metric": "atom_steps_per_sec", "value": round(value, 1), "unit": "atom-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -170,6 +172,7 @@ def main():
                        "kernel_path": used_path, "rebuilds": sim.nrebuild, "stage_ms_rank0": {k: round(v, 3) for k, v in stage_avg.items()},
                        "pe_per_atom": th["pe"] / natoms},
             "max_abs_dF_vs_oracle": max_df,
+            "parity_vs_oracle": parity,
             "roofline": roof,
             "cpu_baseline": cpu,
         }
@@ -201,18 +204,24 @@ def cpu_baseline_and_parity(lib, cfg, weights, model_path, device_index, ncell, 
         reps += 1
     t_eval = (time.perf_counter() - t0) / reps
     f_ref = np.zeros_like(rs.x)
-    glue.compute(oracle, rs.x, rs.type, rs.nlocal, rs.ilist, rs.numneigh, rs.firstneigh, mapper, cm, f_ref)
+    e_ref = np.zeros(len(rs.x))
+    pe_ref, vir_ref, _ = glue.compute(oracle, rs.x, rs.type, rs.nlocal, rs.ilist, rs.numneigh, rs.firstneigh, mapper, cm, f_ref, e_ref)
     m = capi.Model(model_path, device_index, lib)
     m.set_option("path", path)
     m.neigh_update_csr(rs.nall, rs.ilist, rs.offsets, rs.flat)
     f = np.zeros_like(rs.x)
-    m.compute(rs.nlocal, rs.nghost, rs.x, rs.type, mapper, cm, f)
+    e = np.zeros(len(rs.x))
+    pe, vir = m.compute(rs.nlocal, rs.nghost, rs.x, rs.type, mapper, cm, f, e)
     m.close()
     max_df = float(np.abs(f - f_ref).max())
+    # the other observables of the reference's own comparison: per-atom energy, PE per atom, virial per atom
+    parity = {"max_abs_dF": max_df, "max_abs_dEatom": float(np.abs(e[: rs.nlocal] - e_ref[: rs.nlocal]).max()),
+              "abs_dPE_per_atom": float(abs(pe - pe_ref) / rs.nlocal),
+              "max_abs_dvirial_per_atom": float(np.abs(vir - vir_ref).max() / rs.nlocal), "atoms": int(rs.nlocal)}
     cpu = {"value": round(rs.nlocal / t_eval, 1), "unit": "atom-steps/s", "cores": torch.get_num_threads(),
            "kind": "port", "sample": f"{rs.nlocal}-atom bulk Si (config 2), {reps} force evaluations of the TorchScript "
                                      f"oracle (float32 model, autograd forces), {t_eval*1e3:.0f} ms each; glue excluded"}
-    return cpu, max_df
+    return cpu, parity
 
 
 if __name__ == "__main__":

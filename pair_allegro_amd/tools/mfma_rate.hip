@@ -89,7 +89,51 @@ __global__ void __launch_bounds__(256, OCC) k_stream(const float *W, int wbytes,
   if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[0] = (long long)pad[lane];
 }
 
+// per-edge gathers (16 lanes groups of 4 read 64 B each from 16 random 1 KiB blocks, like the two-body table) vs the same bytes
+// read as whole 1 KiB blocks by the 64 lanes of an instruction
+template <int MODE>
+__global__ void __launch_bounds__(256, 2) k_gather(const float *T, int nblk, long long *out, int iters) {
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+  __shared__ float pad[20000];
+  pad[threadIdx.x] = 0.f;
+  unsigned rs = (blockIdx.x * 4 + wave) * 2654435761u + 12345u;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+    rs = rs * 1664525u + 1013904223u;
+    if (MODE == 0) {            // gather: lane (j, g): block of edge j, 16 instructions (tile x coef)
+      const unsigned blk = (rs + 7919u * j) % nblk;
+      const float *e = T + (size_t)blk * 256 + 4 * g;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc += *(const f32x4 *)(e + k * 16);
+    } else {                    // coalesced: instruction k reads the whole block of edge k
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const unsigned blk = (rs + 7919u * k) % nblk;
+        acc += *(const f32x4 *)(T + (size_t)blk * 256 + 4 * lane);
+      }
+    }
+  }
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[0] = (long long)pad[lane];
+}
+
 int main() {
+  {
+    const int nblk = 512;
+    float *T; long long *o2;
+    hipMalloc((void **)&T, (size_t)nblk * 1024); hipMemset(T, 0, (size_t)nblk * 1024);
+    hipMalloc((void **)&o2, 64);
+    hipEvent_t a0, a1; hipEventCreate(&a0); hipEventCreate(&a1);
+    const int it2 = 2000;
+    auto rung = [&](const char *name, auto kern) {
+      for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(a0, 0); hipLaunchKernelGGL(kern, dim3(512), dim3(256), 0, 0, T, nblk, o2, it2); hipEventRecord(a1, 0); hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, a0, a1);
+        if (rep) std::printf("%-44s %7.3f ms  %6.0f cycles per 16 KiB (16 instructions) per wave at 2.3 GHz, 8 waves/CU\n", name, ms, ms * 1e-3 * 2.3e9 / it2);
+      }
+    };
+    rung("table gather (64 B pieces of 16 blocks)", k_gather<0>);
+    rung("same bytes as whole 1 KiB blocks", k_gather<1>);
+  }
   {
     const int entries = 1344;     // ~ the bf16x3 stream of model S
     float *dW; long long *out;

@@ -160,7 +160,7 @@ def main():
         cpu = None
         max_df = None
         parity = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # reported baseline: rank 0 at N = 1 only
             cpu, parity = cpu_baseline_and_parity(lib, cfg, weights, model_path, local_rank, args.cpu_sample_ncell, args.path)
             max_df = parity["max_abs_dF"]
         out = {

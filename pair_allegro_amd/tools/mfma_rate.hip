@@ -36,6 +36,8 @@ __global__ void __launch_bounds__(256, OCC) k_rate(const float *W, int wbytes, f
   if (lane == 0) out[blockIdx.x * 4 + wave] = t1 - t0;
 }
 
+__device__ __forceinline__ f32x4 acc_dummy(u32x4 v) { return __builtin_bit_cast(f32x4, v); }
+
 template <int EPI, int OCC>
 __global__ void __launch_bounds__(256, OCC) k_rate_b(const float *W, int wbytes, float *scr, long long *out, int iters) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, v16 = lane * 16;
@@ -63,6 +65,60 @@ __global__ void __launch_bounds__(256, OCC) k_rate_b(const float *W, int wbytes,
   float sum = 0.f;
   for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r) sum += x[t][r];
   if (sum == 12345.678f) out[0] = (long long)pad[lane];
+}
+
+// bf16x3 64x64 linears with the weight fragments SHARED by the 4 waves of a workgroup through LDS (each wave fetches a quarter of
+// the next linear's 24 fragments while the current ones are consumed; one barrier per linear).  Feasibility probe for the next
+// kernel generation: per-wave register rings are bound by the 64 B/clk/CU return path (see k_rate_b).
+template <int OCC>
+__global__ void __launch_bounds__(256, OCC) k_rate_b_lds(const float *W, int wbytes, long long *out, int iters) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, v16 = lane * 16;
+  __shared__ float ringl[2][24 * 256];                    // two halves of 24 fragments (1 KiB each) = 48 KiB
+  __shared__ float pad[OCC == 2 ? 7000 : 27000];          // pins the number of workgroups per CU
+  pad[threadIdx.x] = 0.f;
+  __amdgpu_buffer_rsrc_t WB = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, wbytes, 0x00020000);
+  f32x4 x[4], y[4];
+  for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r) x[t][r] = 0.001f * (float)((lane * 7 + t * 4 + r) % 13);
+  Bop xb[2];
+  xb[0] = split_pair(x[0], x[1]); xb[1] = split_pair(x[2], x[3]);
+  // prime half 0 with linear 0
+  for (int i = 0; i < 6; ++i) *(f32x4 *)(&ringl[0][(6 * wave + i) * 256 + 4 * lane]) = bload(WB, v16, ((6 * wave + i) * 256) * 4);
+  __syncthreads();
+  int half = 0;
+  for (int it = 0; it < iters; ++it) {
+    // fetch the next linear's fragments (the stream alternates between two linears of 24 fragments)
+    f32x4 nx[6];
+    const int base = ((it + 1) & 1) * 24;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) nx[i] = bload(WB, v16, ((base + 6 * wave + i) * 256) * 4);
+    // consume the current half: 2 tile pairs x 2 K-steps x 6 fragments
+    f32x4 acc[4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 fr[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) fr[i] = __builtin_bit_cast(u32x4, *(const f32x4 *)(&ringl[half][((p * 2 + ks) * 6 + i) * 256 + 4 * lane]));
+        a0 = mfma_b(fr[4], xb[ks].hi, a0); a1 = mfma_b(fr[5], xb[ks].hi, a1);
+        a0 = mfma_b(fr[2], xb[ks].mid, a0); a1 = mfma_b(fr[3], xb[ks].mid, a1);
+        a0 = mfma_b(fr[0], xb[ks].lo, a0); a1 = mfma_b(fr[1], xb[ks].lo, a1);
+        a0 = mfma_b(fr[2], xb[ks].hi, a0); a1 = mfma_b(fr[3], xb[ks].hi, a1);
+        a0 = mfma_b(fr[0], xb[ks].mid, a0); a1 = mfma_b(fr[1], xb[ks].mid, a1);
+        a0 = mfma_b(fr[0], xb[ks].hi, a0); a1 = mfma_b(fr[1], xb[ks].hi, a1);
+      }
+      acc[2 * p] = a0; acc[2 * p + 1] = a1;
+    }
+    xb[0] = split_pair(acc[0], acc[1]); xb[1] = split_pair(acc[2], acc[3]);
+    // publish the fetched fragments into the other half
+#pragma unroll
+    for (int i = 0; i < 6; ++i) *(f32x4 *)(&ringl[half ^ 1][(6 * wave + i) * 256 + 4 * lane]) = nx[i];
+    __syncthreads();
+    half ^= 1;
+  }
+  y[0] = acc_dummy(xb[0].hi);
+  if (y[0][0] == 12345.678f) out[0] = (long long)pad[lane];
 }
 
 // weight-stream bandwidth: every wave reads the same `entries`-KiB stream (L2 resident) with `DEPTH` 1-KiB loads in flight,
@@ -169,6 +225,18 @@ int main() {
           if (rep) std::printf("%-40s %7.3f ms  %6.1f f32-equivalent TFLOP/s, %5.0f cycles per 64x64 linear per wave at 2.3 GHz\n", name, ms, fl / (ms * 1e-3) * 1e-12, ms * 1e-3 * 2.3e9 / (itb * 2.0));
         }
       };
+      auto runl = [&](const char *name, int grid, auto kern) {
+        for (int rep = 0; rep < 2; ++rep) {
+          hipEventRecord(e0, 0);
+          hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, dWb, eb * 1024, out, 2 * itb);
+          hipEventRecord(e1, 0); hipDeviceSynchronize();
+          float ms; hipEventElapsedTime(&ms, e0, e1);
+          const double fl = (double)grid * 4 * itb * 2.0 * 64 * 64 * 16 * 2;
+          if (rep) std::printf("%-40s %7.3f ms  %6.1f f32-equivalent TFLOP/s, %5.0f cycles per 64x64 linear per wave at 2.3 GHz\n", name, ms, fl / (ms * 1e-3) * 1e-12, ms * 1e-3 * 2.3e9 / (itb * 2.0));
+        }
+      };
+      runl("bf16x3 LDS-shared weights, 1 wave/SIMD", 256, k_rate_b_lds<1>);
+      runl("bf16x3 LDS-shared weights, 2 waves/SIMD", 512, k_rate_b_lds<2>);
       runb("bf16x3 no epilogue + split, 1 wave/SIMD", 256, k_rate_b<0, 1>);
       runb("bf16x3 no epilogue + split, 2 waves/SIMD", 512, k_rate_b<0, 2>);
       runb("bf16x3 silu+save+split, 1 wave/SIMD", 256, k_rate_b<1, 1>);

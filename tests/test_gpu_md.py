@@ -65,3 +65,31 @@ def test_nve_energy_conservation(hip_lib, model_dir, path):
     assert abs(t["pe"] - t0["pe"]) > 1e-3      # the system actually evolved
     assert model.last_path == ("fused_f32" if path == "fused" else "generic_f32")
     model.close()
+
+
+def test_full_size_properties_1M(hip_lib, model_dir):
+    """BASELINE configs[3] at full size (1 000 000-atom Si, the bench workload) through size-independent properties: 28 edges
+    per atom from the device-built list, net force = 0 (every edge's force pair, every tile, every dynamically claimed chunk
+    accounted for exactly once), finite per-atom potential energy equal to the small box's up to the jitter, and the same
+    forces on a second evaluation (f64 atomics in a different order)."""
+    cfg, w, model = _model(model_dir, hip_lib)
+    cell, pos, _ = lmp_like.diamond_si(50)
+    n = len(pos)
+    dev = torch.device("cuda", 0)
+    sim = md.Simulation(md.HipBackend(model, [MASS]), np.diag(cell), cfg["r_max"], 1.0, pos, np.zeros(n, np.int32), None, dev)
+    sim.setup()
+    assert model.last_path == "fused_f32"
+    ei, _ = model.get_edges()
+    assert ei.shape[1] == 28 * n
+    f = sim.f[: sim.nlocal].clone()
+    fsum = f.sum(dim=0).abs().max().item()
+    assert fsum < 1e-6 * n ** 0.5, fsum
+    fmax = f.abs().max().item()
+    assert 1e-3 < fmax < 10.0
+    pe = sim.thermo([MASS])["pe"] / n
+    small_cell, small_pos, _ = lmp_like.diamond_si(6)
+    small = util.run_pair(hip_lib, os.path.join(model_dir, "md_float32.ahip"), small_cell, small_pos, np.ones(len(small_pos), np.int32), ["Si"])
+    assert abs(pe - small["pe"] / len(small_pos)) < 5e-3            # same lattice, independent jitter
+    sim.compute_forces()
+    assert (sim.f[: sim.nlocal] - f).abs().max().item() < 1e-9
+    model.close()

@@ -5,6 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+--config {2,3,4,5} selects the BASELINE.json configuration (default 4 = the one the metric is quoted on);
+`python bench.py --gpus N` without a launcher starts its own N rank processes.
+
 Workload (BASELINE.json metric / configs[3]): 1 000 000-atom bulk Si (50^3 diamond cells, a = 5.431 A,
 Gaussian jitter 0.05 A seed 0), model S (l_max = 1, 32 tensor features, 64 scalars, 2 layers,
 seeded random weights), r_max 5 A, skin 1 A, NVE, dt 1 fs, velocities 300 K.  STRONG scaling: the
@@ -52,28 +55,82 @@ def model_macs_per_edge(cfg, two_body_tabulated=False):
     return fwd
 
 
+# ---- BASELINE.json configs.  configs[0] (64-atom Si on CPU libtorch) is the reference's own plumbing case
+# and appears only in the parity tests; --config 4 (1 M-atom Si, model S) is the configuration the metric is quoted on.
+def workload(config: int, ncell: int = 0):
+    """-> dict(name, cell, pos, mtype (model type per atom), cfg, masses (per model type), lammps_names)."""
+    from pair_allegro_amd import lmp_like, model_file
+    if config in (2, 4):
+        n = ncell or (11 if config == 2 else 50)
+        cell, pos, types = lmp_like.diamond_si(n)
+        cfg = model_file.model_S()
+        return dict(name=f"{len(pos)}-atom bulk Si ({n}^3 diamond cells), model S (l_max=1, U=32, S=64, 2 layers)",
+                    cell=cell, pos=pos, mtype=np.zeros(len(pos), np.int32), cfg=cfg, masses=[SI_MASS], lammps_names=["Si"],
+                    lammps_types=types)
+    if config == 3:
+        reps = (10, 16, 20) if not ncell else (ncell, ncell, ncell)
+        cell, pos, types = lmp_like.li3po4(reps)
+        cfg = model_file.model_S(type_names=["Li", "P", "O"], avg_num_neighbors=48.6)
+        names = lmp_like.LI3PO4_LAMMPS_NAMES                      # pair_coeff * * f Li P O O
+        mapper = np.array([cfg["type_names"].index(s) for s in names], dtype=np.int32)
+        return dict(name=f"{len(pos)}-atom Li3PO4 ({reps[0]}x{reps[1]}x{reps[2]} Pnma cells, 4 LAMMPS types Li P O1 O2 -> model types "
+                         f"Li P O), model S (l_max=1, U=32, S=64, 2 layers)",
+                    cell=cell, pos=pos, mtype=mapper[types - 1], cfg=cfg,
+                    masses=[lmp_like.LI3PO4_MASSES[s] for s in cfg["type_names"]], lammps_names=names, lammps_types=types)
+    if config == 5:
+        m = ncell or 55
+        cell, pos, types = lmp_like.water(m)
+        cfg = model_file.model_L(avg_num_neighbors=53.6)
+        return dict(name=f"{len(pos)}-atom water ({m}^3 molecules, O/H), model L (l_max=2, U=64, S=64, 3 layers)",
+                    cell=cell, pos=pos, mtype=(types - 1).astype(np.int32), cfg=cfg,
+                    masses=[lmp_like.WATER_MASSES[s] for s in cfg["type_names"]], lammps_names=["O", "H"], lammps_types=types)
+    raise SystemExit(f"bench.py: unknown --config {config} (2, 3, 4 or 5)")
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` typed as is (no launcher): start N fresh rank processes BEFORE anything touches the GPU
+    (never re-exec a process that has initialised HIP) and relay their exit status; rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--ncell", type=int, default=50, help="diamond cells per box edge (50 -> 1M atoms)")
+    ap.add_argument("--config", type=int, default=4, help="BASELINE.json config: 2 (10k Si), 3 (100k Li3PO4), 4 (1M Si, the metric), 5 (500k water, model L)")
+    ap.add_argument("--ncell", type=int, default=0, help="override the replication of the chosen config (smaller boxes for quick runs)")
     ap.add_argument("--path", default="auto", choices=["auto", "fused", "generic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-ncell", type=int, default=11)
+    ap.add_argument("--no-overlap", action="store_true", help="serial ghost exchange (A/B against the overlapped schedule)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
     import torch
-    from pair_allegro_amd import capi, lmp_like, md, model_file
+    from pair_allegro_amd import capi, md, model_file
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: allegro-hip has no CPU fallback")
@@ -85,10 +142,11 @@ def main():
         dist_mod.init_process_group(backend="nccl", device_id=device)
         dist = dist_mod
 
-    cfg = model_file.model_S()
+    wl = workload(args.config, args.ncell)
+    cfg = wl["cfg"]
     weights = model_file.init_weights(cfg)
     tmpdir = tempfile.mkdtemp(prefix="ahip_bench_")
-    model_path = os.path.join(tmpdir, f"modelS_{rank}.ahip")
+    model_path = os.path.join(tmpdir, f"model_{rank}.ahip")
     model_file.save_ahip(model_path, cfg, weights)
 
     lib = capi.Library()
@@ -96,14 +154,15 @@ def main():
     model.set_option("path", args.path)
     model.set_option("timing", "1")
 
-    cell, pos, _ = lmp_like.diamond_si(args.ncell)
+    pos = wl["pos"]
     natoms = len(pos)
-    box = np.diag(cell)
-    vel = md.maxwell_boltzmann(natoms, np.full(natoms, SI_MASS), 300.0, 12345)
+    box = np.diag(wl["cell"])
+    mass_by_mtype = np.asarray(wl["masses"], dtype=np.float64)
+    vel = md.maxwell_boltzmann(natoms, mass_by_mtype[wl["mtype"]], 300.0, 12345)
     grid = md.choose_grid(world)
-    backend = md.HipBackend(model, [SI_MASS])
-    sim = md.Simulation(backend, box, cfg["r_max"], 1.0, pos, np.zeros(natoms, dtype=np.int32), vel, device,
-                        grid=grid, rank=rank, dist=dist, dt=0.001)
+    backend = md.HipBackend(model, wl["masses"])
+    sim = md.Simulation(backend, box, cfg["r_max"], 1.0, pos, wl["mtype"], vel, device,
+                        grid=grid, rank=rank, dist=dist, dt=0.001, overlap=not args.no_overlap)
     sim.setup()
     for _ in range(args.warmup):
         sim.step()
@@ -116,17 +175,22 @@ def main():
     stage_ms = {}
     barrier()
     t0 = time.perf_counter()
+    edges_step = []
     for _ in range(args.steps):
+        backend.stats = {}
         sim.step()
-        for k, v in model.timings().items():
+        edges_step.append(backend.stats.pop("edges", 0))
+        backend.stats.pop("calls", None)
+        for k, v in backend.stats.items():
             stage_ms.setdefault(k, []).append(v)
+    backend.stats = None
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    th = sim.thermo([SI_MASS])
+    th = sim.thermo(wl["masses"])
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
@@ -135,41 +199,50 @@ def main():
         # ---- roofline of the dominant kernel -------------------------------------------------
         tb_tab = used_path == "fused_f32" and os.environ.get("AHIP_FUSED_TB", "table") != "mlp"
         # ALGORITHMIC flops = the model's dense contractions (SURVEY 8d / DESIGN 4.2), whatever the kernel does with them;
-        # the fused kernel's tabulated two-body embedding executes fewer: reported next to it as executed_flops_per_edge.
+        # the fused kernels' tabulated two-body embedding executes fewer: frac_executed is priced on those.
         flops_per_edge = 2.0 * model_macs_per_edge(cfg) * 2.0       # 2 flop per MAC x (forward + input-gradient backward)
         executed_flops_per_edge = 2.0 * model_macs_per_edge(cfg, two_body_tabulated=tb_tab) * 2.0
-        import ctypes as C
-        ne = C.c_longlong(0)
-        lib.check(lib.lib.ahip_get_edges(model.h, C.byref(ne), None, None))
-        edges_rank0 = ne.value
+        edges_rank0 = int(np.mean(edges_step))          # all centres of this rank (summed over the calls of a step)
         stage_avg = {k: float(np.mean(v)) for k, v in stage_ms.items()}
         dom = max((k for k in stage_avg if k.startswith("model")), key=lambda k: stage_avg[k], default=None)
         roof = None
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")      # measured in a separate PMC run (cannot be collected live)
-        if os.path.exists(tj) and used_path == "fused_f32" and natoms == 1000000 and world == 1:
-            traffic = json.load(open(tj))["traffic_bytes_per_launch"]
+        traffic, traffic_src = None, None
+        tj = os.path.join(ROOT, "profiles", "traffic.json")          # measured in separate --pmc passes (cannot be collected live)
+        if os.path.exists(tj) and world == 1:
+            ent = json.load(open(tj)).get(f"config{args.config}:{used_path}:{natoms}")
+            if ent:
+                traffic, traffic_src = ent["traffic_bytes_per_launch"], ent["source"]
         if dom is not None:
             ach = flops_per_edge * edges_rank0 / (stage_avg[dom] * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": 157.3, "unit": "TFLOP/s",
-                    "frac": round(ach / 157.3, 4), "traffic": traffic, "kernel": dom,
+                    "frac": round(ach / 157.3, 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": dom,
                     "avg_ms": round(stage_avg[dom], 3), "edges_per_launch": edges_rank0,
                     "flops_per_edge": flops_per_edge, "executed_flops_per_edge": executed_flops_per_edge,
+                    "frac_executed": round(ach / 157.3 * executed_flops_per_edge / flops_per_edge, 4),
                     "two_body": "table" if tb_tab else "mlp"}
+            if "edge_build" in stage_avg:
+                # the neighbor gather (HBM-bound): algorithmic bytes per list entry 4 (j) + 24 (x_j) + 4 (type_j), per edge 20
+                # (e_ii, e_j, rvec) + 1 (packed types) -- DESIGN.md 4.1
+                nb = model.nneigh() * 32.0 + edges_rank0 * 21.0
+                gbs = nb / (stage_avg["edge_build"] * 1e-3) / 1e9
+                roof["neighbor_gather"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+                                           "frac": round(gbs / 8000.0, 4), "avg_ms": round(stage_avg["edge_build"], 4),
+                                           "algorithmic_bytes": nb}
         # ---- CPU baseline + max|dF| on a bounded sample --------------------------------------
         cpu = None
         max_df = None
         parity = None
         if not args.no_cpu_baseline and world == 1:       # reported baseline: rank 0 at N = 1 only
-            cpu, parity = cpu_baseline_and_parity(lib, cfg, weights, model_path, local_rank, args.cpu_sample_ncell, args.path)
+            cpu, parity = cpu_baseline_and_parity(lib, args.config, local_rank, args.cpu_sample_ncell, args.path)
             max_df = parity["max_abs_dF"]
         out = {
             "metric": "atom_steps_per_sec", "value": round(value, 1), "unit": "atom-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{natoms}-atom bulk Si ({args.ncell}^3 diamond cells), model S (l_max=1, U=32, S=64, 2 layers), "
-                                   f"r_max 5.0 A + skin 1.0 A, NVE dt=1 fs", "grid": "x".join(map(str, grid)),
-                       "kernel_path": used_path, "rebuilds": sim.nrebuild, "stage_ms_rank0": {k: round(v, 3) for k, v in stage_avg.items()},
+            "config": {"workload": f"BASELINE config {args.config}: {wl['name']}, r_max {cfg['r_max']} A + skin 1.0 A, NVE dt=1 fs",
+                       "grid": "x".join(map(str, grid)), "kernel_path": used_path, "rebuilds": sim.nrebuild,
+                       "comm": "overlapped" if sim.overlap else "serial",
+                       "stage_ms_rank0": {k: round(v, 3) for k, v in stage_avg.items()},
                        "pe_per_atom": th["pe"] / natoms},
             "max_abs_dF_vs_oracle": max_df,
             "parity_vs_oracle": parity,
@@ -183,44 +256,69 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline_and_parity(lib, cfg, weights, model_path, device_index, ncell, path):
-    """Times the oracle (torch CPU, all host cores; a port of the reference's libtorch path) on the
-    config-2 box and measures max|dF| of the HIP path against it on the same configuration."""
+def cpu_sample(config: int, ncell: int):
+    """Bounded sample of the same workload for the CPU leg (about 10-30 s of host work)."""
+    if config in (2, 4):
+        return workload(2, ncell or 11)                       # 10 648-atom Si = BASELINE configs[1] (SURVEY 8d sizes)
+    if config == 3:
+        wl = workload(3, 0)
+        from pair_allegro_amd import lmp_like
+        cell, pos, types = lmp_like.li3po4((3, 5, 6))         # 2 880 atoms, same cell
+        mapper = np.array([wl["cfg"]["type_names"].index(s) for s in wl["lammps_names"]], dtype=np.int32)
+        return dict(wl, name="2880-atom Li3PO4 (3x5x6 cells)", cell=cell, pos=pos, lammps_types=types, mtype=mapper[types - 1])
+    return workload(5, 12)                                    # 5 184-atom water, model L
+
+
+def cpu_baseline_and_parity(lib, config, device_index, ncell, path):
+    """Times the oracle (torch CPU, all host cores; a port of the reference's libtorch path) on a bounded sample of the
+    benchmarked workload and measures max|dF| of the HIP path against it on the same configuration."""
     import torch
     from oracle import allegro_torch, glue
-    from pair_allegro_amd import capi, lmp_like
-    cell, pos, types = lmp_like.diamond_si(ncell)
-    rs = lmp_like.build_rank_system(cell, pos, types, cfg["r_max"] + 1.0)
-    mapper = np.array([0], dtype=np.int32)
-    cm = np.array([[cfg["r_max"]]])
+    from pair_allegro_amd import capi, lmp_like, model_file
+    wl = cpu_sample(config, ncell)
+    cfg = wl["cfg"]
+    weights = model_file.init_weights(cfg)
+    tmpdir = tempfile.mkdtemp(prefix="ahip_bench_cpu_")
+    model_path = os.path.join(tmpdir, "model.ahip")
+    model_file.save_ahip(model_path, cfg, weights)
+    names = wl["lammps_names"]
+    rs = lmp_like.build_rank_system(wl["cell"], wl["pos"], wl["lammps_types"], cfg["r_max"] + 1.0)
+    mapper = np.array([cfg["type_names"].index(s) for s in names], dtype=np.int32)
+    cm = np.full((len(names), len(names)), cfg["r_max"])
     oracle = torch.jit.script(allegro_torch.build(cfg, weights).eval())
     inp = glue.preprocess(rs.x, rs.type, rs.nlocal, rs.ilist, rs.numneigh, rs.firstneigh, mapper, cm)
     tin = {k: torch.from_numpy(v) for k, v in inp.items()}
-    oracle(tin)                                                       # warm-up (JIT profiling runs)
-    oracle(tin)
+    for _ in range(3):                                                # warm-up (JIT profiling runs); SURVEY 8d: 3 warm-up
+        oracle(tin)
     reps, t0 = 0, time.perf_counter()
-    while reps < 3 or (time.perf_counter() - t0 < 10.0 and reps < 20):
-        out = oracle(tin)
+    while reps < 3 or (time.perf_counter() - t0 < 20.0 and reps < 10):    # >= 10 timed evaluations when they fit in ~20 s
+        oracle(tin)
         reps += 1
     t_eval = (time.perf_counter() - t0) / reps
     f_ref = np.zeros_like(rs.x)
     e_ref = np.zeros(len(rs.x))
+    tg = time.perf_counter()
     pe_ref, vir_ref, _ = glue.compute(oracle, rs.x, rs.type, rs.nlocal, rs.ilist, rs.numneigh, rs.firstneigh, mapper, cm, f_ref, e_ref)
+    t_glue_incl = time.perf_counter() - tg
     m = capi.Model(model_path, device_index, lib)
     m.set_option("path", path)
     m.neigh_update_csr(rs.nall, rs.ilist, rs.offsets, rs.flat)
     f = np.zeros_like(rs.x)
     e = np.zeros(len(rs.x))
     pe, vir = m.compute(rs.nlocal, rs.nghost, rs.x, rs.type, mapper, cm, f, e)
+    used = m.last_path
     m.close()
     max_df = float(np.abs(f - f_ref).max())
     # the other observables of the reference's own comparison (SURVEY 8d): per-atom energy, PE per atom, virial per atom
     parity = {"max_abs_dF": max_df, "max_abs_dEatom": float(np.abs(e[: rs.nlocal] - e_ref[: rs.nlocal]).max()),
               "abs_dPE_per_atom": float(abs(pe - pe_ref) / rs.nlocal),
-              "max_abs_dvirial_per_atom": float(np.abs(vir - vir_ref).max() / rs.nlocal), "atoms": int(rs.nlocal)}
+              "max_abs_dvirial_per_atom": float(np.abs(vir - vir_ref).max() / rs.nlocal), "atoms": int(rs.nlocal),
+              "kernel_path": used, "sample": wl["name"]}
     cpu = {"value": round(rs.nlocal / t_eval, 1), "unit": "atom-steps/s", "cores": torch.get_num_threads(),
-           "kind": "port", "sample": f"{rs.nlocal}-atom bulk Si (config 2), {reps} force evaluations of the TorchScript "
-                                     f"oracle (float32 model, autograd forces), {t_eval*1e3:.0f} ms each; glue excluded"}
+           "kind": "port", "sample": f"{wl['name']}: 3 warm-up + {reps} timed force evaluations of the TorchScript oracle (float32 model, "
+                                     f"autograd forces) on torch CPU threads, {t_eval*1e3:.0f} ms each (model only); "
+                                     f"{t_glue_incl*1e3:.0f} ms with preprocess + scatter (python glue)",
+           "value_glue_inclusive": round(rs.nlocal / t_glue_incl, 1)}
     return cpu, parity
 
 

@@ -112,6 +112,19 @@ int ahip_compute_dev(ahip_model *m, int nlocal, int nghost, const double *x_dev,
                      const double *cutoff_matrix_model, double *f_dev, double *eatom_dev,
                      double *eng_vir_dev, void *stream);
 
+/* Same evaluation restricted to the centre atoms ilist[centre_begin .. centre_end) of the installed list (their edges, their
+ * energies; forces still go to every atom they touch).  eng_vir_dev receives this range's partial sums.  This is what lets a
+ * caller overlap the ghost exchange with the force evaluation (SURVEY 8e "Overlap"): centres whose whole neighbourhood is
+ * local are evaluated while ghost positions are in flight, the boundary centres afterwards
+ * (the reference evaluates all centres in one libtorch call after the exchange: pair_nequip_allegro.cpp:333-407). */
+int ahip_compute_dev_range(ahip_model *m, int centre_begin, int centre_end, int nlocal, int nghost, const double *x_dev,
+                           const int *mtype_dev, const double *cutoff_matrix_model, double *f_dev, double *eatom_dev,
+                           double *eng_vir_dev, void *stream);
+
+/* Number of entries of the installed (skin-inflated) neighbor list: sum of numneigh over the centre atoms
+ * (the walk of pair_nequip_allegro.cpp:489-496 visits exactly these). */
+long long ahip_last_list_size(ahip_model *m);
+
 /* `compute allegro` / `compute allegro/atom` support: named entries of the model's output dict kept from the last
  * ahip_compute call (reference: the pair style stashes `output.at(name)` for every name registered through
  * add_custom_output, pair_nequip_allegro.cpp:403-406,681-684; compute/compute_allegro.cpp:81,114,145 reads them).

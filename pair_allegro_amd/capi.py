@@ -22,6 +22,7 @@ SYMBOLS = [
     "ahip_last_error", "ahip_device_count", "ahip_model_load", "ahip_model_free", "ahip_model_meta",
     "ahip_set_option", "ahip_neigh_update", "ahip_neigh_update_csr", "ahip_neigh_update_dev",
     "ahip_compute", "ahip_compute_dev", "ahip_output_register", "ahip_output_get", "ahip_get_edges", "ahip_debug_dump_edges", "ahip_get_timings",
+    "ahip_compute_dev_range", "ahip_last_list_size",
     "ahip_last_path", "ahip_last_max_degree", "ahip_debug_fused_linear", "ahip_debug_fused_edges", "ahip_build_neighbors_dev", "ahip_nve_dev",
 ]
 
@@ -71,6 +72,10 @@ class Library:
                                    C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.ahip_compute_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double),
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ahip_compute_dev_range.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double),
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ahip_last_list_size.argtypes = [C.c_void_p]
+        L.ahip_last_list_size.restype = C.c_longlong
         L.ahip_get_edges.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
         L.ahip_debug_dump_edges.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.ahip_get_timings.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int)]
@@ -197,6 +202,14 @@ class Model:
         self.L.check(self.L.lib.ahip_compute_dev(self.h, nlocal, nghost, x_ptr, mtype_ptr, _p(cm, C.c_double), f_ptr,
                                                   eatom_ptr or None, engvir_ptr, stream or None))
 
+    def compute_dev_range(self, c0: int, c1: int, nlocal: int, nghost: int, x_ptr: int, mtype_ptr: int, f_ptr: int, eatom_ptr: int,
+                          engvir_ptr: int, cutoff_matrix_model: Optional[np.ndarray] = None, stream: int = 0) -> None:
+        cm = None
+        if cutoff_matrix_model is not None:
+            cm = np.ascontiguousarray(cutoff_matrix_model, dtype=np.float64)
+        self.L.check(self.L.lib.ahip_compute_dev_range(self.h, c0, c1, nlocal, nghost, x_ptr, mtype_ptr, _p(cm, C.c_double), f_ptr,
+                                                        eatom_ptr or None, engvir_ptr, stream or None))
+
     def nve_dev(self, mode: int, n: int, x_ptr: int, v_ptr: int, f_ptr: int, mtype_ptr: int, mass_by_mtype,
                 dt: float, ftm2v: float, stream: int = 0) -> None:
         mass = np.ascontiguousarray(mass_by_mtype, dtype=np.float64)
@@ -204,6 +217,14 @@ class Model:
                                               dt, ftm2v, stream or None))
 
     # ---- introspection -----------------------------------------------------------------------
+    def nedges(self) -> int:
+        n = C.c_longlong(0)
+        self.L.check(self.L.lib.ahip_get_edges(self.h, C.byref(n), None, None))
+        return int(n.value)
+
+    def nneigh(self) -> int:
+        return int(self.L.lib.ahip_last_list_size(self.h))
+
     def get_edges(self):
         n = C.c_longlong(0)
         self.L.check(self.L.lib.ahip_get_edges(self.h, C.byref(n), None, None))

@@ -457,6 +457,28 @@ int ahip_compute_dev(ahip_model *m, int nlocal, int nghost, const double *x_dev,
   });
 }
 
+int ahip_compute_dev_range(ahip_model *m, int centre_begin, int centre_end, int nlocal, int nghost, const double *x_dev,
+                           const int *mtype_dev, const double *cutoff_matrix_model, double *f_dev, double *eatom_dev,
+                           double *eng_vir_dev, void *stream) {
+  return guarded([&] {
+    require_model(m);
+    if (!m->have_list) throw StateError("ahip_compute_dev_range called before a neighbor list was installed");
+    if (centre_begin < 0 || centre_end < centre_begin || centre_end > m->inum)
+      throw ArgError("ahip_compute_dev_range: need 0 <= centre_begin <= centre_end <= inum");
+    // narrow the installed CSR list to the centre range (offsets are absolute into the neighbour array), evaluate, restore
+    const int inum = m->inum;
+    const int *il = m->d_ilist, *off = m->d_nloff;
+    m->d_ilist = il + centre_begin; m->d_nloff = off + centre_begin; m->inum = centre_end - centre_begin;
+    const int rc = ahip_compute_dev(m, nlocal, nghost, x_dev, mtype_dev, cutoff_matrix_model, f_dev, eatom_dev, eng_vir_dev, stream);
+    const std::string err = g_err;
+    m->d_ilist = il; m->d_nloff = off; m->inum = inum;
+    if (rc != AHIP_OK) { if (rc == AHIP_ERR_ARG) throw ArgError(err); if (rc == AHIP_ERR_STATE) throw StateError(err);
+                         if (rc == AHIP_ERR_UNSUPPORTED) throw UnsupportedError(err); throw HipError(err); }
+  });
+}
+
+long long ahip_last_list_size(ahip_model *m) { return m ? m->nneigh : 0; }
+
 int ahip_get_edges(ahip_model *m, long long *nedges, long long *edge_index, double *rij) {
   return guarded([&] {
     require_model(m);

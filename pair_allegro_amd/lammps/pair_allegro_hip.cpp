@@ -90,6 +90,7 @@ void PairAllegroHIP::init_style()
   if (atom->tag_enable == 0) error->all(FLERR, "Pair style Allegro requires atom IDs");    // :139
   neighbor->add_request(this, NeighConst::REQ_FULL | NeighConst::REQ_GHOST);               // :146
   if (force->newton_pair == 0) error->all(FLERR, "Pair style allegro requires newton pair on");    // :149
+  last_list_build = -1;    // a new run: whatever list the library holds is stale (atoms may have been displaced between runs)
 }
 
 double PairAllegroHIP::init_one(int /*i*/, int /*j*/) { return cutoff; }    // :153-156
@@ -177,11 +178,14 @@ void PairAllegroHIP::compute(int eflag, int vflag)
   int nghost = atom->nghost;
   int ntotal = nlocal + nghost;
 
-  // hand the list over only when LAMMPS rebuilt it (replaces the per-step list walk of :488-512,:566-629)
-  if (last_list_build != neighbor->lastcall) {
+  // Hand the list over only on steps where LAMMPS (re)built it (replaces the per-step list walk of :488-512,:566-629).
+  // neighbor->ago == 0 is LAMMPS' own "the lists were built this step" (Neighbor::build resets it; every run setup
+  // rebuilds the list WITHOUT advancing the timestep, so the timestep of the last build cannot be the key);
+  // init_style() runs at every run init and drops the installed copy.
+  if (neighbor->ago == 0 || last_list_build < 0) {
     if (ahip_neigh_update(model, inum, ntotal, list->ilist, list->numneigh, list->firstneigh, NEIGHMASK) != AHIP_OK)
       error->one(FLERR, "pair_allegro: {}", ahip_last_error());
-    last_list_build = neighbor->lastcall;
+    last_list_build = 1;
   }
 
   double eng = 0.0;

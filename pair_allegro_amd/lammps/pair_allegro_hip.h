@@ -53,7 +53,7 @@ class PairAllegroHIP : public Pair {
   int debug_mode = 0;
   double **cutoff_matrix = nullptr;    // [ntypes][ntypes], LAMMPS type index
   ahip_model *model = nullptr;
-  bigint last_list_build = -1;         // neighbor->lastcall of the list currently installed in the library
+  bigint last_list_build = -1;         // < 0: the library holds no valid copy of the list (set by init_style at every run init)
 };
 
 }    // namespace LAMMPS_NS

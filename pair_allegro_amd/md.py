@@ -54,6 +54,15 @@ class HipBackend:
     def __init__(self, model, mass_by_mtype: Sequence[float]):
         self.model = model
         self.mass = np.asarray(mass_by_mtype, dtype=np.float64)
+        self.stats = None          # bench.py sets this to a dict: per-stage ms and edge counts are summed over the calls of a step
+
+    def _collect(self) -> None:
+        if self.stats is None:
+            return
+        for k, v in self.model.timings().items():
+            self.stats[k] = self.stats.get(k, 0.0) + v
+        self.stats["edges"] = self.stats.get("edges", 0) + self.model.nedges()
+        self.stats["calls"] = self.stats.get("calls", 0) + 1
 
     def build_neighbors(self, x: torch.Tensor, nlocal: int, lo, hi, rc_list: float) -> None:
         self.model.build_neighbors_dev(nlocal, x.shape[0], x.data_ptr(), lo, hi, rc_list)
@@ -62,6 +71,13 @@ class HipBackend:
         nall = x.shape[0]
         self.model.compute_dev(nlocal, nall - nlocal, x.data_ptr(), mtype.data_ptr(), f.data_ptr(),
                                eatom.data_ptr() if eatom is not None else 0, engvir.data_ptr())
+        self._collect()
+
+    def compute_range(self, c0: int, c1: int, x, mtype, f, nlocal: int, engvir: torch.Tensor) -> None:
+        """Centres ilist[c0:c1) only (ahip_compute_dev_range): lets the ghost exchange run beside the interior centres."""
+        nall = x.shape[0]
+        self.model.compute_dev_range(c0, c1, nlocal, nall - nlocal, x.data_ptr(), mtype.data_ptr(), f.data_ptr(), 0, engvir.data_ptr())
+        self._collect()
 
     def nve(self, mode: int, n: int, x, v, f, mtype, dt: float) -> None:
         self.model.nve_dev(mode, n, x.data_ptr(), v.data_ptr(), f.data_ptr(), mtype.data_ptr(), self.mass, dt, FTM2V)
@@ -83,8 +99,18 @@ class _Swap:
 class Simulation:
     def __init__(self, backend, box: Sequence[float], r_max: float, skin: float, x_global: np.ndarray,
                  mtype_global: np.ndarray, v_global: Optional[np.ndarray], device: torch.device,
-                 grid: Tuple[int, int, int] = (1, 1, 1), rank: int = 0, dist=None, dt: float = 0.001):
+                 grid: Tuple[int, int, int] = (1, 1, 1), rank: int = 0, dist=None, dt: float = 0.001, overlap: bool = True):
         self.backend = backend
+        # Overlapped schedule: local atoms are ordered interior-first at every re-neighboring; the first half of
+        # the interior centres is evaluated while ghost positions travel (forward comm), then the boundary centres, and the
+        # second half of the interior while the ghost forces travel back (reverse comm).  On a GPU the exchange runs on a
+        # second (non-blocking) stream; on CPU tensors (gloo tests) the same schedule runs in program order.
+        self.overlap = bool(overlap) and hasattr(backend, "compute_range")
+        self.comm_stream = torch.cuda.Stream(device) if (self.overlap and device.type == "cuda") else None
+        self.n_int = 0
+        self.n_half = 0
+        self._flag_host = None
+        self._flag_event = None
         self.box = np.asarray(box, dtype=np.float64)
         self.rc = float(r_max) + float(skin)
         self.skin = float(skin)
@@ -112,9 +138,11 @@ class Simulation:
         self.v = torch.tensor(v0, dtype=torch.float64, device=device)
         self.f = torch.zeros((self.nlocal, 3), dtype=torch.float64, device=device)
         self.engvir = torch.zeros(7, dtype=torch.float64, device=device)
+        self.engvir3 = torch.zeros((3, 7), dtype=torch.float64, device=device)
         self.swaps: List[_Swap] = []
         self.nrebuild = 0
         self.x_hold = None
+        self._flag_posted = False
         self.rebuild()
 
     # ---- rank helpers ---------------------------------------------------------------------------
@@ -146,6 +174,25 @@ class Simulation:
             for w in self.dist.batch_isend_irecv(ops):
                 w.wait()
         return recv
+
+    def _sendrecv_pair(self, sends, swaps, reverse: bool = False):
+        """Both directed exchanges of one dimension in ONE batch_isend_irecv (one RCCL group call instead of two).
+        sends[k] goes with swaps[k]; forward: to sendrank, from recvrank (nrecv rows); reverse: the other way (nsend rows)."""
+        out, ops = [None, None], []
+        for k, (buf, sw) in enumerate(zip(sends, swaps)):
+            to, frm, n = (sw.recvrank, sw.sendrank, sw.nsend) if reverse else (sw.sendrank, sw.recvrank, sw.nrecv)
+            if to == self.rank and frm == self.rank:
+                out[k] = buf
+                continue
+            out[k] = torch.empty((n,) + tuple(buf.shape[1:]), dtype=buf.dtype, device=buf.device)
+            if buf.shape[0] > 0:
+                ops.append(self.dist.P2POp(self.dist.isend, buf.contiguous(), to, tag=k))
+            if n > 0:
+                ops.append(self.dist.P2POp(self.dist.irecv, out[k], frm, tag=k))
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+        return out
 
     def _exchange_counts(self, n: int, sendrank: int, recvrank: int) -> int:
         if sendrank == self.rank and recvrank == self.rank:
@@ -212,8 +259,24 @@ class Simulation:
         self.x, self.mtype = x.contiguous(), mt.contiguous()
         self.nall = self.x.shape[0]
 
+    def _order_interior_first(self) -> None:
+        """Local atoms farther than r_max+skin from every brick face come first: every list neighbour of such an atom is a
+        local atom, so its edges need no ghost position and produce no ghost force."""
+        n = self.nlocal
+        lo = torch.tensor(self.lo + self.rc, dtype=torch.float64, device=self.dev)
+        hi = torch.tensor(self.hi - self.rc, dtype=torch.float64, device=self.dev)
+        x = self.x[:n]
+        interior = ((x >= lo) & (x < hi)).all(dim=1)
+        order = torch.argsort((~interior).to(torch.int8), stable=True)
+        self.x, self.v = self.x[order].contiguous(), self.v[order].contiguous()
+        self.tag, self.mtype = self.tag[order].contiguous(), self.mtype[order].contiguous()
+        self.n_int = int(interior.sum().item())
+        self.n_half = self.n_int // 2
+
     def rebuild(self) -> None:
         self._migrate()
+        if self.overlap:
+            self._order_interior_first()
         self._borders()
         self.f = torch.zeros((self.nall, 3), dtype=torch.float64, device=self.dev)
         lo = self.lo - self.rc - 1e-6
@@ -224,47 +287,115 @@ class Simulation:
 
     # ---- per-step communication -------------------------------------------------------------------
     def forward_comm(self) -> None:
-        for sw in self.swaps:
-            buf = self.x[sw.send_idx]
-            if sw.shift != 0.0:
-                buf = buf.clone(); buf[:, sw.dim] += sw.shift
-            rx = self._sendrecv(buf, sw.sendrank, sw.recvrank, sw.nrecv)
-            self.x[sw.first_recv: sw.first_recv + sw.nrecv] = rx
+        for k in range(0, len(self.swaps), 2):
+            pair = self.swaps[k: k + 2]
+            bufs = []
+            for sw in pair:
+                buf = self.x[sw.send_idx]
+                if sw.shift != 0.0:
+                    buf[:, sw.dim] += sw.shift                    # advanced indexing made a copy
+                bufs.append(buf)
+            for sw, rx in zip(pair, self._sendrecv_pair(bufs, pair)):
+                self.x[sw.first_recv: sw.first_recv + sw.nrecv] = rx
 
     def reverse_comm(self) -> None:
-        for sw in reversed(self.swaps):
-            buf = self.f[sw.first_recv: sw.first_recv + sw.nrecv]
-            rx = self._sendrecv(buf, sw.recvrank, sw.sendrank, sw.nsend)
-            if sw.recvrank == self.rank and sw.sendrank == self.rank:
-                rx = rx.clone()                                  # self-exchange returns a view of f
-            self.f.index_add_(0, sw.send_idx, rx)
+        for k in range(len(self.swaps) - 2, -1, -2):
+            pair = self.swaps[k: k + 2]
+            # both directions of a dimension read ghost rows received in that dimension and add into rows known before it
+            bufs = [self.f[sw.first_recv: sw.first_recv + sw.nrecv] for sw in pair]
+            got = self._sendrecv_pair(bufs, pair, reverse=True)
+            for sw, rx in zip(pair, got):
+                if sw.recvrank == self.rank and sw.sendrank == self.rank:
+                    rx = rx.clone()                              # self-exchange returns a view of f
+                self.f.index_add_(0, sw.send_idx, rx)
 
-    def needs_rebuild(self) -> bool:
-        d = self.x[: self.nlocal] - self.x_hold
-        m = (d * d).sum(dim=1).max() if self.nlocal else torch.zeros((), dtype=torch.float64, device=self.dev)
-        flag = (m > (0.5 * self.skin) ** 2).to(torch.int32).reshape(1)
+    def _post_rebuild_flag(self) -> None:
+        """max displacement since the last build > skin/2 (any rank)?  Evaluated on the device, all-reduced there, copied to
+        pinned host memory asynchronously and READ ONE STEP LATER, so no step waits on a device->host round trip; the
+        criterion therefore includes the motion of the step in between (2 dt max|v|)."""
+        if self.nlocal:
+            d = self.x[: self.nlocal] - self.x_hold
+            v = self.v[: self.nlocal]
+            # displacement now + twice the fastest atom's next step (the flag is acted on one step late)
+            reach = (d * d).sum(dim=1).max().sqrt() + 2.0 * self.dt * (v * v).sum(dim=1).max().sqrt()
+        else:
+            reach = torch.zeros((), dtype=torch.float64, device=self.dev)
+        flag = (reach > 0.5 * self.skin).to(torch.int32).reshape(1)
         if self.nranks > 1:
             self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
-        return bool(flag.item())
+        if self.dev.type == "cuda":
+            if self._flag_host is None:
+                self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                self._flag_event = torch.cuda.Event()
+            self._flag_host.copy_(flag, non_blocking=True)
+            self._flag_event.record()
+        else:
+            self._flag_host = flag.clone()
+
+    def needs_rebuild(self) -> bool:
+        """The flag posted during the previous step (False on the first step after a build)."""
+        if self._flag_host is None or not self._flag_posted:
+            return False
+        if self._flag_event is not None:
+            self._flag_event.synchronize()           # recorded a whole force evaluation ago: already complete
+        return bool(int(self._flag_host[0]))
 
     # ---- force evaluation and time step -----------------------------------------------------------
-    def compute_forces(self) -> None:
+    def compute_forces(self, comm_first: bool = True) -> None:
+        """forward comm -> forces of all centres -> reverse comm.  Overlapped schedule: see __init__."""
         self.f.zero_()
-        self.backend.compute(self.x, self.mtype, self.f, self.nlocal, self.engvir)
-        self.reverse_comm()
+        if not self.overlap:
+            if comm_first:
+                self.forward_comm()
+            self.backend.compute(self.x, self.mtype, self.f, self.nlocal, self.engvir)
+            self.reverse_comm()
+            return
+        cs = self.comm_stream
+        n0, n1, nl = self.n_half, self.n_int, self.nlocal
+        ev = self.engvir3
+        ev.zero_()
+        if cs is not None:
+            cur = torch.cuda.current_stream(self.dev)
+            e0 = torch.cuda.Event(); e0.record(cur)
+            with torch.cuda.stream(cs):
+                cs.wait_event(e0)                    # positions integrated, forces zeroed
+                if comm_first:
+                    self.forward_comm()
+                e1 = torch.cuda.Event(); e1.record(cs)
+            self.backend.compute_range(0, n0, self.x, self.mtype, self.f, nl, ev[0])          # interior, first half
+            cur.wait_event(e1)
+            self.backend.compute_range(n1, nl, self.x, self.mtype, self.f, nl, ev[1])         # boundary: needs ghost positions
+            e2 = torch.cuda.Event(); e2.record(cur)
+            with torch.cuda.stream(cs):
+                cs.wait_event(e2)
+                self.reverse_comm()                  # ghost forces exist once the boundary centres are done
+                e3 = torch.cuda.Event(); e3.record(cs)
+            self.backend.compute_range(n0, n1, self.x, self.mtype, self.f, nl, ev[2])         # interior, second half
+            cur.wait_event(e3)
+        else:
+            if comm_first:
+                self.forward_comm()
+            self.backend.compute_range(0, n0, self.x, self.mtype, self.f, nl, ev[0])
+            self.backend.compute_range(n1, nl, self.x, self.mtype, self.f, nl, ev[1])
+            self.reverse_comm()
+            self.backend.compute_range(n0, n1, self.x, self.mtype, self.f, nl, ev[2])
+        torch.sum(ev, dim=0, out=self.engvir)
 
     def setup(self) -> None:
-        self.forward_comm()
         self.compute_forces()
+        self._flag_posted = False
 
     def step(self) -> None:
         n = self.nlocal
         self.backend.nve(0, n, self.x, self.v, self.f, self.mtype, self.dt)         # v += dt/2 f/m ; x += dt v
         if self.needs_rebuild():
             self.rebuild()
+            self._flag_posted = False
+            self.compute_forces(comm_first=False)    # borders() just placed fresh ghost positions
         else:
-            self.forward_comm()
-        self.compute_forces()
+            self._post_rebuild_flag()
+            self._flag_posted = True
+            self.compute_forces()
         self.backend.nve(1, self.nlocal, self.x, self.v, self.f, self.mtype, self.dt)   # v += dt/2 f/m
 
     # ---- observables (reduced over ranks) ----------------------------------------------------------

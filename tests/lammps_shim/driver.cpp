@@ -4,6 +4,7 @@
 #include "pair_allegro_hip.h"
 #include "compute_allegro_hip.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -84,7 +85,28 @@ int main(int argc, char **argv) {
     if (neighbor.requested != (NeighConst::REQ_FULL | NeighConst::REQ_GHOST)) { fprintf(stderr, "bad neighbor request\n"); return 4; }
     const double cut = pair.init_one(1, 1);
     neighbor.lastcall = 1;
+    if (std::getenv("DRIVER_REBUILD_SAME_STEP")) {
+      // `run 0` -> atoms displaced, list rebuilt with a different row order -> `run 0`, all at ONE timestep.
+      // First "run" on a scrambled copy (positions shifted, rows reversed); the second run must not reuse that copy.
+      std::vector<double> xs(x); std::vector<int> fl(flat);
+      size_t o2 = 0;
+      for (int i = 0; i < nall; i++) { std::reverse(fl.begin() + o2, fl.begin() + o2 + numneigh[i]); o2 += numneigh[i]; }
+      for (int i = 0; i < nall; i++) { xs[3 * (size_t)i] += (i < nlocal) ? 0.05 * ((i * 7) % 5 - 2) : 0.0; }
+      std::vector<double *> xsp(nall); std::vector<int *> fsp(nall);
+      o2 = 0;
+      for (int i = 0; i < nall; i++) { xsp[i] = &xs[3 * (size_t)i]; fsp[i] = fl.data() + o2; o2 += numneigh[i]; }
+      std::vector<int> nn2(numneigh);
+      for (int i = 0; i < nlocal; i++) nn2[i] = numneigh[i] / 2;   // ... and with other atoms in range (half of each row)
+      atom.x = xsp.data(); list.firstneigh = fsp.data(); list.numneigh = nn2.data();
+      neighbor.ago = 0;
+      pair.compute(3, 2);
+      std::fill(fr.begin(), fr.end(), 0.0);
+      atom.x = xp.data(); list.firstneigh = first.data(); list.numneigh = numneigh.data();   // second run setup: same timestep, fresh list
+      pair.init_style();
+      neighbor.ago = 0;
+    }
     pair.compute(3, 2);                     // eflag global+atom, vflag global
+    neighbor.ago = 1;
     pair.compute(3, 2);                     // second step on the same list: forces must be ADDED again
     FILE *o = fopen(argv[2], "wb");
     fwrite(&cut, sizeof(double), 1, o);

@@ -56,7 +56,7 @@ class Force { public: int newton_pair = 1; Pair *pair = nullptr; };
 class Update { public: bigint ntimestep = 0; };
 class NeighList { public: int inum = 0, gnum = 0; int *ilist = nullptr, *numneigh = nullptr; int **firstneigh = nullptr; };
 namespace NeighConst { enum { REQ_FULL = 1, REQ_GHOST = 2 }; }
-class Neighbor { public: bigint lastcall = 0; int requested = 0; void add_request(Pair *, int flags) { requested = flags; } };
+class Neighbor { public: bigint lastcall = 0; int ago = 0; int requested = 0; void add_request(Pair *, int flags) { requested = flags; } };
 
 class LAMMPS {
  public:

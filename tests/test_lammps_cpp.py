@@ -69,6 +69,30 @@ def test_cpp_pair_style_matches_oracle(driver, tmp_path, model_dir):
     np.testing.assert_allclose(c_e, ref["eatom"][rs.tag[: rs.nlocal] - 1], atol=1e-10)             # allegro/atom atomic_energy 1 0
 
 
+def test_cpp_pair_style_list_rebuilt_twice_at_one_timestep(driver, tmp_path, model_dir):
+    """`run 0` -> atoms displaced + list rebuilt in another order -> `run 0` at the SAME timestep: the second run must use
+    the fresh list (hand-over keyed on neighbor->ago == 0 and reset by init_style, not on the timestep of the last build).
+    The reference walks the list every step (pair_nequip_allegro.cpp:488-512) and has no such state."""
+    cfg = model_file.model_S(model_dtype="float64", num_scalar_features=16, num_tensor_features=8, mlp_width=16, readout_width=8)
+    w = model_file.init_weights(cfg)
+    mpath = os.path.join(model_dir, "cpp_si_ago.nequip.pth")
+    allegro_torch.export_nequip_pth(mpath, cfg, w)
+    cell, pos, types = lmp_like.diamond_si(2)
+    rs = lmp_like.build_rank_system(cell, pos, types, 6.0)
+    sysf, outf = str(tmp_path / "sys.bin"), str(tmp_path / "out.bin")
+    _write_system(sysf, rs, 1)
+    r = subprocess.run([driver, sysf, outf, mpath, "Si"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       env=dict(os.environ, DRIVER_REBUILD_SAME_STEP="1"))
+    assert r.returncode == 0, r.stdout.decode()
+    out = np.fromfile(outf, dtype=np.float64)
+    f = out[8:8 + 3 * rs.nall].reshape(-1, 3)
+    ref = util.oracle_run(cfg, w, cell, pos, types, ["Si"])
+    forces = np.zeros_like(ref["forces"])
+    np.add.at(forces, rs.tag - 1, f)
+    np.testing.assert_allclose(forces, 2.0 * ref["forces"], atol=1e-9)
+    np.testing.assert_allclose(out[1], ref["pe"], rtol=1e-10)
+
+
 def test_cpp_pair_style_deck_errors(driver, tmp_path, model_dir):
     cfg = model_file.model_S(model_dtype="float64", num_scalar_features=16, num_tensor_features=8, mlp_width=16, readout_width=8)
     mpath = os.path.join(model_dir, "cpp_si.nequip.pth")

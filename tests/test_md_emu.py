@@ -75,3 +75,33 @@ def test_gloo_rebuild_and_migration(emu_lib, model_dir, tmp_path):
     assert int(z["nreb"]) >= 3 and int(z["nreb1"]) >= 3
     np.testing.assert_allclose(z["x2"], z["x1"], atol=1e-8)
     np.testing.assert_allclose(z["e2"], z["e1"], rtol=1e-9)
+
+
+def test_interior_boundary_split_equals_one_call(emu_lib, model_dir):
+    """The overlapped schedule (interior-first ordering, three ahip_compute_dev_range calls per evaluation, exchange between
+    them) gives the forces, energy and virial of the single ahip_compute_dev call on the unordered atoms -- equal up to
+    the order of the float64 sums -- and the same trajectory."""
+    cfg = _small_cfg()
+    w = model_file.init_weights(cfg)
+    path = os.path.join(model_dir, "md_small_ov.ahip")
+    model_file.save_ahip(path, cfg, w)
+    cell, pos, _ = lmp_like.diamond_si(4)                 # 21.7 A box: a genuine interior (atoms > 6 A from every face)
+    vel = md.maxwell_boltzmann(len(pos), np.full(len(pos), 28.0855), 300.0, 7)
+    out = {}
+    for ov in (True, False):
+        model = capi.Model(path, 0, emu_lib)
+        sim = md.Simulation(md.HipBackend(model, [28.0855]), np.diag(cell), cfg["r_max"], 1.0, pos, np.zeros(len(pos), np.int32),
+                            vel, torch.device("cpu"), dt=0.001, overlap=ov)
+        sim.setup()
+        f0 = sim.gather_forces()
+        t0 = sim.thermo([28.0855])
+        for _ in range(3):
+            sim.step()
+        out[ov] = (f0, t0, sim.gather_forces(), sim.thermo([28.0855]), sim.n_int, sim.nlocal)
+        model.close()
+    assert 0 < out[True][4] < out[True][5]                # both classes are populated
+    np.testing.assert_allclose(out[True][0], out[False][0], atol=1e-12)
+    np.testing.assert_allclose(out[True][1]["pe"], out[False][1]["pe"], rtol=1e-13)
+    np.testing.assert_allclose(out[True][1]["virial"], out[False][1]["virial"], atol=1e-10)
+    np.testing.assert_allclose(out[True][2], out[False][2], atol=1e-10)
+    np.testing.assert_allclose(out[True][3]["pe"], out[False][3]["pe"], rtol=1e-12)

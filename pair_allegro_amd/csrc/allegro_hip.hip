@@ -128,6 +128,7 @@ void ahip_model_free(ahip_model *m) {
   fused_free(*m);
   neigh_free(*m);
   edges_free(*m);
+  m->prim.release();
   free_weights(m->wf);
   free_weights(m->wd);
   if (m->cg_dev) (void)hipFree(m->cg_dev);
@@ -472,8 +473,10 @@ int ahip_compute_dev_range(ahip_model *m, int centre_begin, int centre_end, int 
     const int rc = ahip_compute_dev(m, nlocal, nghost, x_dev, mtype_dev, cutoff_matrix_model, f_dev, eatom_dev, eng_vir_dev, stream);
     const std::string err = g_err;
     m->d_ilist = il; m->d_nloff = off; m->inum = inum;
-    if (rc != AHIP_OK) { if (rc == AHIP_ERR_ARG) throw ArgError(err); if (rc == AHIP_ERR_STATE) throw StateError(err);
-                         if (rc == AHIP_ERR_UNSUPPORTED) throw UnsupportedError(err); throw HipError(err); }
+    if (rc == AHIP_ERR_ARG) throw ArgError(err);
+    if (rc == AHIP_ERR_STATE) throw StateError(err);
+    if (rc == AHIP_ERR_UNSUPPORTED) throw UnsupportedError(err);
+    if (rc != AHIP_OK) throw HipError(err);
   });
 }
 

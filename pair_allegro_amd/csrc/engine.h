@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "model_io.h"
+#include "prims.h"
 
 namespace ahip {
 
@@ -127,6 +128,9 @@ struct Model {
   std::vector<TimingSlot> slots;
   std::string timing_names;
   std::vector<double> timing_ms;
+
+  // scratch of the device-wide primitives (scan, column sums): per model, see prims.h
+  PrimScratch prim;
 
   // fused path private state
   void *fused_state = nullptr;

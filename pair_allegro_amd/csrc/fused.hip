@@ -1277,7 +1277,7 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
     StageTimer tm(m, "tile_pack", s);
     const unsigned B = 64;
     hipLaunchKernelGGL(k_pack_tiles<false>, dim3((nseg + B - 1) / B), dim3(B), 0, s, inum, m.b_eoff.as<int>(), nseg, st.seg_count.as<int>(), (const int *)nullptr, (int *)nullptr, tile_slots, maxa);
-    AHIP_CHECK(prim_exclusive_scan_i32(st.seg_count.as<int>(), st.seg_base.as<int>(), nseg, s));
+    AHIP_CHECK(prim_exclusive_scan_i32(m.prim, st.seg_count.as<int>(), st.seg_base.as<int>(), nseg, s));
     hipLaunchKernelGGL(k_pack_tiles<true>, dim3((nseg + B - 1) / B), dim3(B), 0, s, inum, m.b_eoff.as<int>(), nseg, (int *)nullptr, st.seg_base.as<int>(), st.tile_a0.as<int>(), tile_slots, maxa);
     hipLaunchKernelGGL(k_pack_finish, dim3(1), dim3(1), 0, s, inum, nseg, st.seg_base.as<int>(), st.tile_a0.as<int>(), st.ntiles.as<int>());
     const int tcap = inum + nseg + 1;              // upper bound on tiles + 1
@@ -1292,7 +1292,6 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
   }
   FusedArgs A = st.args;
   A.wg_scratch = nw * A.wave_scratch;
-  if (std::getenv("AHIP_FUSED_EXP_ALIAS")) A.wg_scratch = 0;      // timing experiment only: all workgroups share one scratch block (wrong results)
   A.eoff = m.b_eoff.as<int>(); A.e_ii = m.b_eii.as<int>(); A.e_j = m.b_ej.as<int>();
   A.e_tt = m.b_ett.as<unsigned char>(); A.centre = st.centre.as<int2>(); A.rvec = m.b_rvec.as<float>(); A.rcut = m.rcut_model_dev;
   A.tile_a0 = st.tile_a0.as<int>(); A.tile_e0 = st.tile_e0.as<int>(); A.ntiles = st.ntiles.as<int>();
@@ -1322,7 +1321,7 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
 #undef AHIP_LAUNCH
   }
   AHIP_CHECK(hipGetLastError());
-  AHIP_CHECK(prim_sum_columns_f64(st.partial.as<double>(), grid, 7, a.engvir, s));
+  AHIP_CHECK(prim_sum_columns_f64(m.prim, st.partial.as<double>(), grid, 7, a.engvir, s));
   if (st.prof_on || st.clk_on) {
     std::vector<long long> hp(PH_N + 4 * (size_t)grid);
     AHIP_CHECK(hipMemcpyAsync(hp.data(), st.prof.p, hp.size() * sizeof(long long), hipMemcpyDeviceToHost, s));

@@ -52,7 +52,7 @@ template <typename T> static void build_edges(Model &m, const ComputeArgs &a) {
   m.b_eoff.reserve((size_t)(inum + 2) * sizeof(int));
   launch(k_count_edges, inum, a.stream, inum, m.d_ilist, m.d_nloff, m.d_nlj, a.x, a.ftype, a.cutsq, a.nft,
          m.b_cnt.as<int>());
-  AHIP_CHECK(prim_exclusive_scan_i32(m.b_cnt.as<int>(), m.b_eoff.as<int>(), inum, a.stream));
+  AHIP_CHECK(prim_exclusive_scan_i32(m.prim, m.b_cnt.as<int>(), m.b_eoff.as<int>(), inum, a.stream));
   m.b_misc.reserve(64);
   AHIP_CHECK(prim_max_i32(m.b_cnt.as<int>(), inum, m.b_misc.as<int>(), a.stream));
   int tot = 0, mx = 0;
@@ -322,7 +322,7 @@ template <typename T> static void generic_run(Model &m, const ComputeArgs &a) {
       generic_chunk<T>(m, a, A, cuts[q], cuts[q + 1] - cuts[q], e0, Ec);
     }
   }
-  AHIP_CHECK(prim_sum_columns_f64(m.b_partial.as<double>(), inum, 7, a.engvir, a.stream));
+  AHIP_CHECK(prim_sum_columns_f64(m.prim, m.b_partial.as<double>(), inum, 7, a.engvir, a.stream));
   AHIP_CHECK(hipGetLastError());
 }
 

@@ -54,37 +54,43 @@ static bool zip_find_member(const std::vector<unsigned char> &z, const std::stri
   if (cd_off == 0xFFFFFFFFu || cd_entries == 0xFFFF) {          // ZIP64
     if (eocd < 20 || rd32(&z[eocd - 20]) != 0x07064b50u) { err = "broken zip64 locator"; return false; }
     uint64_t e64 = rd64(&z[eocd - 20 + 8]);
-    if (e64 + 56 > n || rd32(&z[e64]) != 0x06064b50u) { err = "broken zip64 record"; return false; }
+    if (e64 > n || n - e64 < 56 || rd32(&z[e64]) != 0x06064b50u) { err = "broken zip64 record"; return false; }
     cd_entries = rd64(&z[e64 + 32]);
     cd_off = rd64(&z[e64 + 48]);
   }
+  if (cd_off > n) { err = "broken zip central directory offset"; return false; }
   size_t p = (size_t)cd_off;
   for (uint64_t k = 0; k < cd_entries; ++k) {
-    if (p + 46 > n || rd32(&z[p]) != 0x02014b50u) { err = "broken zip central directory"; return false; }
+    if (n - p < 46 || rd32(&z[p]) != 0x02014b50u) { err = "broken zip central directory"; return false; }
     uint16_t method = rd16(&z[p + 10]);
     uint64_t csize = rd32(&z[p + 20]), usize = rd32(&z[p + 24]);
     uint16_t nlen = rd16(&z[p + 28]), xlen = rd16(&z[p + 30]), clen = rd16(&z[p + 32]);
     uint64_t lho = rd32(&z[p + 42]);
+    if (n - p - 46 < (size_t)nlen + xlen + clen) { err = "zip central directory entry runs past end of file"; return false; }
     std::string name((const char *)&z[p + 46], nlen);
     // zip64 extra field
     size_t xp = p + 46 + nlen, xe = xp + xlen;
     while (xp + 4 <= xe) {
       uint16_t id = rd16(&z[xp]), sz = rd16(&z[xp + 2]);
+      if (xp + 4 + sz > xe) { err = "broken zip extra field"; return false; }
       if (id == 0x0001) {
         size_t q = xp + 4;
-        if (usize == 0xFFFFFFFFu) { usize = rd64(&z[q]); q += 8; }
-        if (csize == 0xFFFFFFFFu) { csize = rd64(&z[q]); q += 8; }
-        if (lho == 0xFFFFFFFFu) { lho = rd64(&z[q]); q += 8; }
+        const size_t qe = xp + 4 + sz;
+        auto take = [&](uint64_t &v) { if (q + 8 > qe) return false; v = rd64(&z[q]); q += 8; return true; };
+        if ((usize == 0xFFFFFFFFu && !take(usize)) || (csize == 0xFFFFFFFFu && !take(csize)) || (lho == 0xFFFFFFFFu && !take(lho))) {
+          err = "broken zip64 extra field"; return false;
+        }
       }
       xp += 4 + sz;
     }
     if (name.size() >= suffix.size() && name.compare(name.size() - suffix.size(), suffix.size(), suffix) == 0) {
       if (method != 0) { err = "zip member " + name + " is compressed; expected STORED"; return false; }
-      if (lho + 30 > n || rd32(&z[lho]) != 0x04034b50u) { err = "broken zip local header"; return false; }
+      if (lho > n || n - lho < 30 || rd32(&z[lho]) != 0x04034b50u) { err = "broken zip local header"; return false; }
       uint16_t lnlen = rd16(&z[lho + 26]), lxlen = rd16(&z[lho + 28]);
+      if (n - lho - 30 < (size_t)lnlen + lxlen) { err = "zip local header runs past end of file"; return false; }
       off = (size_t)lho + 30 + lnlen + lxlen;
+      if (usize > n - off) { err = "zip member runs past end of file"; return false; }
       len = (size_t)usize;
-      if (off + len > n) { err = "zip member runs past end of file"; return false; }
       return true;
     }
     p += 46 + nlen + xlen + clen;
@@ -113,7 +119,12 @@ HostModel parse_blob(const unsigned char *p, size_t n, const std::string &origin
     if (key == "tensor") {
       Dir d; int nd = 0;
       ls >> d.name >> nd;
-      for (int k = 0; k < nd; ++k) { int s; ls >> s; d.shape.push_back(s); }
+      if (nd < 0 || nd > 8) throw std::runtime_error(origin + ": bad tensor rank: " + line);
+      for (int k = 0; k < nd; ++k) {
+        int s = -1; ls >> s;
+        if (!ls || s < 0) throw std::runtime_error(origin + ": bad tensor dimension: " + line);
+        d.shape.push_back(s);
+      }
       ls >> d.off;
       if (!ls) throw std::runtime_error(origin + ": bad tensor line: " + line);
       dir.push_back(d);
@@ -155,8 +166,13 @@ HostModel parse_blob(const unsigned char *p, size_t n, const std::string &origin
   for (const Dir &d : dir) {
     HostTensor t;
     t.shape = d.shape;
-    size_t cnt = (size_t)t.numel();
-    if (header_bytes + d.off + cnt * 8 > n) throw std::runtime_error(origin + ": tensor " + d.name + " out of bounds");
+    const size_t avail = n - header_bytes;                     // header_bytes <= n checked above
+    size_t cnt = 1;
+    for (int s : t.shape) {                                    // overflow-safe element count
+      if (s != 0 && cnt > (avail / 8) / (size_t)s + 1) throw std::runtime_error(origin + ": tensor " + d.name + " out of bounds");
+      cnt *= (size_t)s;
+    }
+    if (d.off > avail || cnt > (avail - d.off) / 8) throw std::runtime_error(origin + ": tensor " + d.name + " out of bounds");
     t.data.resize(cnt);
     std::memcpy(t.data.data(), p + header_bytes + d.off, cnt * 8);   // little-endian f64 host assumed
     m.tensors[d.name] = std::move(t);

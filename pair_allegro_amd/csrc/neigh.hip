@@ -124,7 +124,7 @@ void neigh_build(Model &m, int nlocal, int nall, const double *x_dev, const doub
   AHIP_CHECK(hipMemsetAsync(st.bin_cnt.p, 0, (size_t)(nbins + 1) * sizeof(int), s));
   AHIP_CHECK(hipMemsetAsync(st.bin_fill.p, 0, (size_t)(nbins + 1) * sizeof(int), s));
   if (nall > 0) hipLaunchKernelGGL(k_bin_count, grid(nall), dim3(B), 0, s, nall, x_dev, g, st.bin_of.as<int>(), st.bin_cnt.as<int>());
-  AHIP_CHECK(prim_exclusive_scan_i32(st.bin_cnt.as<int>(), st.bin_start.as<int>(), (int)nbins, s));
+  AHIP_CHECK(prim_exclusive_scan_i32(m.prim, st.bin_cnt.as<int>(), st.bin_start.as<int>(), (int)nbins, s));
   if (nall > 0) hipLaunchKernelGGL(k_bin_fill, grid(nall), dim3(B), 0, s, nall, st.bin_of.as<int>(), st.bin_start.as<int>(), st.bin_fill.as<int>(), st.sorted.as<int>());
   hipLaunchKernelGGL(k_bin_sort, grid(nbins), dim3(B), 0, s, (int)nbins, st.bin_start.as<int>(), st.sorted.as<int>());
   const double rcsq = rc_list * rc_list;
@@ -132,7 +132,7 @@ void neigh_build(Model &m, int nlocal, int nall, const double *x_dev, const doub
     hipLaunchKernelGGL(k_neigh_pass<false>, grid(nlocal), dim3(B), 0, s, nlocal, x_dev, g, st.bin_start.as<int>(), st.sorted.as<int>(), rcsq, st.cnt.as<int>(), (const int *)nullptr, (int *)nullptr);
     hipLaunchKernelGGL(k_iota, grid(nlocal), dim3(B), 0, s, nlocal, st.ilist.as<int>());
   }
-  AHIP_CHECK(prim_exclusive_scan_i32(st.cnt.as<int>(), st.off.as<int>(), nlocal, s));
+  AHIP_CHECK(prim_exclusive_scan_i32(m.prim, st.cnt.as<int>(), st.off.as<int>(), nlocal, s));
   int tot = 0;
   AHIP_CHECK(hipMemcpyAsync(&tot, st.off.as<int>() + nlocal, sizeof(int), hipMemcpyDeviceToHost, s));
   AHIP_CHECK(hipStreamSynchronize(s));

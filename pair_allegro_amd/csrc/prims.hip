@@ -84,23 +84,20 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_down(const int *in, int n, 
   }
 }
 
-static int *g_tile_buf = nullptr;
-static size_t g_tile_cap = 0;
-static int g_tile_dev = -1;
-
-hipError_t prim_exclusive_scan_i32(const int *in, int *out, int n, hipStream_t s) {
+hipError_t prim_exclusive_scan_i32(PrimScratch &ps, const int *in, int *out, int n, hipStream_t s) {
   if (n <= 0) return hipMemsetAsync(out, 0, sizeof(int), s);
   int ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return e;
-  if ((size_t)ntiles > g_tile_cap || dev != g_tile_dev) {
-    if (g_tile_buf) (void)hipFree(g_tile_buf);
-    g_tile_cap = (size_t)ntiles * 2 + 1024;
-    g_tile_dev = dev;
-    e = hipMalloc((void **)&g_tile_buf, g_tile_cap * sizeof(int));
-    if (e != hipSuccess) { g_tile_buf = nullptr; g_tile_cap = 0; return e; }
+  if ((size_t)ntiles > ps.tile_cap) {
+    // growing: earlier scans of this model on this stream may still read the old buffer
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return e;
+    if (ps.tile) (void)hipFree(ps.tile);
+    ps.tile = nullptr;
+    ps.tile_cap = (size_t)ntiles * 2 + 1024;
+    e = hipMalloc((void **)&ps.tile, ps.tile_cap * sizeof(int));
+    if (e != hipSuccess) { ps.tile = nullptr; ps.tile_cap = 0; return e; }
   }
+  int *g_tile_buf = ps.tile;
   hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(SCAN_BLOCK), 0, s, in, n, g_tile_buf);
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_BLOCK), 0, s, g_tile_buf, ntiles, out + n);
   hipLaunchKernelGGL(k_scan_down, dim3(ntiles), dim3(SCAN_BLOCK), 0, s, in, n, g_tile_buf, out);
@@ -140,19 +137,12 @@ __global__ void __launch_bounds__(64) k_colsum_stage2(const double *part, int nb
   }
 }
 
-static double *g_part = nullptr;
-static int g_part_dev = -1;
-
-hipError_t prim_sum_columns_f64(const double *in, long long nrow, int ncol, double *out, hipStream_t s) {
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return e;
-  if (!g_part || dev != g_part_dev) {
-    if (g_part) (void)hipFree(g_part);
-    e = hipMalloc((void **)&g_part, RED_BLOCKS * 8 * sizeof(double));
-    if (e != hipSuccess) { g_part = nullptr; return e; }
-    g_part_dev = dev;
+hipError_t prim_sum_columns_f64(PrimScratch &ps, const double *in, long long nrow, int ncol, double *out, hipStream_t s) {
+  if (!ps.part) {
+    hipError_t e = hipMalloc((void **)&ps.part, RED_BLOCKS * 8 * sizeof(double));
+    if (e != hipSuccess) { ps.part = nullptr; return e; }
   }
+  double *g_part = ps.part;
   int nb = (int)((nrow + 255) / 256);
   if (nb > RED_BLOCKS) nb = RED_BLOCKS;
   if (nb < 1) nb = 1;

@@ -27,7 +27,7 @@ template <int peratom> ComputeAllegroHIP<peratom>::ComputeAllegroHIP(LAMMPS *lmp
   quantity = arg[3];
   newton = 0;
   nperatom = 0;
-  nmax = -12;
+  nmax = 0;
   if (peratom) {    // :55-64
     peratom_flag = 1;
     nperatom = std::atoi(arg[4]);

@@ -8,13 +8,13 @@
 dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 namespace ahip {
-hipError_t prim_exclusive_scan_i32(const int *in, int *out, int n, hipStream_t) {
+hipError_t prim_exclusive_scan_i32(PrimScratch &, const int *in, int *out, int n, hipStream_t) {
   long long s = 0;
   for (int i = 0; i < n; ++i) { int v = in[i]; out[i] = (int)s; s += v; }
   out[n > 0 ? n : 0] = (int)s;
   return hipSuccess;
 }
-hipError_t prim_sum_columns_f64(const double *in, long long nrow, int ncol, double *out, hipStream_t) {
+hipError_t prim_sum_columns_f64(PrimScratch &, const double *in, long long nrow, int ncol, double *out, hipStream_t) {
   for (int c = 0; c < ncol; ++c) {
     double s = 0;
     for (long long r = 0; r < nrow; ++r) s += in[r * ncol + c];

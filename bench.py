@@ -162,7 +162,7 @@ def main():
     grid = md.choose_grid(world)
     backend = md.HipBackend(model, wl["masses"])
     sim = md.Simulation(backend, box, cfg["r_max"], 1.0, pos, wl["mtype"], vel, device,
-                        grid=grid, rank=rank, dist=dist, dt=0.001, overlap=not args.no_overlap)
+                        grid=grid, rank=rank, dist=dist, dt=0.001, overlap=False if args.no_overlap else None)
     sim.setup()
     for _ in range(args.warmup):
         sim.step()

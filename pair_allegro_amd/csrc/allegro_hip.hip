@@ -126,6 +126,7 @@ void ahip_model_free(ahip_model *m) {
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
   fused_free(*m);
+  fusedlx_free(*m);
   neigh_free(*m);
   edges_free(*m);
   m->prim.release();
@@ -310,7 +311,12 @@ static void run_model(ahip_model *m, const ComputeArgs &a) {
   std::string why;
   bool fused_ok = false;
   if (m->opt_path != "generic") {
-    fused_ok = fused_model_supported(*m, &why) && fused_run(*m, a, &why);
+    if (fused_model_supported(*m, &why)) fused_ok = fused_run(*m, a, &why);
+    else {
+      std::string why2;
+      if (fusedlx_model_supported(*m, &why2)) { fused_ok = fusedlx_run(*m, a, &why2); why = why2; }
+      else why += "; " + why2;
+    }
     if (!fused_ok && m->opt_path == "fused") throw UnsupportedError("fused path unavailable: " + why);
   }
   if (fused_ok) { m->last_path = "fused_f32"; return; }

@@ -132,8 +132,9 @@ struct Model {
   // scratch of the device-wide primitives (scan, column sums): per model, see prims.h
   PrimScratch prim;
 
-  // fused path private state
+  // fused path private state (fused.hip: model S shape; fused_lx.hip: l_max = 2 shapes)
   void *fused_state = nullptr;
+  void *fusedlx_state = nullptr;
 
   // neighbor builder state
   void *nb_state = nullptr;
@@ -179,6 +180,10 @@ bool fused_model_supported(const Model &m, std::string *why);
 // Returns false (and sets *why) if this particular list cannot be handled (e.g. too many edges per atom).
 bool fused_run(Model &m, const ComputeArgs &a, std::string *why);
 void fused_free(Model &m);
+// the same three for the wide shapes (l_max = 2; fused_lx.hip)
+bool fusedlx_model_supported(const Model &m, std::string *why);
+bool fusedlx_run(Model &m, const ComputeArgs &a, std::string *why);
+void fusedlx_free(Model &m);
 
 // ---- single-pass float32 edge build (edges.hip; the host-emulation build links a stub returning false) ----
 // Fills m.nedges, m.last_max_deg, b_eoff/b_eii/b_ej/b_rvec exactly like build_edges<float>; false = a list

@@ -1,0 +1,315 @@
+// Pieces shared by the fused MFMA kernels (fused.hip: model S, l_max = 1, 32 tensor features; fused_lx.hip: l_max <= 2,
+// 32 or 64 tensor features): register-image rows, the streamed register-chain linear with its epilogue functors, the
+// A-operand fragment layout of the weight stream, tile packing.  See fused.hip / DESIGN.md 4.2 for the mapping.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+namespace ahip {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+static constexpr int SEG = 512;          // atoms per sequential packing segment
+static constexpr int ROW = 256;          // floats per saved register image of one 16-feature tile (4 regs x 64 lanes)
+static constexpr int RING = 8;           // weight fragments in flight per wave
+static constexpr int TCHUNK = 4;         // tiles per claim of the dynamic tile schedule
+
+__host__ __device__ inline int feat16(int t, int r, int g) { return 16 * t + 4 * g + r; }
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// 16-byte buffer accesses: wave-uniform descriptor + scalar byte offset + per-lane byte offset
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, int voff, int soff, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+
+__device__ __forceinline__ float sigmoidf_fast(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
+__device__ __forceinline__ float silu1(float z) { return z * sigmoidf_fast(z); }
+__device__ __forceinline__ float dsilu1(float z) {
+  float s = sigmoidf_fast(z);
+  return s * (1.f + z * (1.f - s));
+}
+
+// saved register images: one row = one 16-feature tile = f32x4 per lane
+template <int NT> __device__ __forceinline__ void load_rows(__amdgpu_buffer_rsrc_t S, int row0, f32x4 (&v)[NT], int v16) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) v[t] = bload(S, v16, (row0 + t) * ROW * 4);
+}
+// wave-private LDS park rows, same image as the scratch rows (16 B per lane, conflict-free)
+__device__ __forceinline__ void park_store(float *pk, int row, f32x4 v, int lane) { *(f32x4 *)(pk + row * ROW + lane * 4) = v; }
+__device__ __forceinline__ f32x4 park_load(const float *pk, int row, int lane) { return *(const f32x4 *)(pk + row * ROW + lane * 4); }
+
+__device__ __forceinline__ void cutoff_poly(int p, float x, float &f, float &df) {
+  if (x >= 1.f) { f = 0.f; df = 0.f; return; }
+  float xp1 = 1.f;
+  for (int k = 0; k < p - 1; ++k) xp1 *= x;
+  const float xp = xp1 * x;
+  const float a = 0.5f * (p + 1) * (p + 2), b = (float)p * (p + 2), c = 0.5f * p * (p + 1);
+  f = 1.f - a * xp + b * xp * x - c * xp * x * x;
+  df = -a * p * xp1 + b * (p + 1) * xp - c * (p + 2) * xp * x;
+}
+
+// ---- streamed linear: running weight-fragment ring + epilogue under the next tile pair's MFMAs ----
+// The sequence of linears of a tile is static and the host lays the fragments out in consumption order, so
+// fragment n of the stream always sits at wp + n*256 floats and the 8-deep ring never drains: each step
+// consumes two fragments (output tiles 2p and 2p+1 share the B operand, so their two accumulation chains
+// alternate and hide the 16x16x4 MFMA's 8-cycle dependent-issue gap) and requests the two fragments 8 ahead.
+// Every streamed linear consumes a multiple of 8 fragments except the four 32x32 channel-mixing blocks
+// (4 each), which alternate ring phase RP = 0, 4.  The element-wise epilogue of pair p-1 (SiLU, save,
+// scaling, SiLU') is executed one register at a time between the MFMAs of pair p.
+struct EpiNone {
+  __device__ __forceinline__ void tile_done(int, const f32x4 &) const {}
+  __device__ __forceinline__ float apply(int, int, float v) const { return v; }
+  __device__ __forceinline__ void flush(int) const {}
+};
+struct EpiSave {             // raw rows to scratch, value unchanged
+  __amdgpu_buffer_rsrc_t S; int row0, v16;
+  __device__ __forceinline__ void tile_done(int ot, const f32x4 &acc) const { bstore(S, v16, (row0 + ot) * ROW * 4, acc); }
+  __device__ __forceinline__ float apply(int, int, float v) const { return v; }
+  __device__ __forceinline__ void flush(int) const {}
+};
+struct EpiSavePark : EpiSave {  // raw rows to scratch (for the backward pass) and to the LDS park (next layer's forward)
+  float *pk; int prow, lane;
+  __device__ __forceinline__ void tile_done(int ot, const f32x4 &acc) const {
+    EpiSave::tile_done(ot, acc);
+    park_store(pk, prow + ot, acc, lane);
+  }
+};
+// out = silu(z); the rows saved for the backward pass hold silu'(z) = s + silu (1 - s) (two extra VALU ops here, no
+// exp/rcp and no z there): they are written when all 8 registers of a tile pair have gone through apply()
+struct EpiSiluSaveD {
+  __amdgpu_buffer_rsrc_t S; int row0, v16;
+  f32x4 d[2];
+  __device__ __forceinline__ void tile_done(int, const f32x4 &) const {}
+  __device__ __forceinline__ float apply(int ot, int r, float z) {
+    const float sg = sigmoidf_fast(z), y = z * sg;
+    d[ot & 1][r] = fmaf(y, 1.f - sg, sg);
+    return y;
+  }
+  __device__ __forceinline__ void flush(int ot0) const {
+    bstore(S, v16, (row0 + ot0) * ROW * 4, d[0]);
+    bstore(S, v16, (row0 + ot0 + 1) * ROW * 4, d[1]);
+  }
+};
+struct EpiSaveScale : EpiSave {  // raw rows to scratch, out = c * v
+  float c;
+  __device__ __forceinline__ float apply(int, int, float v) const { return c * v; }
+};
+template <int NT> struct EpiMulRows {        // out = v * d (d = the saved silu' rows)
+  const f32x4 (&d)[NT];
+  __device__ __forceinline__ void tile_done(int, const f32x4 &) const {}
+  __device__ __forceinline__ float apply(int ot, int r, float v) const { return v * d[ot][r]; }
+  __device__ __forceinline__ void flush(int) const {}
+};
+template <int NT> struct EpiResidual : EpiSave {   // raw u rows to scratch, out = ra * xold + rbf * u
+  const f32x4 (&xold)[NT]; float ra, rbf;
+  __device__ __forceinline__ float apply(int ot, int r, float v) const { return ra * xold[ot][r] + rbf * v; }
+};
+
+template <int KT, int NT, bool ACC, int RP, class Epi>
+__device__ __forceinline__ void linear_s(__amdgpu_buffer_rsrc_t W, int &wp, const f32x4 (&in)[KT], f32x4 (&out)[NT], int v16,
+                                         f32x4 (&ring)[RING], Epi epi) {
+  static_assert(NT % 2 == 0, "output tiles are processed in pairs");
+  constexpr int NP = NT / 2, NSTEP = NP * KT, NS = 2 * NSTEP;
+  f32x4 acc0, acc1, prev0, prev1;
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    const int p = s / KT, kt = s % KT;
+    if (kt == 0) {
+      if (ACC) { acc0 = out[2 * p]; acc1 = out[2 * p + 1]; }
+      else { acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    const f32x4 a0 = ring[(RP + 2 * s) % RING], a1 = ring[(RP + 2 * s + 1) % RING];
+    ring[(RP + 2 * s) % RING] = bload(W, v16, (wp + (2 * s + RING) * 256) * 4);
+    ring[(RP + 2 * s + 1) % RING] = bload(W, v16, (wp + (2 * s + RING + 1) * 256) * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        if (hh == 0) acc0 = mfma16(a0[r], in[kt][r], acc0);
+        else acc1 = mfma16(a1[r], in[kt][r], acc1);
+        if (p > 0) {
+          const int idx = kt * 8 + 2 * r + hh;        // MFMA index inside this pair
+          if (idx % KT == 0) {
+            const int e = idx / KT;                   // 0..7: element of the previous pair
+            if (e < 4) out[2 * (p - 1)][e] = epi.apply(2 * (p - 1), e, prev0[e]);
+            else out[2 * (p - 1) + 1][e - 4] = epi.apply(2 * (p - 1) + 1, e - 4, prev1[e - 4]);
+            if (e == 7) epi.flush(2 * (p - 1));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (kt == KT - 1) {
+      epi.tile_done(2 * p, acc0);
+      epi.tile_done(2 * p + 1, acc1);
+      if (p == NP - 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { out[2 * p][r] = epi.apply(2 * p, r, acc0[r]); out[2 * p + 1][r] = epi.apply(2 * p + 1, r, acc1[r]); }
+        epi.flush(2 * p);
+      } else { prev0 = acc0; prev1 = acc1; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  wp += NS * 256;
+}
+// first RING fragments of the stream at wp into the ring
+__device__ __forceinline__ void ring_prime(__amdgpu_buffer_rsrc_t W, int wp, int v16, f32x4 (&ring)[RING]) {
+#pragma unroll
+  for (int j = 0; j < RING; ++j) ring[j] = bload(W, v16, (wp + j * 256) * 4);
+}
+
+__device__ __forceinline__ float gsum(float v) {       // sum over the 4 lanes (groups) that share one edge
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+
+// ---------------------------------------------------------------------------- tile packing
+// Greedy packing of consecutive centre atoms into tiles (<= tile_slots edges, <= maxa atoms), done
+// sequentially inside independent segments of SEG atoms so it parallelises.
+template <bool FILL>
+static __global__ void k_pack_tiles(int inum, const int *eoff, int nseg, int *seg_count, const int *seg_base, int *tile_a0, int tile_slots, int maxa) {
+  int sg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sg >= nseg) return;
+  int a = sg * SEG, end = min(inum, a + SEG);
+  int nt = 0, cur_e = 0, cur_a = 0;
+  int base = FILL ? seg_base[sg] : 0;
+  if (FILL && a < end) tile_a0[base] = a;
+  for (int at = a; at < end; ++at) {
+    int deg = eoff[at + 1] - eoff[at];
+    if (cur_a == maxa || cur_e + deg > tile_slots) {
+      ++nt; cur_e = 0; cur_a = 0;
+      if (FILL) tile_a0[base + nt] = at;
+    }
+    cur_e += deg; ++cur_a;
+  }
+  if (!FILL) seg_count[sg] = (a < end) ? nt + 1 : 0;
+}
+static __global__ void k_pack_finish(int inum, int nseg, const int *seg_base, int *tile_a0, int *ntiles) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int n = seg_base[nseg];
+    tile_a0[n] = inum;
+    ntiles[0] = n;
+    ntiles[1] = 0;          // the fused kernel's tile counter
+  }
+}
+static __global__ void k_centre_info(int inum, const int *ilist, const int *mtype, int2 *centre) {
+  int ii = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ii < inum) { const int i = ilist[ii]; centre[ii] = make_int2(i, mtype[i]); }
+}
+// packed per-edge types when the edge list did not come from the single-pass build (edges.hip writes them itself)
+static __global__ void k_edge_types(long long E, const int *e_ii, const int *e_j, const int *ilist, const int *mtype, unsigned char *e_tt) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < E) e_tt[e] = (unsigned char)((mtype[ilist[e_ii[e]]] << 4) | mtype[e_j[e]]);
+}
+static __global__ void k_tile_e0(const int *ntiles, const int *tile_a0, const int *eoff, int *tile_e0) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t <= *ntiles) tile_e0[t] = eoff[tile_a0[t]];
+}
+
+// Fragment tiling of a [K][N] linear: KT input tiles x NT output tiles of 16 features; NT is padded to
+// even (tile pairs), and a single-input-tile linear is padded to KT = 2 so that it consumes 8 fragments.
+static void frag_dims(int K, int N, int &KT, int &NT) {
+  KT = (K + 15) / 16;
+  NT = (N + 15) / 16;
+  NT += NT & 1;
+  if (KT == 1) KT = 2;
+}
+// A-operand fragments of W [K][N] (row-major, x @ W) in consumption order [pair p][kt][half][lane][r]:
+//   value = W[16 kt + 4 (lane>>4) + r][16 (2p+half) + (lane & 15)], zero padded.
+static int append_frag(std::vector<float> &out, const double *W, int K, int N, int ldw) {
+  int KT, NT;
+  frag_dims(K, N, KT, NT);
+  for (int p = 0; p < NT / 2; ++p)
+    for (int kt = 0; kt < KT; ++kt)
+      for (int half = 0; half < 2; ++half)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int r = 0; r < 4; ++r) {
+            int k = feat16(kt, r, lane >> 4), n = 16 * (2 * p + half) + (lane & 15);
+            out.push_back((k < K && n < N) ? (float)W[(size_t)k * ldw + n] : 0.f);
+          }
+  return KT * NT;
+}
+static std::vector<double> transpose(const double *W, int K, int N) {
+  std::vector<double> t((size_t)K * N);
+  for (int k = 0; k < K; ++k)
+    for (int n = 0; n < N; ++n) t[(size_t)n * K + k] = W[(size_t)k * N + n];
+  return t;
+}
+
+// Tabulated two-body embedding: x0(d; type pair) = f_c * MLP([one-hots, Bessel * f_c]) depends on the edge only through
+// (d, t_i, t_j), so it is evaluated here in float64 -- with its exact d/dd (forward mode) -- at NK + 1 knots per type pair and
+// stored as cubic-Hermite coefficients [pair][NK intervals][tile 4][coef 4][16]; the kernels gather 16 x 16 B per lane.
+static void append_two_body_table(std::vector<float> &w, const HostModel &h, const std::vector<double> &rcut_model_host, int NKin) {
+  const int T = h.num_types;
+  const HostTensor &w0 = h.get("tb.w0");          // [2T+8][64]
+  const double *wc = w0.data.data() + (size_t)2 * T * 64;       // Bessel block [8][64]
+  auto T_ = [&](const std::string &name) -> const double * { return h.get(name).data.data(); };
+  struct { const std::vector<double> &rcut_model_host; } m{rcut_model_host};
+  const int NK = NKin;
+  const double PI = 3.14159265358979323846;
+  const double *W1 = T_("tb.w1"), *W2 = T_("tb.w2");
+  auto silu = [](double z) { return z / (1.0 + std::exp(-z)); };
+  auto dsilu = [](double z) { const double sg = 1.0 / (1.0 + std::exp(-z)); return sg * (1.0 + z * (1.0 - sg)); };
+  std::vector<double> y((size_t)(NK + 1) * 64), dy((size_t)(NK + 1) * 64);
+  for (int ti = 0; ti < T; ++ti)
+    for (int tj = 0; tj < T; ++tj) {
+      const double rc = m.rcut_model_host[(size_t)ti * T + tj];
+      const double hstep = rc / NK;
+      for (int k = 0; k <= NK; ++k) {
+        const double d = k * hstep, xq = d / rc;
+        double fcv = 0, dfc = 0;                       // cutoff envelope and d/dx
+        if (xq < 1.0) {
+          const int p = h.poly_p;
+          const double xp1 = std::pow(xq, p - 1), xp = xp1 * xq;
+          const double ca = 0.5 * (p + 1) * (p + 2), cb = (double)p * (p + 2), cc = 0.5 * p * (p + 1);
+          fcv = 1.0 - ca * xp + cb * xp * xq - cc * xp * xq * xq;
+          dfc = -ca * p * xp1 + cb * (p + 1) * xp - cc * (p + 2) * xp * xq;
+        }
+        double z1[64], dz1[64], h1[64], dh1[64], z2[64], dz2[64], h2[64], dh2[64];
+        for (int n = 0; n < 64; ++n) { z1[n] = w0.data[(size_t)ti * 64 + n] + w0.data[(size_t)(T + tj) * 64 + n]; dz1[n] = 0; }
+        for (int b = 1; b <= 8; ++b) {
+          const double a = b * PI / rc;
+          double sv, ds;                                // s = sin(a d)/d and ds/dd, series near 0
+          if (a * d < 1e-4) { sv = a * (1.0 - a * a * d * d / 6.0); ds = -a * a * a * d / 3.0; }
+          else { sv = std::sin(a * d) / d; ds = (a * d * std::cos(a * d) - std::sin(a * d)) / (d * d); }
+          const double bf = 2.0 / rc * sv * fcv, dbf = 2.0 / rc * (ds * fcv + sv * dfc / rc);
+          for (int n = 0; n < 64; ++n) { z1[n] += wc[(size_t)(b - 1) * 64 + n] * bf; dz1[n] += wc[(size_t)(b - 1) * 64 + n] * dbf; }
+        }
+        for (int n = 0; n < 64; ++n) { h1[n] = silu(z1[n]); dh1[n] = dsilu(z1[n]) * dz1[n]; z2[n] = 0; dz2[n] = 0; }
+        for (int q = 0; q < 64; ++q)
+          for (int n = 0; n < 64; ++n) { z2[n] += h1[q] * W1[(size_t)q * 64 + n]; dz2[n] += dh1[q] * W1[(size_t)q * 64 + n]; }
+        for (int n = 0; n < 64; ++n) { h2[n] = silu(z2[n]); dh2[n] = dsilu(z2[n]) * dz2[n]; }
+        for (int n = 0; n < 64; ++n) {
+          double u = 0, du = 0;
+          for (int q = 0; q < 64; ++q) { u += h2[q] * W2[(size_t)q * 64 + n]; du += dh2[q] * W2[(size_t)q * 64 + n]; }
+          y[(size_t)k * 64 + n] = fcv * u;
+          dy[(size_t)k * 64 + n] = dfc / rc * u + fcv * du;
+        }
+      }
+      for (int k = 0; k < NK; ++k)
+        for (int t = 0; t < 4; ++t)
+          for (int c = 0; c < 4; ++c)
+            for (int q = 0; q < 16; ++q) {
+              const int f = 16 * t + q;               // lane (j, g) reads the 4 floats at 4 g: features 16 t + 4 g + r
+              const double y0 = y[(size_t)k * 64 + f], y1 = y[(size_t)(k + 1) * 64 + f];
+              const double m0 = hstep * dy[(size_t)k * 64 + f], m1 = hstep * dy[(size_t)(k + 1) * 64 + f];
+              const double cf = c == 0 ? y0 : c == 1 ? m0 : c == 2 ? 3.0 * (y1 - y0) - 2.0 * m0 - m1 : 2.0 * (y0 - y1) + m0 + m1;
+              w.push_back((float)cf);
+            }
+    }
+}
+}  // namespace ahip

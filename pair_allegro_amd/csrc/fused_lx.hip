@@ -1,0 +1,816 @@
+// Fused MFMA path for the wider Allegro shapes: l_max = 1 or 2, 32 or 64 tensor features (BASELINE config 5's model L:
+// l_max = 2, U = 64, 3 layers; the reference test YAML's shape: l_max = 2, U = 32, 3 layers,
+// /root/reference/tests/test_data/test_repro_allegro.yaml:89-99).  Same mapping as fused.hip (one launch = forward + analytic
+// backward, every per-edge vector in the v_mfma_f32_16x16x4_f32 C/D layout, weights as one A-fragment stream in consumption
+// order, per-centre reductions through LDS, saved rows in a per-wave scratch) with what the larger state forces:
+//
+//  * The edge tensor V[lm][u] is D*U = 576 floats per edge for model L: 144 registers per lane.  It stays in REGISTERS for the
+//    whole tile -- streaming it through memory would cost ~50 KB per edge per step -- so a wave owns the whole 512-entry
+//    register file of its SIMD: one 4-wave workgroup (64 edge slots) per CU, __launch_bounds__(256, 1).
+//  * The tensor product is channel-wise, so it runs one 16-feature K-tile t at a time IN PLACE on V[.][t] (9 + 9 live rows), with
+//    the Clebsch-Gordan table unrolled at compile time from cg_tables.h; the channel mixing V[lm] <- V[lm] @ M_l is done in place
+//    per (l, m) row; backward the same way (mix^T in place, then the tensor-product gradient in place per K-tile).
+//  * The per-centre environment sum goes through a double-buffered LDS stage holding ONE K-tile ([slots][D x 16]); one barrier
+//    per K-tile.
+//  * Two-body embedding from the per-type-pair spline table (fused_common.h), always.
+// Reference graph: the TorchScript model executed at /root/reference/pair_nequip_allegro.cpp:409-430; the oracle is
+// oracle/allegro_torch.py (autograd), so the hand-derived backward below is checked against an independent derivation.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/allegro_hip.h"
+#include "cg_tables.h"
+#include "engine.h"
+#include "fused_common.h"
+#include "prims.h"
+
+namespace ahip {
+
+static constexpr int LX_MAXNL = 3;
+
+template <int L> struct CgX;
+template <> struct CgX<1> { static constexpr const AhipCgEntry *tab = ahip_cg_l1; static constexpr int N = AHIP_CG_L1_N, NS = AHIP_CG_L1_NSCALAR, NP = AHIP_CG_L1_NPATHS, NPS = AHIP_CG_L1_NPATHS_SCALAR; };
+template <> struct CgX<2> { static constexpr const AhipCgEntry *tab = ahip_cg_l2; static constexpr int N = AHIP_CG_L2_N, NS = AHIP_CG_L2_NSCALAR, NP = AHIP_CG_L2_NPATHS, NPS = AHIP_CG_L2_NPATHS_SCALAR; };
+
+__host__ __device__ constexpr int l_of_lm(int lm) { return lm == 0 ? 0 : (lm < 4 ? 1 : 2); }
+
+struct FusedLxArgs {
+  // edge list
+  const int *eoff, *e_ii, *e_j;
+  const unsigned char *e_tt;     // per edge: (model type of centre) << 4 | (model type of neighbour)
+  const int2 *centre;            // per centre ii: {atom index ilist[ii], model type}
+  const float *rvec;
+  const double *rcut;            // [T*T]
+  int T, NL, p;
+  float cenv;
+  // tiles
+  unsigned int *tile_counter;
+  const int *tile_a0, *tile_e0, *ntiles;
+  // weights (offsets in floats into wbase)
+  const float *wbase;
+  int wbytes;
+  int o_stream, o_tbtab, tb_nk, o_tpl, o_out1, o_scale, o_shift;
+  int o_res[LX_MAXNL];
+  // scratch
+  float *scratch;
+  long long wg_scratch, wave_scratch;     // floats
+  // outputs
+  double *f, *eatom, *partial;            // partial [gridDim.x][7]
+  long long *prof;
+};
+
+// Shapes of one instantiation
+template <int L, int UT, int NW> struct ShapeX {
+  static constexpr int D = (L + 1) * (L + 1), NLP = L + 1, U = 16 * UT, EW = NLP * UT;   // EW: 16-feature tiles of an (l, u) weight vector
+  static constexpr int SLOTS = 16 * NW;
+  static constexpr int MAXA = 4;                        // centre atoms per tile (LDS budget of the environment rows)
+  static constexpr int STG_LD = D * 16 + 4;             // one K-tile of a slot: [lm][16] + pad (16-byte rows, conflict-free b128 writes)
+  static constexpr int ENVA = D * U + 4;                // environment row of one centre: [lm][u] + pad
+  static constexpr int NP = CgX<L>::NP;
+  // scratch rows (per wave, 1 KiB each): d x0/dd 4 | w0 EW | per layer: omega EW, silu'(z1) 4, silu'(z2) 4, u 4, V_in D*UT
+  static constexpr int R_DX0 = 0, R_W0 = 4, LSZ = EW + 12 + D * UT;
+  __host__ __device__ static constexpr int R_LAYER(int kk) { return 4 + EW + kk * LSZ; }
+  __host__ __device__ static constexpr int R_TOTAL(int NL) { return 4 + EW + NL * LSZ; }
+  static constexpr int O_OM = 0, O_Z1 = EW, O_Z2 = EW + 4, O_U = EW + 8, O_VIN = EW + 12;
+};
+
+template <int L, int UT, int NW> struct __attribute__((aligned(16))) LdsX {
+  using S = ShapeX<L, UT, NW>;
+  float stage[2][S::SLOTS * S::STG_LD];
+  float env[LX_MAXNL][S::MAXA * S::ENVA];
+  float denv[S::MAXA * S::ENVA];
+  float tp[LX_MAXNL][S::NP * S::U];          // tensor-product path weights [layer][path][u]
+  double eacc[S::MAXA];
+  double virw[NW][6];
+  int aoff[2][S::MAXA + 2];
+  float rc[16];
+  float scale[4], shift[4];
+  float res[LX_MAXNL][2];
+  int chunk[2];
+};
+
+// ---------------------------------------------------------------------------- tensor product, CG table unrolled
+// out[i3] += pw[path] * c * v[i1] * e[i2] over the table entries; every index is a compile-time constant.
+template <int L, bool SCALAR, int U>
+__device__ __forceinline__ void tp_fwd_x(const f32x4 (&v)[(L + 1) * (L + 1)], const float *en, const float *tp,
+                                         f32x4 (&out)[SCALAR ? 1 : (L + 1) * (L + 1)]) {
+  constexpr int D = (L + 1) * (L + 1), DOUT = SCALAR ? 1 : D, N = SCALAR ? CgX<L>::NS : CgX<L>::N, NP = SCALAR ? CgX<L>::NPS : CgX<L>::NP;
+  (void)NP;
+  f32x4 ee[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) ee[k] = *(const f32x4 *)(en + k * U);
+#pragma unroll
+  for (int k = 0; k < DOUT; ++k) out[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // The table is sorted by path: the entries of one path accumulate (CG constants as literals) into at most 2 l3 + 1 partial
+  // rows, which are scaled by the path weight once -- few live registers, two VALU operations per entry and feature.
+  f32x4 acc[2 * L + 1];
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    constexpr const AhipCgEntry *tab = CgX<L>::tab;
+    const int p = tab[q].path, l3 = l_of_lm(tab[q].i3), b3 = l3 * l3;
+    if (q == 0 || tab[q - 1].path != p) {
+#pragma unroll
+      for (int k = 0; k < 2 * L + 1; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    acc[tab[q].i3 - b3] += (float)tab[q].c * (v[tab[q].i1] * ee[tab[q].i2]);
+    if (q == N - 1 || tab[q + 1].path != p) {
+      const f32x4 pw = *(const f32x4 *)(tp + p * U);
+#pragma unroll
+      for (int k = 0; k < 2 * L + 1; ++k)
+        if (k < 2 * l3 + 1) out[b3 + k] += pw * acc[k];
+    }
+  }
+}
+// a[i1] += pw c g[i3] e[i2]  (gradient w.r.t. the edge tensor);  b[i2] += pw c g[i3] v[i1]  (w.r.t. the environment)
+template <int L, bool SCALAR, int U>
+__device__ __forceinline__ void tp_bwd_x(const f32x4 (&v)[(L + 1) * (L + 1)], const float *en, const float *tp,
+                                         const f32x4 (&g)[SCALAR ? 1 : (L + 1) * (L + 1)], f32x4 (&a)[(L + 1) * (L + 1)],
+                                         f32x4 (&b)[(L + 1) * (L + 1)]) {
+  constexpr int D = (L + 1) * (L + 1), N = SCALAR ? CgX<L>::NS : CgX<L>::N, NP = SCALAR ? CgX<L>::NPS : CgX<L>::NP;
+  (void)NP;
+  f32x4 ee[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) { ee[k] = *(const f32x4 *)(en + k * U); a[k] = f32x4{0.f, 0.f, 0.f, 0.f}; b[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  // per path: the output-gradient rows scaled by the path weight once, then three VALU operations per entry and feature
+  f32x4 gp[2 * L + 1];
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    constexpr const AhipCgEntry *tab = CgX<L>::tab;
+    const int p = tab[q].path, l3 = l_of_lm(tab[q].i3), b3 = l3 * l3;
+    if (q == 0 || tab[q - 1].path != p) {
+      const f32x4 pw = *(const f32x4 *)(tp + p * U);
+#pragma unroll
+      for (int k = 0; k < 2 * L + 1; ++k)
+        if (k < 2 * l3 + 1) gp[k] = pw * g[SCALAR ? 0 : b3 + k];
+    }
+    const f32x4 wv = (float)tab[q].c * gp[tab[q].i3 - b3];
+    a[tab[q].i1] += wv * ee[tab[q].i2];
+    b[tab[q].i2] += wv * v[tab[q].i1];
+  }
+}
+
+__device__ __forceinline__ float hsum4(const f32x4 &v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+
+// Per-centre sum of one staged K-tile: env[a][lm][16 t + f] = scale * sum_{slots of a} stage[slot][lm][f].
+template <int L, int UT, int NW>
+__device__ __forceinline__ void reduce_stage_x(const float *stg, const int *aoff, float *dst, int na, float scale, int t, int tid) {
+  using S = ShapeX<L, UT, NW>;
+  constexpr int PER = S::D * 16;
+  for (int o = tid; o < na * PER; o += NW * 64) {
+    const int a = o / PER, r = o - a * PER;
+    const int s0 = aoff[a], s1 = aoff[a + 1];
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    int sl = s0;
+    for (; sl + 4 <= s1; sl += 4) {
+      acc0 += stg[sl * S::STG_LD + r];
+      acc1 += stg[(sl + 1) * S::STG_LD + r];
+      acc2 += stg[(sl + 2) * S::STG_LD + r];
+      acc3 += stg[(sl + 3) * S::STG_LD + r];
+    }
+    for (; sl < s1; ++sl) acc0 += stg[sl * S::STG_LD + r];
+    dst[a * S::ENVA + (r >> 4) * S::U + 16 * t + (r & 15)] = scale * ((acc0 + acc1) + (acc2 + acc3));
+  }
+}
+
+enum { PX_GEOM = 0, PX_EMB, PX_ENV, PX_TP, PX_LAT, PX_MIX, PX_OUT, PX_BLAT, PX_BMIX, PX_BTP, PX_BENV, PX_BEMB, PX_FIN, PX_N };
+#define PHASEX(id) do { if (PROF) { long long _t = clock64(); pacc[id] += _t - tprev; tprev = _t; } } while (0)
+
+// ---------------------------------------------------------------------------- the kernel
+template <int L, int UT, int NW, bool PROF>
+__global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
+  using S = ShapeX<L, UT, NW>;
+  constexpr int NTHREADS = NW * 64, D = S::D, U = S::U, EW = S::EW, MAXA = S::MAXA, STG_LD = S::STG_LD, ENVA = S::ENVA, NP = S::NP;
+  __shared__ LdsX<L, UT, NW> lds;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
+  const int v16 = lane * 16;
+  __amdgpu_buffer_rsrc_t SB, WB;
+  {
+    unsigned long long b = (unsigned long long)(A.scratch + (size_t)blockIdx.x * A.wg_scratch + (size_t)wave * A.wave_scratch);
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    SB = __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, (int)(A.wave_scratch * 4), 0x00020000);
+    WB = __builtin_amdgcn_make_buffer_rsrc((void *)A.wbase, 0, A.wbytes, 0x00020000);
+  }
+  const float *__restrict__ Wb = A.wbase;
+  const int NL = A.NL;
+  for (int k = tid; k < NL * NP * U; k += NTHREADS) lds.tp[k / (NP * U)][k % (NP * U)] = Wb[A.o_tpl + k];
+  const int ntiles = *A.ntiles;
+  double acc_part = 0.0;
+  long long pacc[PX_N];
+  long long tprev = 0;
+  if (PROF) {
+#pragma unroll
+    for (int k = 0; k < PX_N; ++k) pacc[k] = 0;
+    tprev = clock64();
+  }
+  f32x4 ring[RING];
+  int wp = A.o_stream;
+  ring_prime(WB, wp, v16, ring);
+  if (tid < MAXA) lds.eacc[tid] = 0.0;
+  if (lane < 6) lds.virw[wave][lane] = 0.0;
+  if (tid < A.T * A.T) lds.rc[tid] = (float)A.rcut[tid];
+  if (tid < A.T) { lds.scale[tid] = Wb[A.o_scale + tid]; lds.shift[tid] = Wb[A.o_shift + tid]; }
+  if (tid < 2 * NL) lds.res[tid >> 1][tid & 1] = Wb[A.o_res[tid >> 1] + (tid & 1)];
+
+  const int s = wave * 16 + j;                 // this lane's edge slot
+  const int ca = tid >> 4;                     // centre slot served by this thread in the per-centre output step
+  if (tid == 0) lds.chunk[0] = (int)atomicAdd(A.tile_counter, (unsigned)TCHUNK);
+  __syncthreads();
+  int par = 0, cpar = 0, ck = 0;
+  int cbase = __builtin_amdgcn_readfirstlane(lds.chunk[0]);
+
+  for (;;) {
+    const int tile = cbase + ck;
+    if (tile >= ntiles) break;
+    int claimed = 0;
+    if (ck == 0 && tid == 0) claimed = (int)atomicAdd(A.tile_counter, (unsigned)TCHUNK);
+    const int a0 = A.tile_a0[tile], a1 = A.tile_a0[tile + 1], e0 = A.tile_e0[tile], e1 = A.tile_e0[tile + 1];
+    const int na = a1 - a0;
+    par ^= 1;
+    int *const aoffp = lds.aoff[par];
+    const int e = e0 + s;
+    const bool valid = e < e1;
+    float rx = 1.f, ry = 0.f, rz = 0.f;
+    int aloc = 0, ti = 0, tj = 0, jat = 0, c_i = 0, c_t = 0;
+    if (valid) {
+      rx = A.rvec[3 * (size_t)e]; ry = A.rvec[3 * (size_t)e + 1]; rz = A.rvec[3 * (size_t)e + 2];
+      aloc = A.e_ii[e] - a0;
+      jat = A.e_j[e];
+      const int tt = A.e_tt[e];
+      ti = tt >> 4; tj = tt & 15;
+    }
+    if (ca < na) { const int2 ci = A.centre[a0 + ca]; c_i = ci.x; c_t = ci.y; }
+    if (tid <= na) aoffp[tid] = A.eoff[a0 + tid] - e0;
+
+    // ---------------- geometry ----------------
+    const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+    const float inv = 1.f / d;
+    const float nx = rx * inv, ny = ry * inv, nz = rz * inv;
+    const float rc = lds.rc[ti * A.T + tj];
+    const float xx = d / rc;
+    float fc, dfc_dx;
+    cutoff_poly(A.p, xx, fc, dfc_dx);
+    if (!valid) { fc = 0.f; dfc_dx = 0.f; }
+    // real spherical harmonics, component normalisation, m = -l..l (pair_allegro_amd/cg.py)
+    constexpr float C3 = 1.7320508075688772f, C15 = 3.872983346207417f, C5H = 1.118033988749895f;
+    float Y[D];
+    Y[0] = 1.f;
+    Y[1] = C3 * ny; Y[2] = C3 * nz; Y[3] = C3 * nx;
+    if constexpr (L >= 2) {
+      Y[4] = C15 * nx * ny; Y[5] = C15 * ny * nz; Y[6] = C5H * (2.f * nz * nz - nx * nx - ny * ny);
+      Y[7] = C15 * nx * nz; Y[8] = 0.5f * C15 * (nx * nx - ny * ny);
+    }
+    const int envoff = aloc * ENVA + 4 * g;      // + kk * MAXA*ENVA (layer) + lm * U + 16 t
+    float *const st0 = lds.stage[0] + s * STG_LD + 4 * g;
+    float *const st1 = lds.stage[1] + s * STG_LD + 4 * g;
+    PHASEX(PX_GEOM);
+
+    // ---------------- two-body embedding x0(d; type pair) from the spline table ----------------
+    f32x4 x[4];
+    {
+      const float tb_invh = (float)A.tb_nk / rc;
+      const float sft = d * tb_invh;
+      const int kq = min((int)sft, A.tb_nk - 1);
+      const float tb_t = sft - (float)kq;
+      const float *tb_ent = Wb + A.o_tbtab + ((size_t)(ti * A.T + tj) * A.tb_nk + kq) * 256 + 4 * g;
+      const float vm = (valid && xx < 1.f) ? 1.f : 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 c0 = *(const f32x4 *)(tb_ent + (t * 4 + 0) * 16), c1 = *(const f32x4 *)(tb_ent + (t * 4 + 1) * 16);
+        const f32x4 c2 = *(const f32x4 *)(tb_ent + (t * 4 + 2) * 16), c3 = *(const f32x4 *)(tb_ent + (t * 4 + 3) * 16);
+        x[t] = (c0 + tb_t * (c1 + tb_t * (c2 + tb_t * c3))) * vm;
+        bstore(SB, v16, (S::R_DX0 + t) * ROW * 4, (c1 + tb_t * (2.f * c2 + (3.f * tb_t) * c3)) * (vm * tb_invh));
+      }
+    }
+    // ---------------- tensor embedding V^0[lm][u] = w0[l][u] Y[lm] ----------------
+    f32x4 V[D][UT];          // the edge tensor, forward; its gradient, backward
+    {
+      f32x4 w0[EW];
+      linear_s<4, EW, false, 0>(WB, wp, x, w0, v16, ring, EpiSave{SB, S::R_W0, v16});
+#pragma unroll
+      for (int lm = 0; lm < D; ++lm)
+#pragma unroll
+        for (int t = 0; t < UT; ++t) V[lm][t] = lm == 0 ? w0[t] : w0[l_of_lm(lm) * UT + t] * Y[lm];
+    }
+    if (ck == 0 && tid == 0) lds.chunk[cpar ^ 1] = claimed;
+    __syncthreads();          // aoff visible; previous tile's LDS users done
+    PHASEX(PX_EMB);
+
+    // ---------------- layers, forward ----------------
+    for (int kk = 0; kk < NL; ++kk) {
+      const bool last = (kk == NL - 1);
+      const int RL = S::R_LAYER(kk);
+      float *const envk = lds.env[kk];
+      {
+        f32x4 om[EW];
+        linear_s<4, EW, false, 0>(WB, wp, x, om, v16, ring, EpiSave{SB, RL + S::O_OM, v16});
+        // environment sum over the centre's edges, one K-tile at a time through the double-buffered stage
+#pragma unroll
+        for (int t = 0; t < UT; ++t) {
+          float *const sp = (t & 1) ? st1 : st0;
+#pragma unroll
+          for (int lm = 0; lm < D; ++lm) *(f32x4 *)(sp + lm * 16) = lm == 0 ? om[t] : om[l_of_lm(lm) * UT + t] * Y[lm];
+          __syncthreads();
+          reduce_stage_x<L, UT, NW>(lds.stage[t & 1], aoffp, envk, na, A.cenv, t, tid);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+      }
+      PHASEX(PX_ENV);
+      // tensor product, in place per K-tile
+      f32x4 sc[UT];            // scalar outputs (l3 = 0) of the tensor product: the latent MLP's second input
+      {
+        const float *en = envk + envoff;
+        const float *tp = lds.tp[kk] + 4 * g;
+        if (!last) {
+#pragma unroll
+          for (int t = 0; t < UT; ++t) {
+            f32x4 vin[D], out[D];
+#pragma unroll
+            for (int lm = 0; lm < D; ++lm) vin[lm] = V[lm][t];
+            tp_fwd_x<L, false, U>(vin, en + 16 * t, tp + 16 * t, out);
+#pragma unroll
+            for (int lm = 0; lm < D; ++lm) V[lm][t] = out[lm];
+            sc[t] = out[0];
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < UT; ++t) {
+            f32x4 vin[D], out[1];
+#pragma unroll
+            for (int lm = 0; lm < D; ++lm) vin[lm] = V[lm][t];
+            tp_fwd_x<L, true, U>(vin, en + 16 * t, tp + 16 * t, out);
+            sc[t] = out[0];
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      PHASEX(PX_TP);
+      // latent MLP on [x, scalars]
+      {
+        f32x4 cat[4 + UT], z[4], z2[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) cat[t] = x[t];
+#pragma unroll
+        for (int t = 0; t < UT; ++t) cat[4 + t] = sc[t];
+        linear_s<4 + UT, 4, false, 0>(WB, wp, cat, z, v16, ring, EpiSiluSaveD{SB, RL + S::O_Z1, v16});
+        linear_s<4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, RL + S::O_Z2, v16});
+        const float ra = lds.res[kk][0], rbf = lds.res[kk][1] * fc;
+        f32x4 xn[4];
+        linear_s<4, 4, false, 0>(WB, wp, z2, xn, v16, ring, EpiResidual<4>{{SB, RL + S::O_U, v16}, x, ra, rbf});
+#pragma unroll
+        for (int t = 0; t < 4; ++t) x[t] = xn[t];
+      }
+      PHASEX(PX_LAT);
+      // channel mixing, in place per (l, m) row -> V^{kk+1}, saved as the next layer's V_in rows
+      if (!last) {
+#pragma unroll
+        for (int lm = 0; lm < D; ++lm) {
+          f32x4 o[UT];
+          linear_s<UT, UT, false, 0>(WB, wp, V[lm], o, v16, ring, EpiSave{SB, S::R_LAYER(kk + 1) + S::O_VIN + lm * UT, v16});
+#pragma unroll
+          for (int t = 0; t < UT; ++t) V[lm][t] = o[t];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      PHASEX(PX_MIX);
+    }
+
+    // ---------------- read-out ----------------
+    f32x4 zr[2];
+    linear_s<4, 2, false, 0>(WB, wp, x, zr, v16, ring, EpiNone{});
+    f32x4 wo1[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) wo1[t] = *(const f32x4 *)(Wb + A.o_out1 + 16 * t + 4 * g);
+    float eps = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) eps += silu1(zr[t][r]) * wo1[t][r];
+    eps = gsum(eps);
+
+    // =========================== backward ===========================
+    const float deps = valid ? lds.scale[ti] * A.cenv : 0.f;
+    f32x4 dx[4];
+    {
+      f32x4 dzr[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dzr[t][r] = deps * wo1[t][r] * dsilu1(zr[t][r]);
+      linear_s<2, 4, false, 0>(WB, wp, dzr, dx, v16, ring, EpiNone{});
+    }
+    float dfc_part = 0.f;
+    float dY[D];
+#pragma unroll
+    for (int lm = 0; lm < D; ++lm) dY[lm] = 0.f;
+    PHASEX(PX_OUT);
+
+    for (int kk = NL - 1; kk >= 0; --kk) {
+      const bool last = (kk == NL - 1);
+      const int RL = S::R_LAYER(kk);
+      f32x4 ds[UT];
+      {
+        f32x4 du[4], dh[4], rows[4];
+        load_rows<4>(SB, RL + S::O_U, rows, v16);
+        {
+          const float ra = lds.res[kk][0], rb = lds.res[kk][1];
+          f32x4 accv = rows[0] * dx[0];
+#pragma unroll
+          for (int t = 1; t < 4; ++t) accv += rows[t] * dx[t];
+          const float rbfc = rb * fc;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { du[t] = rbfc * dx[t]; dx[t] = ra * dx[t]; }
+          dfc_part += rb * hsum4(accv);
+        }
+        load_rows<4>(SB, RL + S::O_Z2, rows, v16);
+        __builtin_amdgcn_sched_barrier(0);
+        linear_s<4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{rows});
+        f32x4 rows1[4];
+        load_rows<4>(SB, RL + S::O_Z1, rows1, v16);
+        __builtin_amdgcn_sched_barrier(0);
+        linear_s<4, 4, false, 0>(WB, wp, dh, du, v16, ring, EpiMulRows<4>{rows1});
+        f32x4 dcat[4 + UT];
+        linear_s<4, 4 + UT, false, 0>(WB, wp, du, dcat, v16, ring, EpiNone{});
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dx[t] += dcat[t];
+#pragma unroll
+        for (int t = 0; t < UT; ++t) ds[t] = dcat[4 + t];
+      }
+      PHASEX(PX_BLAT);
+      // mix^T in place per (l, m) row: V holds dE/dV^{kk+1}, becomes dE/dV' (tensor-product output gradient)
+      if (!last) {
+#pragma unroll
+        for (int lm = 0; lm < D; ++lm) {
+          f32x4 o[UT];
+          linear_s<UT, UT, false, 0>(WB, wp, V[lm], o, v16, ring, EpiNone{});
+#pragma unroll
+          for (int t = 0; t < UT; ++t) V[lm][t] = lm == 0 ? o[t] + ds[t] : o[t];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      PHASEX(PX_BMIX);
+      // tensor-product gradient in place per K-tile; the per-edge environment gradient goes through the stage
+      {
+        const float *en = lds.env[kk] + envoff;
+        const float *tp = lds.tp[kk] + 4 * g;
+#pragma unroll
+        for (int t = 0; t < UT; ++t) {
+          f32x4 vin[D], a[D], b[D];
+          if (kk > 0) {
+#pragma unroll
+            for (int lm = 0; lm < D; ++lm) vin[lm] = bload(SB, v16, (RL + S::O_VIN + lm * UT + t) * ROW * 4);
+          } else {
+            f32x4 w0r[L + 1];
+#pragma unroll
+            for (int l = 0; l <= L; ++l) w0r[l] = bload(SB, v16, (S::R_W0 + l * UT + t) * ROW * 4);
+#pragma unroll
+            for (int lm = 0; lm < D; ++lm) vin[lm] = lm == 0 ? w0r[0] : w0r[l_of_lm(lm)] * Y[lm];
+          }
+          if (!last) {
+            f32x4 gg[D];
+#pragma unroll
+            for (int lm = 0; lm < D; ++lm) gg[lm] = V[lm][t];
+            tp_bwd_x<L, false, U>(vin, en + 16 * t, tp + 16 * t, gg, a, b);
+          } else {
+            f32x4 gg[1];
+            gg[0] = ds[t];
+            tp_bwd_x<L, true, U>(vin, en + 16 * t, tp + 16 * t, gg, a, b);
+          }
+          float *const sp = (t & 1) ? st1 : st0;
+#pragma unroll
+          for (int lm = 0; lm < D; ++lm) { V[lm][t] = a[lm]; *(f32x4 *)(sp + lm * 16) = b[lm]; }
+          __syncthreads();
+          reduce_stage_x<L, UT, NW>(lds.stage[t & 1], aoffp, lds.denv, na, A.cenv, t, tid);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+      }
+      PHASEX(PX_BTP);
+      // environment weights backward: d omega[l][u] = sum_m denv[lm][u] Y[lm];  dY[lm] += sum_u denv[lm][u] omega[l][u]
+      {
+        f32x4 dom[EW];
+        const float *dn = lds.denv + envoff;
+#pragma unroll
+        for (int t = 0; t < UT; ++t) {
+          f32x4 omr[L + 1];
+#pragma unroll
+          for (int l = 1; l <= L; ++l) omr[l] = bload(SB, v16, (RL + S::O_OM + l * UT + t) * ROW * 4);
+#pragma unroll
+          for (int l = 0; l <= L; ++l) dom[l * UT + t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int lm = 0; lm < D; ++lm) {
+            const f32x4 dv = *(const f32x4 *)(dn + lm * U + 16 * t);
+            if (lm == 0) dom[t] = dv;
+            else {
+              dom[l_of_lm(lm) * UT + t] += dv * Y[lm];
+              dY[lm] += hsum4(dv * omr[l_of_lm(lm)]);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        linear_s<EW, 4, true, 0>(WB, wp, dom, dx, v16, ring, EpiNone{});
+      }
+      PHASEX(PX_BENV);
+    }
+    // ---------------- embedding backward: V holds dE/dV^0 ----------------
+    {
+      f32x4 dw0[EW];
+#pragma unroll
+      for (int t = 0; t < UT; ++t) {
+        f32x4 w0r[L + 1];
+#pragma unroll
+        for (int l = 1; l <= L; ++l) w0r[l] = bload(SB, v16, (S::R_W0 + l * UT + t) * ROW * 4);
+#pragma unroll
+        for (int l = 0; l <= L; ++l) dw0[l * UT + t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int lm = 0; lm < D; ++lm) {
+          if (lm == 0) dw0[t] = V[0][t];
+          else {
+            dw0[l_of_lm(lm) * UT + t] += V[lm][t] * Y[lm];
+            dY[lm] += hsum4(V[lm][t] * w0r[l_of_lm(lm)]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      linear_s<EW, 4, true, 0>(WB, wp, dw0, dx, v16, ring, EpiNone{});
+      wp = A.o_stream;                                                     // last linear of the tile (wrap-around copy follows it)
+    }
+    PHASEX(PX_BEMB);
+    // ---------------- two-body embedding backward ----------------
+    float dd_part;
+    {
+      f32x4 rows[4];
+      load_rows<4>(SB, S::R_DX0, rows, v16);
+      f32x4 accv = dx[0] * rows[0];
+#pragma unroll
+      for (int t = 1; t < 4; ++t) accv += dx[t] * rows[t];
+      dd_part = hsum4(accv);
+    }
+    // ---------------- geometry backward, outputs ----------------
+    {
+      const float dfc_tot = gsum(dfc_part);
+      const float dd = dfc_tot * (dfc_dx / rc) + gsum(dd_part);
+      float yv[D];
+#pragma unroll
+      for (int lm = 1; lm < D; ++lm) yv[lm] = gsum(dY[lm]);
+      // G = sum_lm dE/dY_lm * dY_lm/dn (n treated as a free vector), then projected onto the sphere
+      float Gx = C3 * yv[3], Gy = C3 * yv[1], Gz = C3 * yv[2];
+      if constexpr (L >= 2) {
+        Gx += C15 * (yv[4] * ny + yv[7] * nz + yv[8] * nx) - 2.f * C5H * yv[6] * nx;
+        Gy += C15 * (yv[4] * nx + yv[5] * nz - yv[8] * ny) - 2.f * C5H * yv[6] * ny;
+        Gz += C15 * (yv[5] * ny + yv[7] * nx) + 4.f * C5H * yv[6] * nz;
+      }
+      const float gn = Gx * nx + Gy * ny + Gz * nz;
+      const float gx = dd * nx + (Gx - gn * nx) * inv;
+      const float gy = dd * ny + (Gy - gn * ny) * inv;
+      const float gz = dd * nz + (Gz - gn * nz) * inv;
+      const float m = valid ? 1.f : 0.f;
+      float *const st = lds.stage[0] + s * STG_LD;
+      if (g == 0) {
+        st[0] = m * gx; st[1] = m * gy; st[2] = m * gz; st[3] = m * eps;
+        if (valid) {
+          atomicAdd(&A.f[3 * (size_t)jat], -(double)gx);
+          atomicAdd(&A.f[3 * (size_t)jat + 1], -(double)gy);
+          atomicAdd(&A.f[3 * (size_t)jat + 2], -(double)gz);
+        }
+      }
+      float w6[6] = {-m * rx * gx, -m * ry * gy, -m * rz * gz, -m * 0.5f * (rx * gy + ry * gx),
+                     -m * 0.5f * (rx * gz + rz * gx), -m * 0.5f * (ry * gz + rz * gy)};
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) w6[c] += __shfl_xor(w6[c], off, 64);
+      }
+      if (lane < 6) {
+        const float mine = lane == 0 ? w6[0] : lane == 1 ? w6[1] : lane == 2 ? w6[2] : lane == 3 ? w6[3] : lane == 4 ? w6[4] : w6[5];
+        lds.virw[wave][lane] += (double)mine;
+      }
+    }
+    __syncthreads();
+    {
+      const int col = tid & 3, part = (tid >> 2) & 3;
+      float sum = 0.f;
+      if (ca < na)
+        for (int sl = aoffp[ca] + part; sl < aoffp[ca + 1]; sl += 4) sum += lds.stage[0][sl * STG_LD + col];
+      sum += __shfl_xor(sum, 4, 64);
+      sum += __shfl_xor(sum, 8, 64);
+      if (ca < na && part == 0) {
+        if (col < 3) atomicAdd(&A.f[3 * (size_t)c_i + col], (double)sum);
+        else {
+          const float ei = lds.scale[c_t] * (sum * A.cenv) + lds.shift[c_t];
+          if (A.eatom) A.eatom[c_i] = (double)ei;
+          lds.eacc[ca] += (double)ei;
+        }
+      }
+    }
+    // no trailing barrier: the next tile's first staging write sits behind the barrier after its embedding linear
+    PHASEX(PX_FIN);
+    if (++ck == TCHUNK) { ck = 0; cpar ^= 1; cbase = __builtin_amdgcn_readfirstlane(lds.chunk[cpar]); }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int a = 0; a < MAXA; ++a) acc_part += lds.eacc[a];
+  } else if (tid >= 64 && tid < 70) {
+    for (int w = 0; w < NW; ++w) acc_part += lds.virw[w][tid - 64];
+  }
+  if (PROF && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < PX_N; ++k) atomicAdd((unsigned long long *)&A.prof[k], (unsigned long long)pacc[k]);
+  }
+  if (tid == 0) A.partial[7 * (size_t)blockIdx.x] = acc_part;
+  if (tid >= 64 && tid < 70) A.partial[7 * (size_t)blockIdx.x + 1 + (tid - 64)] = acc_part;
+}
+
+// ---------------------------------------------------------------------------- host side
+struct FusedLxState {
+  DevBuf wbuf, scratch, seg_count, seg_base, tile_a0, tile_e0, centre, ntiles, partial, prof;
+  FusedLxArgs args;
+  bool ready = false, prof_on = false;
+  int ncu = 256;
+  int L = 0, UT = 0;
+};
+
+bool fusedlx_model_supported(const Model &m, std::string *why) {
+  const HostModel &h = m.hm;
+  auto no = [&](const char *msg) { if (why) *why = msg; return false; };
+  if (h.l_max != 2) return no("wide fused kernels are built for l_max = 2");
+  if (h.U != 64) return no("wide fused kernels need 64 tensor features");
+  if (h.S != 64 || h.mlp_width != 64 || h.readout_width != 32) return no("fused kernels need S=64, MLP width 64, read-out width 32");
+  if (h.mlp_depth != 2 || h.readout_depth != 1) return no("fused kernels need MLP depth 2 and read-out depth 1");
+  if (h.num_bessels != 8) return no("fused kernels need 8 Bessel functions");
+  if (h.num_layers < 1 || h.num_layers > LX_MAXNL) return no("fused kernels need 1..3 layers");
+  if (h.num_types > 4) return no("fused kernels support at most 4 model types");
+  return true;
+}
+
+template <int L, int UT> static void fusedlx_prepare_t(Model &m, FusedLxState &st) {
+  using S = ShapeX<L, UT, 4>;
+  const HostModel &h = m.hm;
+  const int T = h.num_types, NL = h.num_layers, U = S::U, D = S::D;
+  std::vector<float> w;
+  FusedLxArgs &A = st.args;
+  std::memset(&A, 0, sizeof(A));
+  auto mark = [&]() { while (w.size() % 64) w.push_back(0.f); return (int)w.size(); };
+  auto T_ = [&](const std::string &name) -> const double * { return h.get(name).data.data(); };
+  auto fwd = [&](const double *W, int K, int N) { append_frag(w, W, K, N, N); };
+  auto bwd = [&](const double *W, int K, int N) { auto t = transpose(W, K, N); append_frag(w, t.data(), N, K, K); };
+  // ---- the weight stream, in the order one tile consumes it (see k_fused_lx) ----
+  A.o_stream = mark();
+  const size_t stream0 = w.size();
+  fwd(T_("emb.w"), 64, U * (L + 1));
+  for (int k = 0; k < NL; ++k) {
+    const std::string lk = "l" + std::to_string(k + 1);
+    fwd(T_(lk + ".env"), 64, U * (L + 1));
+    fwd(T_(lk + ".lat.w0"), 64 + U, 64);
+    fwd(T_(lk + ".lat.w1"), 64, 64);
+    fwd(T_(lk + ".lat.w2"), 64, 64);
+    if (k < NL - 1) {
+      const double *mx = T_(lk + ".mix");            // [L+1][U][U]; block l serves its 2l+1 components
+      for (int lm = 0; lm < D; ++lm) fwd(mx + (size_t)l_of_lm(lm) * U * U, U, U);
+    }
+  }
+  fwd(T_("out.w0"), 64, 32);
+  bwd(T_("out.w0"), 64, 32);
+  for (int k = NL - 1; k >= 0; --k) {
+    const std::string lk = "l" + std::to_string(k + 1);
+    bwd(T_(lk + ".lat.w2"), 64, 64);
+    bwd(T_(lk + ".lat.w1"), 64, 64);
+    bwd(T_(lk + ".lat.w0"), 64 + U, 64);
+    if (k < NL - 1) {
+      const double *mx = T_(lk + ".mix");
+      for (int lm = 0; lm < D; ++lm) bwd(mx + (size_t)l_of_lm(lm) * U * U, U, U);
+    }
+    bwd(T_(lk + ".env"), 64, U * (L + 1));
+  }
+  bwd(T_("emb.w"), 64, U * (L + 1));
+  for (size_t i = 0; i < (size_t)RING * 256; ++i) w.push_back(w[stream0 + i]);      // wrap-around copy
+  // two-body table
+  A.tb_nk = 512;
+  A.o_tbtab = mark();
+  append_two_body_table(w, h, m.rcut_model_host, A.tb_nk);
+  // small tables: path weights (last layer: only the scalar paths, the rest zero)
+  A.o_tpl = mark();
+  for (int k = 0; k < NL; ++k) {
+    const HostTensor &tp = h.get("l" + std::to_string(k + 1) + ".tp");
+    for (int p = 0; p < S::NP; ++p)
+      for (int u = 0; u < U; ++u) w.push_back(p < tp.shape[0] ? (float)tp.data[(size_t)p * U + u] : 0.f);
+  }
+  for (int k = 0; k < NL; ++k) {
+    const HostTensor &res = h.get("l" + std::to_string(k + 1) + ".res");
+    A.o_res[k] = mark(); w.push_back((float)res.data[0]); w.push_back((float)res.data[1]);
+  }
+  A.o_out1 = mark(); for (int u = 0; u < 32; ++u) w.push_back((float)h.get("out.w1").data[u]);
+  A.o_scale = mark(); for (int t = 0; t < T; ++t) w.push_back((float)h.get("scale").data[t]);
+  A.o_shift = mark(); for (int t = 0; t < T; ++t) w.push_back((float)h.get("shift").data[t]);
+  mark();
+  st.wbuf.reserve(w.size() * sizeof(float));
+  AHIP_CHECK(hipMemcpy(st.wbuf.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+  A.wbase = st.wbuf.as<float>();
+  A.wbytes = (int)(w.size() * sizeof(float));
+  A.T = T; A.NL = NL; A.p = h.poly_p;
+  A.cenv = (float)(1.0 / std::sqrt(h.avg_num_neighbors));
+  A.wave_scratch = (long long)S::R_TOTAL(NL) * ROW;
+}
+
+static void fusedlx_prepare(Model &m) {
+  if (!m.fusedlx_state) m.fusedlx_state = new FusedLxState();
+  FusedLxState &st = *(FusedLxState *)m.fusedlx_state;
+  if (st.ready) return;
+  st.L = m.hm.l_max; st.UT = m.hm.U / 16;
+  fusedlx_prepare_t<2, 4>(m, st);
+  hipDeviceProp_t prop;
+  AHIP_CHECK(hipGetDeviceProperties(&prop, m.device));
+  st.ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  st.scratch.reserve((size_t)st.ncu * 4 * st.args.wave_scratch * sizeof(float));
+  st.args.scratch = st.scratch.as<float>();
+  st.partial.reserve((size_t)st.ncu * 7 * sizeof(double));
+  st.ntiles.reserve(64);
+  st.prof.reserve(64 * sizeof(long long));
+  const char *pe = std::getenv("AHIP_FUSED_PROF");
+  st.prof_on = pe && pe[0] == '1';
+  st.ready = true;
+}
+
+bool fusedlx_run(Model &m, const ComputeArgs &a, std::string *why) {
+  constexpr int NW = 4, SLOTS = 16 * NW;
+  if (m.last_max_deg > SLOTS) {
+    if (why) *why = "an atom has " + std::to_string(m.last_max_deg) + " edges (> " + std::to_string(SLOTS) + " per tile of the wide fused kernel)";
+    return false;
+  }
+  if (m.edges_T_size != 4) { if (why) *why = "edge vectors are not float32"; return false; }
+  fusedlx_prepare(m);
+  FusedLxState &st = *(FusedLxState *)m.fusedlx_state;
+  hipStream_t s = a.stream;
+  const int inum = m.inum;
+  const int maxa = ShapeX<2, 4, NW>::MAXA;
+  const int grid = st.ncu;
+  const int nseg = (inum + SEG - 1) / SEG;
+  st.seg_count.reserve((size_t)(nseg + 1) * sizeof(int));
+  st.seg_base.reserve((size_t)(nseg + 2) * sizeof(int));
+  st.tile_a0.reserve((size_t)(inum + nseg + 2) * sizeof(int));
+  st.tile_e0.reserve((size_t)(inum + nseg + 2) * sizeof(int));
+  {
+    StageTimer tm(m, "tile_pack", s);
+    const unsigned B = 64;
+    hipLaunchKernelGGL(k_pack_tiles<false>, dim3((nseg + B - 1) / B), dim3(B), 0, s, inum, m.b_eoff.as<int>(), nseg, st.seg_count.as<int>(), (const int *)nullptr, (int *)nullptr, SLOTS, maxa);
+    AHIP_CHECK(prim_exclusive_scan_i32(m.prim, st.seg_count.as<int>(), st.seg_base.as<int>(), nseg, s));
+    hipLaunchKernelGGL(k_pack_tiles<true>, dim3((nseg + B - 1) / B), dim3(B), 0, s, inum, m.b_eoff.as<int>(), nseg, (int *)nullptr, st.seg_base.as<int>(), st.tile_a0.as<int>(), SLOTS, maxa);
+    hipLaunchKernelGGL(k_pack_finish, dim3(1), dim3(1), 0, s, inum, nseg, st.seg_base.as<int>(), st.tile_a0.as<int>(), st.ntiles.as<int>());
+    const int tcap = inum + nseg + 1;
+    st.centre.reserve((size_t)std::max(inum, 1) * sizeof(int2));
+    hipLaunchKernelGGL(k_centre_info, dim3((inum + 255) / 256), dim3(256), 0, s, inum, m.d_ilist, a.mtype, st.centre.as<int2>());
+    if (!m.have_ett) {
+      m.b_ett.reserve((size_t)std::max<long long>(m.nedges, 1));
+      hipLaunchKernelGGL(k_edge_types, dim3((unsigned)((m.nedges + 255) / 256)), dim3(256), 0, s, m.nedges, m.b_eii.as<int>(), m.b_ej.as<int>(), m.d_ilist, a.mtype, m.b_ett.as<unsigned char>());
+      m.have_ett = true;
+    }
+    hipLaunchKernelGGL(k_tile_e0, dim3((tcap + 255) / 256), dim3(256), 0, s, st.ntiles.as<int>(), st.tile_a0.as<int>(), m.b_eoff.as<int>(), st.tile_e0.as<int>());
+  }
+  FusedLxArgs A = st.args;
+  A.wg_scratch = NW * A.wave_scratch;
+  A.eoff = m.b_eoff.as<int>(); A.e_ii = m.b_eii.as<int>(); A.e_j = m.b_ej.as<int>();
+  A.e_tt = m.b_ett.as<unsigned char>(); A.centre = st.centre.as<int2>(); A.rvec = m.b_rvec.as<float>(); A.rcut = m.rcut_model_dev;
+  A.tile_a0 = st.tile_a0.as<int>(); A.tile_e0 = st.tile_e0.as<int>(); A.ntiles = st.ntiles.as<int>();
+  A.tile_counter = (unsigned int *)(st.ntiles.as<int>() + 1);
+  A.f = a.f; A.eatom = a.eatom; A.partial = st.partial.as<double>();
+  {
+    StageTimer tm(m, "model_fused", s);
+    if (st.prof_on) {
+      AHIP_CHECK(hipMemsetAsync(st.prof.p, 0, 64 * sizeof(long long), s));
+      A.prof = st.prof.as<long long>();
+      hipLaunchKernelGGL((k_fused_lx<2, 4, NW, true>), dim3(grid), dim3(NW * 64), 0, s, A);
+    } else {
+      hipLaunchKernelGGL((k_fused_lx<2, 4, NW, false>), dim3(grid), dim3(NW * 64), 0, s, A);
+    }
+  }
+  AHIP_CHECK(hipGetLastError());
+  AHIP_CHECK(prim_sum_columns_f64(m.prim, st.partial.as<double>(), grid, 7, a.engvir, s));
+  if (st.prof_on) {
+    std::vector<long long> hp(PX_N);
+    AHIP_CHECK(hipMemcpyAsync(hp.data(), st.prof.p, hp.size() * sizeof(long long), hipMemcpyDeviceToHost, s));
+    AHIP_CHECK(hipStreamSynchronize(s));
+    static const char *names[PX_N] = {"geom+tb", "embed", "env+reduce", "tp", "latent_mlp", "mix", "readout", "b_latent", "b_mix", "b_tp+reduce", "b_env", "b_embed", "finish"};
+    double tot = 0;
+    for (int k = 0; k < PX_N; ++k) tot += (double)hp[k];
+    std::fprintf(stderr, "[ahip fused_lx prof] wave-cycles by phase (sum over %d waves):", grid * NW);
+    for (int k = 0; k < PX_N; ++k) std::fprintf(stderr, " %s=%.1f%%", names[k], 100.0 * hp[k] / tot);
+    std::fprintf(stderr, " | total=%.3g cycles\n", tot);
+  }
+  return true;
+}
+
+void fusedlx_free(Model &m) {
+  if (!m.fusedlx_state) return;
+  FusedLxState *st = (FusedLxState *)m.fusedlx_state;
+  for (DevBuf *b : {&st->wbuf, &st->scratch, &st->seg_count, &st->seg_base, &st->tile_a0, &st->tile_e0, &st->centre, &st->ntiles, &st->partial, &st->prof}) b->release();
+  delete st;
+  m.fusedlx_state = nullptr;
+}
+
+}  // namespace ahip

@@ -31,6 +31,9 @@ hipError_t prim_max_i32(const int *in, int n, int *out, hipStream_t) {
 bool fused_model_supported(const Model &, std::string *why) { if (why) *why = "host emulation has no MFMA"; return false; }
 bool fused_run(Model &, const ComputeArgs &, std::string *why) { if (why) *why = "host emulation has no MFMA"; return false; }
 void fused_free(Model &) {}
+bool fusedlx_model_supported(const Model &, std::string *why) { if (why) *why = "host emulation has no MFMA"; return false; }
+bool fusedlx_run(Model &, const ComputeArgs &, std::string *why) { if (why) *why = "host emulation has no MFMA"; return false; }
+void fusedlx_free(Model &) {}
 bool edges_build_f32(Model &, const ComputeArgs &) { return false; }   // emulation runs the two-pass kernels
 void edges_free(Model &) {}
 bool gemm_f32(hipStream_t, long long, int, int, const float *, int, const float *, int, bool, float *, int, bool, float *, const float *) { return false; }

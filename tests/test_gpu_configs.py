@@ -79,8 +79,9 @@ def _full_size_properties(hip_lib, model_dir, cfg, cell, pos, mtype, masses, exp
         sim2 = md.Simulation(md.HipBackend(model, masses), np.diag(cell), cfg["r_max"], 1.0, pos, mtype, None, dev, overlap=True)
         sim2.setup()
         assert 0 < sim2.n_half < sim2.n_int < sim2.nlocal
-        assert np.abs(sim2.gather_forces() - f_by_tag).max() < 1e-8
-        np.testing.assert_allclose(sim2.thermo(masses)["pe"], pe, rtol=1e-9)
+        # (other atom order -> other neighbour order in the device-built list -> other float32 summation order)
+        assert np.abs(sim2.gather_forces() - f_by_tag).max() < 5e-6
+        np.testing.assert_allclose(sim2.thermo(masses)["pe"], pe, rtol=1e-7)
         model.close()
     return used
 

@@ -27,7 +27,8 @@ def test_device_neighbor_list_equals_host_list(hip_lib, model_dir):
     cell, pos, types = lmp_like.diamond_si(8)
     ref = util.run_pair(hip_lib, os.path.join(model_dir, "md_float32.ahip"), cell, pos, types, ["Si"])
     dev = torch.device("cuda", 0)
-    sim = md.Simulation(md.HipBackend(model, [MASS]), np.diag(cell), cfg["r_max"], 1.0, pos, np.zeros(len(pos), np.int32), None, dev)
+    sim = md.Simulation(md.HipBackend(model, [MASS]), np.diag(cell), cfg["r_max"], 1.0, pos, np.zeros(len(pos), np.int32), None, dev,
+                        overlap=False)                # one ahip_compute_dev call: get_edges() below returns all centres' edges
     sim.setup()
     f = sim.gather_forces()
     assert np.abs(f - ref["forces"]).max() < 2e-5
@@ -40,8 +41,8 @@ def test_device_neighbor_list_equals_host_list(hip_lib, model_dir):
     model.close()
 
 
-@pytest.mark.parametrize("path", ["fused", "generic"])
-def test_nve_energy_conservation(hip_lib, model_dir, path):
+@pytest.mark.parametrize("path,overlap", [("fused", False), ("fused", True), ("generic", False)])
+def test_nve_energy_conservation(hip_lib, model_dir, path, overlap):
     """50 NVE steps of 1728 Si atoms at 300 K: total energy drift << kinetic energy scale; forces drive real motion
     (rebuild logic exercised by a tiny skin)."""
     cfg, w, model = _model(model_dir, hip_lib)
@@ -50,7 +51,8 @@ def test_nve_energy_conservation(hip_lib, model_dir, path):
     n = len(pos)
     vel = md.maxwell_boltzmann(n, np.full(n, MASS), 300.0, 12345)
     dev = torch.device("cuda", 0)
-    sim = md.Simulation(md.HipBackend(model, [MASS]), np.diag(cell), cfg["r_max"], 0.3, pos, np.zeros(n, np.int32), vel, dev, dt=0.001)
+    sim = md.Simulation(md.HipBackend(model, [MASS]), np.diag(cell), cfg["r_max"], 0.3, pos, np.zeros(n, np.int32), vel, dev, dt=0.001,
+                        overlap=overlap)              # overlap: interior/boundary centre ranges + exchange on a second stream
     sim.setup()
     t0 = sim.thermo([MASS])
     e0 = t0["pe"] + t0["ke"]
@@ -76,7 +78,7 @@ def test_full_size_properties_1M(hip_lib, model_dir):
     cell, pos, _ = lmp_like.diamond_si(50)
     n = len(pos)
     dev = torch.device("cuda", 0)
-    sim = md.Simulation(md.HipBackend(model, [MASS]), np.diag(cell), cfg["r_max"], 1.0, pos, np.zeros(n, np.int32), None, dev)
+    sim = md.Simulation(md.HipBackend(model, [MASS]), np.diag(cell), cfg["r_max"], 1.0, pos, np.zeros(n, np.int32), None, dev, overlap=False)
     sim.setup()
     assert model.last_path == "fused_f32"
     ei, _ = model.get_edges()

@@ -136,7 +136,7 @@ void ahip_model_free(ahip_model *m) {
   if (m->rcut_model_dev) (void)hipFree(m->rcut_model_dev);
   for (DevBuf *b : {&m->b_ilist, &m->b_nloff, &m->b_nlj, &m->b_x, &m->b_ftype, &m->b_mtype, &m->b_f, &m->b_eatom,
                     &m->b_engvir, &m->b_cutsq, &m->b_cnt, &m->b_eoff, &m->b_eii, &m->b_ej, &m->b_rvec, &m->b_ett, &m->b_partial,
-                    &m->b_ws, &m->b_misc})
+                    &m->b_ws, &m->b_misc, &m->hv_eoff, &m->hv_eii, &m->hv_ej, &m->hv_rvec, &m->hv_ilist, &m->hv_engvir})
     b->release();
   for (auto &t : m->slots) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
   delete m;
@@ -294,6 +294,30 @@ static void collect_timings(ahip_model *m) {
   }
 }
 
+static __global__ void k_add7(double *dst, const double *src) { if (threadIdx.x < 7) dst[threadIdx.x] += src[threadIdx.x]; }
+
+// The few centres that do not fit a tile of the wide fused kernel: layer-at-a-time float32 kernels on a compact copy of their
+// edges; forces and per-atom energies accumulate into the same arrays, energy / virial partial sums are added.
+static void heavy_generic(ahip_model *m, const ComputeArgs &a) {
+  edges_compact_heavy(*m, a);
+  m->hv_engvir.reserve(8 * sizeof(double));
+  auto swap_in = [&]() {
+    std::swap(m->b_eoff, m->hv_eoff); std::swap(m->b_eii, m->hv_eii); std::swap(m->b_ej, m->hv_ej); std::swap(m->b_rvec, m->hv_rvec);
+  };
+  const int *il = m->d_ilist;
+  const int inum = m->inum;
+  const long long ne = m->nedges;
+  swap_in();
+  m->d_ilist = m->hv_ilist.as<int>();
+  m->inum = m->nheavy; m->nedges = m->hv_nedges;
+  ComputeArgs a2 = a;
+  a2.engvir = m->hv_engvir.as<double>();
+  try { generic_run<float>(*m, a2); }
+  catch (...) { swap_in(); m->d_ilist = il; m->inum = inum; m->nedges = ne; throw; }
+  swap_in(); m->d_ilist = il; m->inum = inum; m->nedges = ne;
+  hipLaunchKernelGGL(k_add7, dim3(1), dim3(64), 0, a.stream, a.engvir, a2.engvir);
+}
+
 static void run_model(ahip_model *m, const ComputeArgs &a) {
   AHIP_CHECK(hipMemsetAsync(a.engvir, 0, 7 * sizeof(double), a.stream));
   m->nedges = 0;
@@ -307,7 +331,9 @@ static void run_model(ahip_model *m, const ComputeArgs &a) {
     return;
   }
   m->have_ett = false;
-  if (!edges_build_f32(*m, a)) build_edges<float>(*m, a);
+  m->nheavy = 0;
+  m->heavy_thresh = (m->opt_path != "generic" && !fused_model_supported(*m, nullptr) && fusedlx_model_supported(*m, nullptr)) ? 64 : 0;
+  if (!edges_build_f32(*m, a)) { m->nheavy = 0; m->heavy_thresh = 0; build_edges<float>(*m, a); }
   std::string why;
   bool fused_ok = false;
   if (m->opt_path != "generic") {
@@ -319,7 +345,11 @@ static void run_model(ahip_model *m, const ComputeArgs &a) {
     }
     if (!fused_ok && m->opt_path == "fused") throw UnsupportedError("fused path unavailable: " + why);
   }
-  if (fused_ok) { m->last_path = "fused_f32"; return; }
+  if (fused_ok) {
+    if (m->nheavy > 0) heavy_generic(m, a);
+    m->last_path = "fused_f32";
+    return;
+  }
   generic_run<float>(*m, a);
   m->last_path = "generic_f32";
 }

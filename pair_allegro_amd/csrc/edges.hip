@@ -28,7 +28,8 @@ __global__ void __launch_bounds__(256) k_build_edges(int inum, const int *__rest
                                                        const int *__restrict__ ftype, const double *__restrict__ cutsq, int nft,
                                                        unsigned int *ticket, unsigned long long *status, int *eoff, int *e_ii,
                                                        int *e_j, float *rvec, int *maxdeg, int *overflow,
-                                                       const int *__restrict__ mtype, unsigned char *e_tt) {
+                                                       const int *__restrict__ mtype, unsigned char *e_tt, int heavy_thresh,
+                                                       int *heavy_cnt, int *heavy_list) {
   __shared__ int s_cnt[EB_ATOMS];
   __shared__ int s_base[EB_ATOMS + 1];
   __shared__ int s_blk;
@@ -86,7 +87,11 @@ __global__ void __launch_bounds__(256) k_build_edges(int inum, const int *__rest
       for (int c = 0; c < EB_CHUNKS; ++c) { jj[k][c] = 0; dxs[k][c] = dys[k][c] = dzs[k][c] = 0.f; rank[k][c] = -1; tts[k][c] = 0; }
     }
     kept_k[k] = kept;
-    if (lane == 0) s_cnt[la] = kept;
+    if (lane == 0) {
+      s_cnt[la] = kept;
+      // centres with more edges than a tile of the wide fused kernel holds: listed for the layer-at-a-time kernels
+      if (heavy_thresh > 0 && kept > heavy_thresh) heavy_list[atomicAdd(heavy_cnt, 1)] = ii;
+    }
   }
   __syncthreads();
 
@@ -152,7 +157,49 @@ __global__ void __launch_bounds__(256) k_build_edges(int inum, const int *__rest
   }
 }
 
-struct EdgeState { DevBuf flags; };
+struct EdgeState { DevBuf flags, heavy, hoff; };
+
+// ---- compact copy of the edges of the listed ("heavy") centres: the edge list the layer-at-a-time kernels run on ----
+static __global__ void k_heavy_offsets(int nh, const int *heavy, const int *eoff, int *hoff) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int acc = 0;
+    for (int k = 0; k < nh; ++k) { hoff[k] = acc; acc += eoff[heavy[k] + 1] - eoff[heavy[k]]; }
+    hoff[nh] = acc;
+  }
+}
+static __global__ void k_heavy_copy(int nh, const int *heavy, const int *ilist, const int *eoff, const int *e_j, const float *rvec,
+                                    const int *hoff, int *h_ilist, int *h_eii, int *h_ej, float *h_rvec) {
+  const int k = blockIdx.x;
+  if (k >= nh) return;
+  const int ii = heavy[k], e0 = eoff[ii], n = eoff[ii + 1] - e0, o = hoff[k];
+  if (threadIdx.x == 0) h_ilist[k] = ilist[ii];
+  for (int q = threadIdx.x; q < n; q += blockDim.x) {
+    h_eii[o + q] = k;
+    h_ej[o + q] = e_j[e0 + q];
+    h_rvec[3 * (size_t)(o + q)] = rvec[3 * (size_t)(e0 + q)];
+    h_rvec[3 * (size_t)(o + q) + 1] = rvec[3 * (size_t)(e0 + q) + 1];
+    h_rvec[3 * (size_t)(o + q) + 2] = rvec[3 * (size_t)(e0 + q) + 2];
+  }
+}
+
+void edges_compact_heavy(Model &m, const ComputeArgs &a) {
+  EdgeState &st = *(EdgeState *)m.edge_state;
+  const int nh = m.nheavy;
+  m.hv_eoff.reserve((size_t)(nh + 2) * sizeof(int));
+  m.hv_ilist.reserve((size_t)(nh + 1) * sizeof(int));
+  hipLaunchKernelGGL(k_heavy_offsets, dim3(1), dim3(64), 0, a.stream, nh, st.heavy.as<int>(), m.b_eoff.as<int>(), m.hv_eoff.as<int>());
+  int tot = 0;
+  AHIP_CHECK(hipMemcpyAsync(&tot, m.hv_eoff.as<int>() + nh, sizeof(int), hipMemcpyDeviceToHost, a.stream));
+  AHIP_CHECK(hipStreamSynchronize(a.stream));
+  m.hv_nedges = tot;
+  const size_t E = (size_t)std::max(tot, 1);
+  m.hv_eii.reserve(E * sizeof(int));
+  m.hv_ej.reserve(E * sizeof(int));
+  m.hv_rvec.reserve(E * 3 * sizeof(float));
+  hipLaunchKernelGGL(k_heavy_copy, dim3(nh), dim3(64), 0, a.stream, nh, st.heavy.as<int>(), m.d_ilist, m.b_eoff.as<int>(), m.b_ej.as<int>(),
+                     m.b_rvec.as<float>(), m.hv_eoff.as<int>(), m.hv_ilist.as<int>(), m.hv_eii.as<int>(), m.hv_ej.as<int>(), m.hv_rvec.as<float>());
+  AHIP_CHECK(hipGetLastError());
+}
 
 bool edges_build_f32(Model &m, const ComputeArgs &a) {
   StageTimer tm(m, "edge_build", a.stream);
@@ -160,7 +207,7 @@ bool edges_build_f32(Model &m, const ComputeArgs &a) {
   const int nblocks = (inum + EB_ATOMS - 1) / EB_ATOMS;
   if (!m.edge_state) m.edge_state = new EdgeState();
   EdgeState &st = *(EdgeState *)m.edge_state;
-  // header: [0] ticket (u32), [1] maxdeg, [2] overflow; status array starts at byte 64
+  // header: [0] ticket (u32), [1] maxdeg, [2] overflow, [3] number of heavy centres; status array starts at byte 64
   const size_t bytes = 64 + (size_t)nblocks * sizeof(unsigned long long);
   st.flags.reserve(bytes);
   AHIP_CHECK(hipMemsetAsync(st.flags.p, 0, bytes, a.stream));
@@ -172,18 +219,21 @@ bool edges_build_f32(Model &m, const ComputeArgs &a) {
   m.b_ett.reserve(cap);
   m.edges_T_size = 4;
   int *hdr = st.flags.as<int>();
+  if (m.heavy_thresh > 0) st.heavy.reserve((size_t)std::max(inum, 1) * sizeof(int));
   hipLaunchKernelGGL(k_build_edges, dim3(nblocks), dim3(256), 0, a.stream, inum, m.d_ilist, m.d_nloff, m.d_nlj, a.x, a.ftype,
                      a.cutsq, a.nft, (unsigned int *)hdr, (unsigned long long *)((char *)st.flags.p + 64), m.b_eoff.as<int>(),
-                     m.b_eii.as<int>(), m.b_ej.as<int>(), m.b_rvec.as<float>(), hdr + 1, hdr + 2, a.mtype, m.b_ett.as<unsigned char>());
+                     m.b_eii.as<int>(), m.b_ej.as<int>(), m.b_rvec.as<float>(), hdr + 1, hdr + 2, a.mtype, m.b_ett.as<unsigned char>(),
+                     m.heavy_thresh, hdr + 3, st.heavy.as<int>());
   AHIP_CHECK(hipGetLastError());
-  int h3[3] = {0, 0, 0}, tot = 0;
+  int h3[4] = {0, 0, 0, 0}, tot = 0;
   // the scalar read-back per step (the Kokkos path has the same one: pair_nequip_allegro_kokkos.cpp:203-206)
-  AHIP_CHECK(hipMemcpyAsync(h3, hdr, 3 * sizeof(int), hipMemcpyDeviceToHost, a.stream));
+  AHIP_CHECK(hipMemcpyAsync(h3, hdr, 4 * sizeof(int), hipMemcpyDeviceToHost, a.stream));
   AHIP_CHECK(hipMemcpyAsync(&tot, m.b_eoff.as<int>() + inum, sizeof(int), hipMemcpyDeviceToHost, a.stream));
   AHIP_CHECK(hipStreamSynchronize(a.stream));
   if (h3[2] != 0) return false;                     // a row longer than 128 entries: caller uses the two-pass kernels
   m.nedges = tot;
   m.last_max_deg = h3[1];
+  m.nheavy = m.heavy_thresh > 0 ? h3[3] : 0;
   m.have_ett = true;
   return true;
 }
@@ -192,6 +242,8 @@ void edges_free(Model &m) {
   if (!m.edge_state) return;
   EdgeState *st = (EdgeState *)m.edge_state;
   st->flags.release();
+  st->heavy.release();
+  st->hoff.release();
   delete st;
   m.edge_state = nullptr;
 }

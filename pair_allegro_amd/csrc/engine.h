@@ -120,6 +120,12 @@ struct Model {
   int last_max_deg = 0;
   std::string last_path;
 
+  // Centres with more edges than a tile of the wide fused kernel holds (fused_lx.hip): found by the edge build when
+  // heavy_thresh > 0, evaluated by the layer-at-a-time kernels on a compact copy of their edges (hv_*)
+  int heavy_thresh = 0, nheavy = 0;
+  long long hv_nedges = 0;
+  DevBuf hv_eoff, hv_eii, hv_ej, hv_rvec, hv_ilist, hv_engvir;
+
   // `compute allegro`: registered output names and their values from the last host-path compute
   std::vector<std::string> custom_names;
   std::map<std::string, std::vector<double>> custom_out;
@@ -190,6 +196,8 @@ void fusedlx_free(Model &m);
 // row is too long for the register-resident version and the caller must run the two-pass kernels.
 bool edges_build_f32(Model &m, const ComputeArgs &a);
 void edges_free(Model &m);
+// compact copy (m.hv_*) of the edges of the m.nheavy centres the last edges_build_f32 listed
+void edges_compact_heavy(Model &m, const ComputeArgs &a);
 
 // ---- float32 dense layers of the generic path on the matrix cores (gemm.hip; the host-emulation build links a stub
 // returning false and keeps the one-thread-per-output kernels) ----

@@ -27,11 +27,19 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 
 // 16-byte buffer accesses: wave-uniform descriptor + scalar byte offset + per-lane byte offset
+// cache policy of the saved-row traffic (aux bits of the buffer instructions; 2 = nt: stream through L2 without displacing the
+// weight stream, which every CU re-reads); the including kernel may define it before this header
+#ifndef AHIP_ROW_AUX
+#define AHIP_ROW_AUX 0
+#endif
 __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AHIP_ROW_AUX));
 }
 __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, int voff, int soff, f32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, AHIP_ROW_AUX);
+}
+__device__ __forceinline__ f32x4 bload_w(__amdgpu_buffer_rsrc_t r, int voff, int soff) {        // weight fragments: default policy
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
 __device__ __forceinline__ float sigmoidf_fast(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
@@ -131,8 +139,8 @@ __device__ __forceinline__ void linear_s(__amdgpu_buffer_rsrc_t W, int &wp, cons
       else { acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
     const f32x4 a0 = ring[(RP + 2 * s) % RING], a1 = ring[(RP + 2 * s + 1) % RING];
-    ring[(RP + 2 * s) % RING] = bload(W, v16, (wp + (2 * s + RING) * 256) * 4);
-    ring[(RP + 2 * s + 1) % RING] = bload(W, v16, (wp + (2 * s + RING + 1) * 256) * 4);
+    ring[(RP + 2 * s) % RING] = bload_w(W, v16, (wp + (2 * s + RING) * 256) * 4);
+    ring[(RP + 2 * s + 1) % RING] = bload_w(W, v16, (wp + (2 * s + RING + 1) * 256) * 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -167,7 +175,7 @@ __device__ __forceinline__ void linear_s(__amdgpu_buffer_rsrc_t W, int &wp, cons
 // first RING fragments of the stream at wp into the ring
 __device__ __forceinline__ void ring_prime(__amdgpu_buffer_rsrc_t W, int wp, int v16, f32x4 (&ring)[RING]) {
 #pragma unroll
-  for (int j = 0; j < RING; ++j) ring[j] = bload(W, v16, (wp + j * 256) * 4);
+  for (int j = 0; j < RING; ++j) ring[j] = bload_w(W, v16, (wp + j * 256) * 4);
 }
 
 __device__ __forceinline__ float gsum(float v) {       // sum over the 4 lanes (groups) that share one edge

@@ -24,6 +24,9 @@
 #include <cstring>
 
 #include "../../include/allegro_hip.h"
+#ifndef AHIP_ROW_AUX
+#define AHIP_ROW_AUX 2          // saved rows: non-temporal (fused_common.h)
+#endif
 #include "cg_tables.h"
 #include "engine.h"
 #include "fused_common.h"
@@ -94,86 +97,151 @@ template <int L, int UT, int NW> struct __attribute__((aligned(16))) LdsX {
   int chunk[2];
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// scalar f32 helpers on 2-feature half rows: component indices written out (v_fmac_f32 with the CG constant as an inline
+// literal; packed f32 would hold every constant in an SGPR pair and the kernel runs out of SGPRs)
+#ifdef AHIP_LX_SCALAR_TP
+__device__ __forceinline__ f32x2 fma_cab(float c, const f32x2 &a, const f32x2 &b, const f32x2 &acc) {      // acc + c * (a * b)
+  f32x2 r;
+  r[0] = fmaf(c, a[0] * b[0], acc[0]); r[1] = fmaf(c, a[1] * b[1], acc[1]);
+  return r;
+}
+__device__ __forceinline__ f32x2 fma_cgo(float c, const f32x2 &gq, const f32x2 &o, const f32x2 &acc) {    // acc + (c * g) * o
+  f32x2 r;
+  r[0] = fmaf(c * gq[0], o[0], acc[0]); r[1] = fmaf(c * gq[1], o[1], acc[1]);
+  return r;
+}
+__device__ __forceinline__ f32x2 fma_rows(const f32x2 &a, const f32x2 &b, const f32x2 &acc) {              // acc + a * b
+  f32x2 r;
+  r[0] = fmaf(a[0], b[0], acc[0]); r[1] = fmaf(a[1], b[1], acc[1]);
+  return r;
+}
+__device__ __forceinline__ f32x2 mul_rows(const f32x2 &a, const f32x2 &b) {
+  f32x2 r;
+  r[0] = a[0] * b[0]; r[1] = a[1] * b[1];
+  return r;
+}
+#else
+// packed f32 (v_pk_mul_f32 / v_pk_fma_f32): a lone wave on a SIMD issues one instruction per 4 cycles whatever it is, so the
+// two-feature packed forms halve the tensor product's issue time
+__device__ __forceinline__ f32x2 fma_cab(float c, const f32x2 &a, const f32x2 &b, const f32x2 &acc) { return acc + c * (a * b); }
+__device__ __forceinline__ f32x2 fma_cgo(float c, const f32x2 &gq, const f32x2 &o, const f32x2 &acc) { return acc + (c * gq) * o; }
+__device__ __forceinline__ f32x2 fma_rows(const f32x2 &a, const f32x2 &b, const f32x2 &acc) { return acc + a * b; }
+__device__ __forceinline__ f32x2 mul_rows(const f32x2 &a, const f32x2 &b) { return a * b; }
+#endif
+
 // ---------------------------------------------------------------------------- tensor product, CG table unrolled
-// out[i3] += pw[path] * c * v[i1] * e[i2] over the table entries; every index is a compile-time constant.
+// The tensor product is element-wise over features, so it is evaluated on HALF rows (2 of the lane's 4 features of a K-tile)
+// at a time: the row sets it keeps live (inputs, environment, outputs) are half as large, which is what lets the whole edge
+// tensor stay in registers next to them.
+// out[i3] += pw[path] * c * v[i1] * e[i2] over the table entries; every index is a compile-time constant.  The table is sorted
+// by path: the entries of one path accumulate (CG constants as literals) into at most 2 l3 + 1 partial rows, which are scaled
+// by the path weight once: two VALU operations per entry and feature.
 template <int L, bool SCALAR, int U>
-__device__ __forceinline__ void tp_fwd_x(const f32x4 (&v)[(L + 1) * (L + 1)], const float *en, const float *tp,
-                                         f32x4 (&out)[SCALAR ? 1 : (L + 1) * (L + 1)]) {
-  constexpr int D = (L + 1) * (L + 1), DOUT = SCALAR ? 1 : D, N = SCALAR ? CgX<L>::NS : CgX<L>::N, NP = SCALAR ? CgX<L>::NPS : CgX<L>::NP;
-  (void)NP;
-  f32x4 ee[D];
+__device__ __forceinline__ void tp_fwd_x(const f32x2 (&v)[(L + 1) * (L + 1)], const float *en, const float *tp,
+                                         f32x2 (&out)[SCALAR ? 1 : (L + 1) * (L + 1)]) {
+  constexpr int D = (L + 1) * (L + 1), DOUT = SCALAR ? 1 : D, N = SCALAR ? CgX<L>::NS : CgX<L>::N;
+  f32x2 ee[D];
 #pragma unroll
-  for (int k = 0; k < D; ++k) ee[k] = *(const f32x4 *)(en + k * U);
+  for (int k = 0; k < D; ++k) ee[k] = *(const f32x2 *)(en + k * U);
 #pragma unroll
-  for (int k = 0; k < DOUT; ++k) out[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // The table is sorted by path: the entries of one path accumulate (CG constants as literals) into at most 2 l3 + 1 partial
-  // rows, which are scaled by the path weight once -- few live registers, two VALU operations per entry and feature.
-  f32x4 acc[2 * L + 1];
+  for (int k = 0; k < DOUT; ++k) out[k] = f32x2{0.f, 0.f};
+  f32x2 acc[2 * L + 1];
 #pragma unroll
   for (int q = 0; q < N; ++q) {
     constexpr const AhipCgEntry *tab = CgX<L>::tab;
     const int p = tab[q].path, l3 = l_of_lm(tab[q].i3), b3 = l3 * l3;
     if (q == 0 || tab[q - 1].path != p) {
 #pragma unroll
-      for (int k = 0; k < 2 * L + 1; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < 2 * L + 1; ++k) acc[k] = f32x2{0.f, 0.f};
     }
-    acc[tab[q].i3 - b3] += (float)tab[q].c * (v[tab[q].i1] * ee[tab[q].i2]);
+    acc[tab[q].i3 - b3] = fma_cab((float)tab[q].c, v[tab[q].i1], ee[tab[q].i2], acc[tab[q].i3 - b3]);
     if (q == N - 1 || tab[q + 1].path != p) {
-      const f32x4 pw = *(const f32x4 *)(tp + p * U);
+      const f32x2 pw = *(const f32x2 *)(tp + p * U);
 #pragma unroll
       for (int k = 0; k < 2 * L + 1; ++k)
-        if (k < 2 * l3 + 1) out[b3 + k] += pw * acc[k];
+        if (k < 2 * l3 + 1) out[b3 + k] = fma_rows(pw, acc[k], out[b3 + k]);
+      __builtin_amdgcn_sched_barrier(0);       // one path at a time: bounds the live products
     }
   }
 }
-// a[i1] += pw c g[i3] e[i2]  (gradient w.r.t. the edge tensor);  b[i2] += pw c g[i3] v[i1]  (w.r.t. the environment)
-template <int L, bool SCALAR, int U>
-__device__ __forceinline__ void tp_bwd_x(const f32x4 (&v)[(L + 1) * (L + 1)], const float *en, const float *tp,
-                                         const f32x4 (&g)[SCALAR ? 1 : (L + 1) * (L + 1)], f32x4 (&a)[(L + 1) * (L + 1)],
-                                         f32x4 (&b)[(L + 1) * (L + 1)]) {
-  constexpr int D = (L + 1) * (L + 1), N = SCALAR ? CgX<L>::NS : CgX<L>::N, NP = SCALAR ? CgX<L>::NPS : CgX<L>::NP;
-  (void)NP;
-  f32x4 ee[D];
+// Gradient of the tensor product, as two passes over the table so that each pass keeps three row sets live instead of five:
+//   which = 0:  r[i1] += pw c g[i3] o[i2]   with o = environment rows (from LDS)     -> gradient w.r.t. the edge tensor
+//   which = 1:  r[i2] += pw c g[i3] o[i1]   with o = edge tensor rows (registers)   -> per-edge environment gradient
+// per path the output-gradient rows are scaled by the path weight once; two VALU operations per entry and feature.
+template <int L, bool SCALAR, int U, int WHICH>
+__device__ __forceinline__ void tp_bwd_half(const f32x2 (&o)[(L + 1) * (L + 1)], const f32x2 (&pw)[CgX<L>::NP],
+                                            const f32x2 (&g)[SCALAR ? 1 : (L + 1) * (L + 1)], f32x2 (&r)[(L + 1) * (L + 1)]) {
+  constexpr int D = (L + 1) * (L + 1), N = SCALAR ? CgX<L>::NS : CgX<L>::N;
 #pragma unroll
-  for (int k = 0; k < D; ++k) { ee[k] = *(const f32x4 *)(en + k * U); a[k] = f32x4{0.f, 0.f, 0.f, 0.f}; b[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  // per path: the output-gradient rows scaled by the path weight once, then three VALU operations per entry and feature
-  f32x4 gp[2 * L + 1];
+  for (int k = 0; k < D; ++k) r[k] = f32x2{0.f, 0.f};
+  f32x2 gp[2 * L + 1];
 #pragma unroll
   for (int q = 0; q < N; ++q) {
     constexpr const AhipCgEntry *tab = CgX<L>::tab;
     const int p = tab[q].path, l3 = l_of_lm(tab[q].i3), b3 = l3 * l3;
     if (q == 0 || tab[q - 1].path != p) {
-      const f32x4 pw = *(const f32x4 *)(tp + p * U);
 #pragma unroll
       for (int k = 0; k < 2 * L + 1; ++k)
-        if (k < 2 * l3 + 1) gp[k] = pw * g[SCALAR ? 0 : b3 + k];
+        if (k < 2 * l3 + 1) gp[k] = mul_rows(pw[p], g[SCALAR ? 0 : b3 + k]);
     }
-    const f32x4 wv = (float)tab[q].c * gp[tab[q].i3 - b3];
-    a[tab[q].i1] += wv * ee[tab[q].i2];
-    b[tab[q].i2] += wv * v[tab[q].i1];
+    if (WHICH == 0) r[tab[q].i1] = fma_cgo((float)tab[q].c, gp[tab[q].i3 - b3], o[tab[q].i2], r[tab[q].i1]);
+    else r[tab[q].i2] = fma_cgo((float)tab[q].c, gp[tab[q].i3 - b3], o[tab[q].i1], r[tab[q].i2]);
+    if (q == N - 1 || tab[q + 1].path != p) __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+// The edge tensor lives in the ACCUMULATOR half of the unified register file (AGPRs): its 144 registers then do not compete
+// with the arithmetic VGPRs in the register allocator.  A value is parked with v_accvgpr_write (inline asm: there is no
+// builtin); reads are plain uses, the compiler inserts v_accvgpr_read.  No MFMA reads a parked value within the next
+// instructions (every park is followed by VALU / memory work), so the asm needs no wait states of its own.
+__device__ __forceinline__ float acc_park(float x) {
+  float a;
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(x));
+  return a;
+}
+__device__ __forceinline__ void acc_put4(float (&dst)[4], const f32x4 &v) {
+  dst[0] = acc_park(v[0]); dst[1] = acc_park(v[1]); dst[2] = acc_park(v[2]); dst[3] = acc_park(v[3]);
+}
+__device__ __forceinline__ void acc_put2(float (&dst)[4], int h, const f32x2 &v) {
+  if (h == 0) { dst[0] = acc_park(v[0]); dst[1] = acc_park(v[1]); } else { dst[2] = acc_park(v[0]); dst[3] = acc_park(v[1]); }
+}
+__device__ __forceinline__ f32x4 acc_get4(const float (&src)[4]) { return f32x4{src[0], src[1], src[2], src[3]}; }
+__device__ __forceinline__ f32x2 acc_get2(const float (&src)[4], int h) { return h == 0 ? f32x2{src[0], src[1]} : f32x2{src[2], src[3]}; }
+
+__device__ __forceinline__ f32x2 half_of(const f32x4 &v, int h) { return h == 0 ? f32x2{v[0], v[1]} : f32x2{v[2], v[3]}; }
+__device__ __forceinline__ void set_half(f32x4 &v, int h, const f32x2 &x) { if (h == 0) { v[0] = x[0]; v[1] = x[1]; } else { v[2] = x[0]; v[3] = x[1]; } }
+// 8-byte half of a saved row image (row = [lane][4 floats])
+__device__ __forceinline__ f32x2 bload_half(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AHIP_ROW_AUX));
 }
 
 __device__ __forceinline__ float hsum4(const f32x4 &v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 
 // Per-centre sum of one staged K-tile: env[a][lm][16 t + f] = scale * sum_{slots of a} stage[slot][lm][f].
+// Two adjacent lanes share an output (even / odd slots) and combine with one cross-lane add: 2 * na * D * 16 work items.
 template <int L, int UT, int NW>
 __device__ __forceinline__ void reduce_stage_x(const float *stg, const int *aoff, float *dst, int na, float scale, int t, int tid) {
   using S = ShapeX<L, UT, NW>;
   constexpr int PER = S::D * 16;
-  for (int o = tid; o < na * PER; o += NW * 64) {
-    const int a = o / PER, r = o - a * PER;
-    const int s0 = aoff[a], s1 = aoff[a + 1];
+  const int part = tid & 1;
+  for (int o = tid >> 1; o < ((na * PER + 127) & ~127); o += NW * 32) {       // whole waves keep iterating together (shuffle below)
+    const bool live = o < na * PER;
+    const int a = live ? o / PER : 0, r = live ? o - a * PER : 0;
+    const int s0 = aoff[a] + part, s1 = live ? aoff[a + 1] : 0;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     int sl = s0;
-    for (; sl + 4 <= s1; sl += 4) {
+    for (; sl + 6 < s1; sl += 8) {
       acc0 += stg[sl * S::STG_LD + r];
-      acc1 += stg[(sl + 1) * S::STG_LD + r];
-      acc2 += stg[(sl + 2) * S::STG_LD + r];
-      acc3 += stg[(sl + 3) * S::STG_LD + r];
+      acc1 += stg[(sl + 2) * S::STG_LD + r];
+      acc2 += stg[(sl + 4) * S::STG_LD + r];
+      acc3 += stg[(sl + 6) * S::STG_LD + r];
     }
-    for (; sl < s1; ++sl) acc0 += stg[sl * S::STG_LD + r];
-    dst[a * S::ENVA + (r >> 4) * S::U + 16 * t + (r & 15)] = scale * ((acc0 + acc1) + (acc2 + acc3));
+    for (; sl < s1; sl += 2) acc0 += stg[sl * S::STG_LD + r];
+    float sum = (acc0 + acc1) + (acc2 + acc3);
+    sum += __shfl_xor(sum, 1, 64);
+    if (live && part == 0) dst[a * S::ENVA + (r >> 4) * S::U + 16 * t + (r & 15)] = scale * sum;
   }
 }
 
@@ -181,7 +249,9 @@ enum { PX_GEOM = 0, PX_EMB, PX_ENV, PX_TP, PX_LAT, PX_MIX, PX_OUT, PX_BLAT, PX_B
 #define PHASEX(id) do { if (PROF) { long long _t = clock64(); pacc[id] += _t - tprev; tprev = _t; } } while (0)
 
 // ---------------------------------------------------------------------------- the kernel
-template <int L, int UT, int NW, bool PROF>
+// NLT = number of layers: the layer loops are unrolled so that `last layer` / `first layer` are compile-time facts -- with
+// run-time branches inside them the register allocator shuffles dozens of spill slots at every join (load, wait, store).
+template <int L, int UT, int NW, int NLT, bool PROF>
 __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
   using S = ShapeX<L, UT, NW>;
   constexpr int NTHREADS = NW * 64, D = S::D, U = S::U, EW = S::EW, MAXA = S::MAXA, STG_LD = S::STG_LD, ENVA = S::ENVA, NP = S::NP;
@@ -196,7 +266,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
     WB = __builtin_amdgcn_make_buffer_rsrc((void *)A.wbase, 0, A.wbytes, 0x00020000);
   }
   const float *__restrict__ Wb = A.wbase;
-  const int NL = A.NL;
+  constexpr int NL = NLT;
   for (int k = tid; k < NL * NP * U; k += NTHREADS) lds.tp[k / (NP * U)][k % (NP * U)] = Wb[A.o_tpl + k];
   const int ntiles = *A.ntiles;
   double acc_part = 0.0;
@@ -230,6 +300,14 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
     if (ck == 0 && tid == 0) claimed = (int)atomicAdd(A.tile_counter, (unsigned)TCHUNK);
     const int a0 = A.tile_a0[tile], a1 = A.tile_a0[tile + 1], e0 = A.tile_e0[tile], e1 = A.tile_e0[tile + 1];
     const int na = a1 - a0;
+    if (e1 - e0 > S::SLOTS) {
+      // a single centre with more edges than the tile has slots (the packing gives such a centre a tile of its own): it is
+      // evaluated by the layer-at-a-time kernels afterwards (heavy_generic, allegro_hip.hip)
+      if (ck == 0 && tid == 0) lds.chunk[cpar ^ 1] = claimed;
+      __syncthreads();
+      if (++ck == TCHUNK) { ck = 0; cpar ^= 1; cbase = __builtin_amdgcn_readfirstlane(lds.chunk[cpar]); }
+      continue;
+    }
     par ^= 1;
     int *const aoffp = lds.aoff[par];
     const int e = e0 + s;
@@ -287,20 +365,21 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
       }
     }
     // ---------------- tensor embedding V^0[lm][u] = w0[l][u] Y[lm] ----------------
-    f32x4 V[D][UT];          // the edge tensor, forward; its gradient, backward
+    float V[D][UT][4];       // the edge tensor, forward; its gradient, backward: parked in AGPRs (acc_park)
     {
       f32x4 w0[EW];
       linear_s<4, EW, false, 0>(WB, wp, x, w0, v16, ring, EpiSave{SB, S::R_W0, v16});
 #pragma unroll
       for (int lm = 0; lm < D; ++lm)
 #pragma unroll
-        for (int t = 0; t < UT; ++t) V[lm][t] = lm == 0 ? w0[t] : w0[l_of_lm(lm) * UT + t] * Y[lm];
+        for (int t = 0; t < UT; ++t) acc_put4(V[lm][t], lm == 0 ? w0[t] : w0[l_of_lm(lm) * UT + t] * Y[lm]);
     }
     if (ck == 0 && tid == 0) lds.chunk[cpar ^ 1] = claimed;
     __syncthreads();          // aoff visible; previous tile's LDS users done
     PHASEX(PX_EMB);
 
     // ---------------- layers, forward ----------------
+#pragma unroll
     for (int kk = 0; kk < NL; ++kk) {
       const bool last = (kk == NL - 1);
       const int RL = S::R_LAYER(kk);
@@ -309,6 +388,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
         f32x4 om[EW];
         linear_s<4, EW, false, 0>(WB, wp, x, om, v16, ring, EpiSave{SB, RL + S::O_OM, v16});
         // environment sum over the centre's edges, one K-tile at a time through the double-buffered stage
+#ifndef ABL_NO_ENVSTAGE
 #pragma unroll
         for (int t = 0; t < UT; ++t) {
           float *const sp = (t & 1) ? st1 : st0;
@@ -318,6 +398,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
           reduce_stage_x<L, UT, NW>(lds.stage[t & 1], aoffp, envk, na, A.cenv, t, tid);
           __builtin_amdgcn_sched_barrier(0);
         }
+#endif
         __syncthreads();
       }
       PHASEX(PX_ENV);
@@ -326,32 +407,44 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
       {
         const float *en = envk + envoff;
         const float *tp = lds.tp[kk] + 4 * g;
+#ifndef ABL_NO_FTP
         if (!last) {
 #pragma unroll
           for (int t = 0; t < UT; ++t) {
-            f32x4 vin[D], out[D];
 #pragma unroll
-            for (int lm = 0; lm < D; ++lm) vin[lm] = V[lm][t];
-            tp_fwd_x<L, false, U>(vin, en + 16 * t, tp + 16 * t, out);
+            for (int h = 0; h < 2; ++h) {
+              f32x2 vin[D], out[D];
 #pragma unroll
-            for (int lm = 0; lm < D; ++lm) V[lm][t] = out[lm];
-            sc[t] = out[0];
-            __builtin_amdgcn_sched_barrier(0);
+              for (int lm = 0; lm < D; ++lm) vin[lm] = acc_get2(V[lm][t], h);
+              tp_fwd_x<L, false, U>(vin, en + 16 * t + 2 * h, tp + 16 * t + 2 * h, out);
+#pragma unroll
+              for (int lm = 0; lm < D; ++lm) acc_put2(V[lm][t], h, out[lm]);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            sc[t] = acc_get4(V[0][t]);
           }
         } else {
 #pragma unroll
           for (int t = 0; t < UT; ++t) {
-            f32x4 vin[D], out[1];
 #pragma unroll
-            for (int lm = 0; lm < D; ++lm) vin[lm] = V[lm][t];
-            tp_fwd_x<L, true, U>(vin, en + 16 * t, tp + 16 * t, out);
-            sc[t] = out[0];
-            __builtin_amdgcn_sched_barrier(0);
+            for (int h = 0; h < 2; ++h) {
+              f32x2 vin[D], out[1];
+#pragma unroll
+              for (int lm = 0; lm < D; ++lm) vin[lm] = acc_get2(V[lm][t], h);
+              tp_fwd_x<L, true, U>(vin, en + 16 * t + 2 * h, tp + 16 * t + 2 * h, out);
+              set_half(sc[t], h, out[0]);
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
         }
+#else
+#pragma unroll
+        for (int t = 0; t < UT; ++t) sc[t] = acc_get4(V[0][t]) * *(const f32x4 *)(en + 16 * t) * *(const f32x4 *)(tp + 16 * t);
+#endif
       }
       PHASEX(PX_TP);
       // latent MLP on [x, scalars]
+#ifndef ABL_NO_LAT
       {
         f32x4 cat[4 + UT], z[4], z2[4];
 #pragma unroll
@@ -366,22 +459,35 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) x[t] = xn[t];
       }
+#else
+      x[0] += sc[0]; x[1] += sc[1]; x[2] += sc[2]; x[3] += sc[3];
+#endif
       PHASEX(PX_LAT);
       // channel mixing, in place per (l, m) row -> V^{kk+1}, saved as the next layer's V_in rows
+#ifndef ABL_NO_MIX
       if (!last) {
 #pragma unroll
         for (int lm = 0; lm < D; ++lm) {
-          f32x4 o[UT];
-          linear_s<UT, UT, false, 0>(WB, wp, V[lm], o, v16, ring, EpiSave{SB, S::R_LAYER(kk + 1) + S::O_VIN + lm * UT, v16});
+          f32x4 vi[UT], o[UT];
 #pragma unroll
-          for (int t = 0; t < UT; ++t) V[lm][t] = o[t];
+          for (int t = 0; t < UT; ++t) vi[t] = acc_get4(V[lm][t]);
+          linear_s<UT, UT, false, 0>(WB, wp, vi, o, v16, ring, EpiSave{SB, S::R_LAYER(kk + 1) + S::O_VIN + lm * UT, v16});
+#pragma unroll
+          for (int t = 0; t < UT; ++t) acc_put4(V[lm][t], o[t]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+#endif
       PHASEX(PX_MIX);
     }
 
     // ---------------- read-out ----------------
+    // saved rows are requested well ahead of their first use all through the backward pass (their round trip is an L2 miss:
+    // 1-2 us, and with one wave per SIMD nothing else covers it): u and silu'(z2) of the last layer under the read-out MFMAs
+    f32x4 upre[4], zt[4], w0pre[L * UT];
+    load_rows<4>(SB, S::R_LAYER(NL - 1) + S::O_U, upre, v16);
+    load_rows<4>(SB, S::R_LAYER(NL - 1) + S::O_Z2, zt, v16);
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 zr[2];
     linear_s<4, 2, false, 0>(WB, wp, x, zr, v16, ring, EpiNone{});
     f32x4 wo1[2];
@@ -411,29 +517,27 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
     for (int lm = 0; lm < D; ++lm) dY[lm] = 0.f;
     PHASEX(PX_OUT);
 
+#pragma unroll
     for (int kk = NL - 1; kk >= 0; --kk) {
       const bool last = (kk == NL - 1);
       const int RL = S::R_LAYER(kk);
       f32x4 ds[UT];
       {
-        f32x4 du[4], dh[4], rows[4];
-        load_rows<4>(SB, RL + S::O_U, rows, v16);
+        f32x4 du[4], dh[4];
+        f32x4 rows1[4];
+        load_rows<4>(SB, RL + S::O_Z1, rows1, v16);            // silu'(z1): first used one linear from here
+        __builtin_amdgcn_sched_barrier(0);
         {
           const float ra = lds.res[kk][0], rb = lds.res[kk][1];
-          f32x4 accv = rows[0] * dx[0];
+          f32x4 accv = upre[0] * dx[0];
 #pragma unroll
-          for (int t = 1; t < 4; ++t) accv += rows[t] * dx[t];
+          for (int t = 1; t < 4; ++t) accv += upre[t] * dx[t];
           const float rbfc = rb * fc;
 #pragma unroll
           for (int t = 0; t < 4; ++t) { du[t] = rbfc * dx[t]; dx[t] = ra * dx[t]; }
           dfc_part += rb * hsum4(accv);
         }
-        load_rows<4>(SB, RL + S::O_Z2, rows, v16);
-        __builtin_amdgcn_sched_barrier(0);
-        linear_s<4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{rows});
-        f32x4 rows1[4];
-        load_rows<4>(SB, RL + S::O_Z1, rows1, v16);
-        __builtin_amdgcn_sched_barrier(0);
+        linear_s<4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt});
         linear_s<4, 4, false, 0>(WB, wp, dh, du, v16, ring, EpiMulRows<4>{rows1});
         f32x4 dcat[4 + UT];
         linear_s<4, 4 + UT, false, 0>(WB, wp, du, dcat, v16, ring, EpiNone{});
@@ -447,10 +551,12 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
       if (!last) {
 #pragma unroll
         for (int lm = 0; lm < D; ++lm) {
-          f32x4 o[UT];
-          linear_s<UT, UT, false, 0>(WB, wp, V[lm], o, v16, ring, EpiNone{});
+          f32x4 vi[UT], o[UT];
 #pragma unroll
-          for (int t = 0; t < UT; ++t) V[lm][t] = lm == 0 ? o[t] + ds[t] : o[t];
+          for (int t = 0; t < UT; ++t) vi[t] = acc_get4(V[lm][t]);
+          linear_s<UT, UT, false, 0>(WB, wp, vi, o, v16, ring, EpiNone{});
+#pragma unroll
+          for (int t = 0; t < UT; ++t) acc_put4(V[lm][t], lm == 0 ? o[t] + ds[t] : o[t]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -459,48 +565,77 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
       {
         const float *en = lds.env[kk] + envoff;
         const float *tp = lds.tp[kk] + 4 * g;
-#pragma unroll
-        for (int t = 0; t < UT; ++t) {
-          f32x4 vin[D], a[D], b[D];
+        // the saved input rows V^{kk}[.][t] (w0 rows for the first layer) of half pass (t, h) are requested one half pass
+        // ahead: their round trip (L2 miss: 1-2 us) runs under the previous half pass
+        f32x2 vpre[D];
+        f32x4 omall[L * UT];      // omega rows of l >= 1 (all K-tiles) for the step after this one: requested before the last reduction
+        auto request_vin = [&](int t, int h) {
           if (kk > 0) {
 #pragma unroll
-            for (int lm = 0; lm < D; ++lm) vin[lm] = bload(SB, v16, (RL + S::O_VIN + lm * UT + t) * ROW * 4);
+            for (int lm = 0; lm < D; ++lm) vpre[lm] = bload_half(SB, v16 + 8 * h, (RL + S::O_VIN + lm * UT + t) * ROW * 4);
           } else {
-            f32x4 w0r[L + 1];
 #pragma unroll
-            for (int l = 0; l <= L; ++l) w0r[l] = bload(SB, v16, (S::R_W0 + l * UT + t) * ROW * 4);
-#pragma unroll
-            for (int lm = 0; lm < D; ++lm) vin[lm] = lm == 0 ? w0r[0] : w0r[l_of_lm(lm)] * Y[lm];
+            for (int l = 0; l <= L; ++l) vpre[l] = bload_half(SB, v16 + 8 * h, (S::R_W0 + l * UT + t) * ROW * 4);
           }
-          if (!last) {
-            f32x4 gg[D];
+        };
+        request_vin(0, 0);
 #pragma unroll
-            for (int lm = 0; lm < D; ++lm) gg[lm] = V[lm][t];
-            tp_bwd_x<L, false, U>(vin, en + 16 * t, tp + 16 * t, gg, a, b);
-          } else {
-            f32x4 gg[1];
-            gg[0] = ds[t];
-            tp_bwd_x<L, true, U>(vin, en + 16 * t, tp + 16 * t, gg, a, b);
-          }
+        for (int t = 0; t < UT; ++t) {
           float *const sp = (t & 1) ? st1 : st0;
 #pragma unroll
-          for (int lm = 0; lm < D; ++lm) { V[lm][t] = a[lm]; *(f32x4 *)(sp + lm * 16) = b[lm]; }
+          for (int h = 0; h < 2; ++h) {
+            f32x2 vin[D], a[D], b[D], ee[D];
+#pragma unroll
+            for (int lm = 0; lm < D; ++lm) vin[lm] = vpre[lm];
+            __builtin_amdgcn_sched_barrier(0);
+            if (2 * t + h + 1 < 2 * UT) request_vin(h == 1 ? t + 1 : t, h ^ 1);
+#pragma unroll
+            for (int lm = 0; lm < D; ++lm) ee[lm] = *(const f32x2 *)(en + 16 * t + 2 * h + lm * U);
+            f32x2 pwh[NP];          // path weights of this half pass: one batch of LDS reads, one wait
+#pragma unroll
+            for (int pth = 0; pth < NP; ++pth) pwh[pth] = *(const f32x2 *)(tp + 16 * t + 2 * h + pth * U);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!last) {
+              f32x2 gg[D];
+#pragma unroll
+              for (int lm = 0; lm < D; ++lm) gg[lm] = acc_get2(V[lm][t], h);
+              tp_bwd_half<L, false, U, 0>(ee, pwh, gg, a);
+              __builtin_amdgcn_sched_barrier(0);
+              if (kk == 0) {
+#pragma unroll
+                for (int lm = D - 1; lm >= 1; --lm) vin[lm] = vin[l_of_lm(lm)] * Y[lm];
+              }
+              tp_bwd_half<L, false, U, 1>(vin, pwh, gg, b);
+            } else {
+              f32x2 gg[1];
+              gg[0] = half_of(ds[t], h);
+              tp_bwd_half<L, true, U, 0>(ee, pwh, gg, a);
+              __builtin_amdgcn_sched_barrier(0);
+              if (kk == 0) {
+#pragma unroll
+                for (int lm = D - 1; lm >= 1; --lm) vin[lm] = vin[l_of_lm(lm)] * Y[lm];
+              }
+              tp_bwd_half<L, true, U, 1>(vin, pwh, gg, b);
+            }
+#pragma unroll
+            for (int lm = 0; lm < D; ++lm) { acc_put2(V[lm][t], h, a[lm]); *(f32x2 *)(sp + lm * 16 + 2 * h) = b[lm]; }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (t == UT - 1) load_rows<L * UT>(SB, RL + S::O_OM + UT, omall, v16);
           __syncthreads();
           reduce_stage_x<L, UT, NW>(lds.stage[t & 1], aoffp, lds.denv, na, A.cenv, t, tid);
           __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
-      }
       PHASEX(PX_BTP);
       // environment weights backward: d omega[l][u] = sum_m denv[lm][u] Y[lm];  dY[lm] += sum_u denv[lm][u] omega[l][u]
-      {
         f32x4 dom[EW];
         const float *dn = lds.denv + envoff;
 #pragma unroll
         for (int t = 0; t < UT; ++t) {
           f32x4 omr[L + 1];
 #pragma unroll
-          for (int l = 1; l <= L; ++l) omr[l] = bload(SB, v16, (RL + S::O_OM + l * UT + t) * ROW * 4);
+          for (int l = 1; l <= L; ++l) omr[l] = omall[(l - 1) * UT + t];
 #pragma unroll
           for (int l = 0; l <= L; ++l) dom[l * UT + t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -514,6 +649,12 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
           }
           __builtin_amdgcn_sched_barrier(0);
         }
+        // next iteration's u / silu'(z2) rows (or the l >= 1 embedding weights for the last step) under this linear
+        if (kk > 0) {
+          load_rows<4>(SB, S::R_LAYER(kk - 1) + S::O_U, upre, v16);
+          load_rows<4>(SB, S::R_LAYER(kk - 1) + S::O_Z2, zt, v16);
+        } else load_rows<L * UT>(SB, S::R_W0 + UT, w0pre, v16);
+        __builtin_amdgcn_sched_barrier(0);
         linear_s<EW, 4, true, 0>(WB, wp, dom, dx, v16, ring, EpiNone{});
       }
       PHASEX(PX_BENV);
@@ -525,15 +666,16 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
       for (int t = 0; t < UT; ++t) {
         f32x4 w0r[L + 1];
 #pragma unroll
-        for (int l = 1; l <= L; ++l) w0r[l] = bload(SB, v16, (S::R_W0 + l * UT + t) * ROW * 4);
+        for (int l = 1; l <= L; ++l) w0r[l] = w0pre[(l - 1) * UT + t];
 #pragma unroll
         for (int l = 0; l <= L; ++l) dw0[l * UT + t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int lm = 0; lm < D; ++lm) {
-          if (lm == 0) dw0[t] = V[0][t];
+          const f32x4 dv = acc_get4(V[lm][t]);
+          if (lm == 0) dw0[t] = dv;
           else {
-            dw0[l_of_lm(lm) * UT + t] += V[lm][t] * Y[lm];
-            dY[lm] += hsum4(V[lm][t] * w0r[l_of_lm(lm)]);
+            dw0[l_of_lm(lm) * UT + t] += dv * Y[lm];
+            dY[lm] += hsum4(dv * w0r[l_of_lm(lm)]);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -739,7 +881,9 @@ static void fusedlx_prepare(Model &m) {
 
 bool fusedlx_run(Model &m, const ComputeArgs &a, std::string *why) {
   constexpr int NW = 4, SLOTS = 16 * NW;
-  if (m.last_max_deg > SLOTS) {
+  if (m.last_max_deg > SLOTS && (m.heavy_thresh != SLOTS || (long long)m.nheavy * 8 > m.inum)) {
+    // centres with more than 64 edges are listed by the edge build and evaluated by the layer-at-a-time kernels; when the edge
+    // build did not list them (two-pass fallback) or they are not a small minority, the whole system goes that way
     if (why) *why = "an atom has " + std::to_string(m.last_max_deg) + " edges (> " + std::to_string(SLOTS) + " per tile of the wide fused kernel)";
     return false;
   }
@@ -781,17 +925,17 @@ bool fusedlx_run(Model &m, const ComputeArgs &a, std::string *why) {
   A.f = a.f; A.eatom = a.eatom; A.partial = st.partial.as<double>();
   {
     StageTimer tm(m, "model_fused", s);
-    if (st.prof_on) {
+    if (st.prof_on && A.NL == 3) {
       AHIP_CHECK(hipMemsetAsync(st.prof.p, 0, 64 * sizeof(long long), s));
       A.prof = st.prof.as<long long>();
-      hipLaunchKernelGGL((k_fused_lx<2, 4, NW, true>), dim3(grid), dim3(NW * 64), 0, s, A);
-    } else {
-      hipLaunchKernelGGL((k_fused_lx<2, 4, NW, false>), dim3(grid), dim3(NW * 64), 0, s, A);
-    }
+      hipLaunchKernelGGL((k_fused_lx<2, 4, NW, 3, true>), dim3(grid), dim3(NW * 64), 0, s, A);
+    } else if (A.NL == 3) hipLaunchKernelGGL((k_fused_lx<2, 4, NW, 3, false>), dim3(grid), dim3(NW * 64), 0, s, A);
+    else if (A.NL == 2) hipLaunchKernelGGL((k_fused_lx<2, 4, NW, 2, false>), dim3(grid), dim3(NW * 64), 0, s, A);
+    else hipLaunchKernelGGL((k_fused_lx<2, 4, NW, 1, false>), dim3(grid), dim3(NW * 64), 0, s, A);
   }
   AHIP_CHECK(hipGetLastError());
   AHIP_CHECK(prim_sum_columns_f64(m.prim, st.partial.as<double>(), grid, 7, a.engvir, s));
-  if (st.prof_on) {
+  if (st.prof_on && A.NL == 3) {
     std::vector<long long> hp(PX_N);
     AHIP_CHECK(hipMemcpyAsync(hp.data(), st.prof.p, hp.size() * sizeof(long long), hipMemcpyDeviceToHost, s));
     AHIP_CHECK(hipStreamSynchronize(s));

@@ -1,8 +1,8 @@
 #!/bin/bash
 # PMC passes over the fused kernel (separate runs, --kernel-trace only).
-# Usage (from the repo root, on the GPU box): pair_allegro_amd/tools/pmc_passes.sh <tag> [ncell]
+# Usage (from the repo root, on the GPU box): pair_allegro_amd/tools/pmc_passes.sh <tag> ["bench.py arguments"]   (default: --ncell 20)
 # Writes gpurun_out/pmc_<tag>/summary.txt: per-dispatch averages of every counter for k_fused.
-tag=${1:-x}; ncell=${2:-20}
+tag=${1:-x}; bargs=${2:---ncell 20}
 root=$(pwd)
 out=$root/gpurun_out/pmc_$tag
 mkdir -p $out
@@ -11,7 +11,7 @@ i=0
 while read -r ctrs; do
   [ -z "$ctrs" ] && continue
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out/p$i -o p -- python3 $root/bench.py --ncell $ncell --steps 2 --warmup 1 --no-cpu-baseline > $out/p$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out/p$i -o p -- python3 $root/bench.py $bargs --steps 2 --warmup 1 --no-cpu-baseline > $out/p$i.log 2>&1
 done <<'LIST'
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_SALU

@@ -34,6 +34,7 @@ void fused_free(Model &) {}
 bool fusedlx_model_supported(const Model &, std::string *why) { if (why) *why = "host emulation has no MFMA"; return false; }
 bool fusedlx_run(Model &, const ComputeArgs &, std::string *why) { if (why) *why = "host emulation has no MFMA"; return false; }
 void fusedlx_free(Model &) {}
+void edges_compact_heavy(Model &, const ComputeArgs &) {}
 bool edges_build_f32(Model &, const ComputeArgs &) { return false; }   // emulation runs the two-pass kernels
 void edges_free(Model &) {}
 bool gemm_f32(hipStream_t, long long, int, int, const float *, int, const float *, int, bool, float *, int, bool, float *, const float *) { return false; }

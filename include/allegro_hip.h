@@ -64,6 +64,8 @@ int ahip_model_meta(const ahip_model *m, double *r_max, int *num_types, const ch
  *                                                 and the per-atom edge counts allow it)
  *   "precision" = "model" | "float64"            compute dtype; float64 is the debug/parity build
  *   "chunk_edges" = "<n>"                        max edges processed per pass (workspace bound)
+ *   "reserve_wgs" = "<n>"                        half-CU workgroup slots the persistent fused kernels leave unoccupied, so that
+ *                                                 kernels launched on OTHER streams (ghost exchange) can run beside them (default 0)
  */
 int ahip_set_option(ahip_model *m, const char *key, const char *value);
 

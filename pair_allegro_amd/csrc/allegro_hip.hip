@@ -180,6 +180,10 @@ int ahip_set_option(ahip_model *m, const char *key, const char *value) {
       long long n = std::atoll(value);
       if (n < 1) throw ArgError("option chunk_edges: expected a positive integer");
       m->chunk_edges = n;
+    } else if (k == "reserve_wgs") {
+      int n = std::atoi(value);
+      if (n < 0 || n > 128) throw ArgError("option reserve_wgs: expected 0..128");
+      m->reserve_wgs = n;
     } else if (k == "timing") {
       m->timing = (v == "1" || v == "on" || v == "true");
     } else throw ArgError("unknown option '" + k + "'");

@@ -88,6 +88,7 @@ struct Model {
   std::string opt_fused_tb = "table";       // table | mlp: two-body embedding of the fused kernel from the spline table or as an MLP
   std::string opt_fused_arith = "f32";      // f32 | bf16x3: arithmetic of the fused kernel's linears (fused.hip)
   long long chunk_edges = 2000000;
+  int reserve_wgs = 0;                      // workgroup slots the persistent fused kernels leave free (for kernels of other streams)
   bool timing = false;
 
   // weights

@@ -982,7 +982,9 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
   int nw = m.last_max_deg <= 64 ? 4 : 8;
   if (st.force_nw == 8 || (st.force_nw == 4 && m.last_max_deg <= 64)) nw = st.force_nw;
   const int tile_slots = 16 * nw, maxa = nw == 4 ? Lds<4>::MAXA : Lds<8>::MAXA;
-  const int grid = st.ncu * (8 / nw);
+  // persistent workgroups fill every CU; reserve_wgs leaves a few slots free so that the exchange kernels of another stream
+  // (ghost pack / unpack, RCCL send / recv) can be scheduled while this kernel runs (md.py, overlapped schedule)
+  const int grid = std::max(1, st.ncu * (8 / nw) - m.reserve_wgs);
   const int nseg = (inum + SEG - 1) / SEG;
   st.seg_count.reserve((size_t)(nseg + 1) * sizeof(int));
   st.seg_base.reserve((size_t)(nseg + 2) * sizeof(int));

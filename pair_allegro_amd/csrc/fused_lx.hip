@@ -245,6 +245,36 @@ __device__ __forceinline__ void reduce_stage_x(const float *stg, const int *aoff
   }
 }
 
+// Saves only the first NMAX output tiles of a linear (the rest is zero padding of a ring-aligned fragment block)
+template <int NMAX> struct EpiSaveN {
+  __amdgpu_buffer_rsrc_t S; int row0, v16;
+  __device__ __forceinline__ void tile_done(int ot, const f32x4 &acc) const { if (ot < NMAX) bstore(S, v16, (row0 + ot) * ROW * 4, acc); }
+  __device__ __forceinline__ float apply(int, int, float v) const { return v; }
+  __device__ __forceinline__ void flush(int) const {}
+};
+// Channel mixing, one (l, m) row at a time, in place on the parked edge tensor: V[lm] <- V[lm] @ M_l (forward, output rows
+// saved as the next layer's V_in) or V[lm] <- V[lm] @ M_l^T (+ ds on the scalar row: backward).  With 32 tensor features a row
+// is 2 x 2 tiles = 4 weight fragments = half a ring: rows alternate the ring phase, and the last (ninth) row is zero-padded on
+// the host to 8 fragments so that the stream stays ring-aligned.
+template <int LM, int D, int UT, bool FWD>
+__device__ __forceinline__ void mix_rows(float (&V)[D][UT][4], __amdgpu_buffer_rsrc_t WB, int &wp, int v16, f32x4 (&ring)[RING],
+                                         __amdgpu_buffer_rsrc_t SB, int row0, const f32x4 (&ds)[UT]) {
+  if constexpr (LM < D) {
+    constexpr bool PADDED = (UT == 2) && (LM == D - 1) && (D % 2 == 1);
+    constexpr int NTO = PADDED ? 4 : UT;
+    constexpr int RP = (UT == 2 && !PADDED) ? 4 * (LM & 1) : 0;
+    f32x4 vi[UT], o[NTO];
+#pragma unroll
+    for (int t = 0; t < UT; ++t) vi[t] = acc_get4(V[LM][t]);
+    if constexpr (FWD) linear_s<UT, NTO, false, RP>(WB, wp, vi, o, v16, ring, EpiSaveN<UT>{SB, row0 + LM * UT, v16});
+    else linear_s<UT, NTO, false, RP>(WB, wp, vi, o, v16, ring, EpiNone{});
+#pragma unroll
+    for (int t = 0; t < UT; ++t) acc_put4(V[LM][t], (!FWD && LM == 0) ? o[t] + ds[t] : o[t]);
+    __builtin_amdgcn_sched_barrier(0);
+    mix_rows<LM + 1, D, UT, FWD>(V, WB, wp, v16, ring, SB, row0, ds);
+  }
+}
+
 enum { PX_GEOM = 0, PX_EMB, PX_ENV, PX_TP, PX_LAT, PX_MIX, PX_OUT, PX_BLAT, PX_BMIX, PX_BTP, PX_BENV, PX_BEMB, PX_FIN, PX_N };
 #define PHASEX(id) do { if (PROF) { long long _t = clock64(); pacc[id] += _t - tprev; tprev = _t; } } while (0)
 
@@ -465,18 +495,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
       PHASEX(PX_LAT);
       // channel mixing, in place per (l, m) row -> V^{kk+1}, saved as the next layer's V_in rows
 #ifndef ABL_NO_MIX
-      if (!last) {
-#pragma unroll
-        for (int lm = 0; lm < D; ++lm) {
-          f32x4 vi[UT], o[UT];
-#pragma unroll
-          for (int t = 0; t < UT; ++t) vi[t] = acc_get4(V[lm][t]);
-          linear_s<UT, UT, false, 0>(WB, wp, vi, o, v16, ring, EpiSave{SB, S::R_LAYER(kk + 1) + S::O_VIN + lm * UT, v16});
-#pragma unroll
-          for (int t = 0; t < UT; ++t) acc_put4(V[lm][t], o[t]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
+      if (!last) mix_rows<0, D, UT, true>(V, WB, wp, v16, ring, SB, S::R_LAYER(kk + 1) + S::O_VIN, sc);
 #endif
       PHASEX(PX_MIX);
     }
@@ -548,18 +567,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
       }
       PHASEX(PX_BLAT);
       // mix^T in place per (l, m) row: V holds dE/dV^{kk+1}, becomes dE/dV' (tensor-product output gradient)
-      if (!last) {
-#pragma unroll
-        for (int lm = 0; lm < D; ++lm) {
-          f32x4 vi[UT], o[UT];
-#pragma unroll
-          for (int t = 0; t < UT; ++t) vi[t] = acc_get4(V[lm][t]);
-          linear_s<UT, UT, false, 0>(WB, wp, vi, o, v16, ring, EpiNone{});
-#pragma unroll
-          for (int t = 0; t < UT; ++t) acc_put4(V[lm][t], lm == 0 ? o[t] + ds[t] : o[t]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
+      if (!last) mix_rows<0, D, UT, false>(V, WB, wp, v16, ring, SB, 0, ds);
       PHASEX(PX_BMIX);
       // tensor-product gradient in place per K-tile; the per-edge environment gradient goes through the stage
       {
@@ -782,7 +790,7 @@ bool fusedlx_model_supported(const Model &m, std::string *why) {
   const HostModel &h = m.hm;
   auto no = [&](const char *msg) { if (why) *why = msg; return false; };
   if (h.l_max != 2) return no("wide fused kernels are built for l_max = 2");
-  if (h.U != 64) return no("wide fused kernels need 64 tensor features");
+  if (h.U != 32 && h.U != 64) return no("wide fused kernels need 32 or 64 tensor features");
   if (h.S != 64 || h.mlp_width != 64 || h.readout_width != 32) return no("fused kernels need S=64, MLP width 64, read-out width 32");
   if (h.mlp_depth != 2 || h.readout_depth != 1) return no("fused kernels need MLP depth 2 and read-out depth 1");
   if (h.num_bessels != 8) return no("fused kernels need 8 Bessel functions");
@@ -802,6 +810,18 @@ template <int L, int UT> static void fusedlx_prepare_t(Model &m, FusedLxState &s
   auto T_ = [&](const std::string &name) -> const double * { return h.get(name).data.data(); };
   auto fwd = [&](const double *W, int K, int N) { append_frag(w, W, K, N, N); };
   auto bwd = [&](const double *W, int K, int N) { auto t = transpose(W, K, N); append_frag(w, t.data(), N, K, K); };
+  // one channel-mixing row; with 32 features the last row is padded to 64 output columns (8 fragments, see mix_rows)
+  auto mixfrag = [&](const double *Wl, int lm, bool transposed) {
+    std::vector<double> m2((size_t)U * U);
+    for (int a = 0; a < U; ++a)
+      for (int b = 0; b < U; ++b) m2[(size_t)a * U + b] = transposed ? Wl[(size_t)b * U + a] : Wl[(size_t)a * U + b];
+    if (UT == 2 && lm == D - 1 && (D % 2) == 1) {
+      std::vector<double> pad((size_t)U * 2 * U, 0.0);
+      for (int a = 0; a < U; ++a)
+        for (int b = 0; b < U; ++b) pad[(size_t)a * 2 * U + b] = m2[(size_t)a * U + b];
+      append_frag(w, pad.data(), U, 2 * U, 2 * U);
+    } else append_frag(w, m2.data(), U, U, U);
+  };
   // ---- the weight stream, in the order one tile consumes it (see k_fused_lx) ----
   A.o_stream = mark();
   const size_t stream0 = w.size();
@@ -814,7 +834,7 @@ template <int L, int UT> static void fusedlx_prepare_t(Model &m, FusedLxState &s
     fwd(T_(lk + ".lat.w2"), 64, 64);
     if (k < NL - 1) {
       const double *mx = T_(lk + ".mix");            // [L+1][U][U]; block l serves its 2l+1 components
-      for (int lm = 0; lm < D; ++lm) fwd(mx + (size_t)l_of_lm(lm) * U * U, U, U);
+      for (int lm = 0; lm < D; ++lm) mixfrag(mx + (size_t)l_of_lm(lm) * U * U, lm, false);
     }
   }
   fwd(T_("out.w0"), 64, 32);
@@ -826,7 +846,7 @@ template <int L, int UT> static void fusedlx_prepare_t(Model &m, FusedLxState &s
     bwd(T_(lk + ".lat.w0"), 64 + U, 64);
     if (k < NL - 1) {
       const double *mx = T_(lk + ".mix");
-      for (int lm = 0; lm < D; ++lm) bwd(mx + (size_t)l_of_lm(lm) * U * U, U, U);
+      for (int lm = 0; lm < D; ++lm) mixfrag(mx + (size_t)l_of_lm(lm) * U * U, lm, true);
     }
     bwd(T_(lk + ".env"), 64, U * (L + 1));
   }
@@ -865,7 +885,7 @@ static void fusedlx_prepare(Model &m) {
   FusedLxState &st = *(FusedLxState *)m.fusedlx_state;
   if (st.ready) return;
   st.L = m.hm.l_max; st.UT = m.hm.U / 16;
-  fusedlx_prepare_t<2, 4>(m, st);
+  if (st.UT == 4) fusedlx_prepare_t<2, 4>(m, st); else fusedlx_prepare_t<2, 2>(m, st);
   hipDeviceProp_t prop;
   AHIP_CHECK(hipGetDeviceProperties(&prop, m.device));
   st.ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -893,7 +913,7 @@ bool fusedlx_run(Model &m, const ComputeArgs &a, std::string *why) {
   hipStream_t s = a.stream;
   const int inum = m.inum;
   const int maxa = ShapeX<2, 4, NW>::MAXA;
-  const int grid = st.ncu;
+  const int grid = std::max(1, st.ncu - (m.reserve_wgs + 1) / 2);      // see fused.hip: slots left free for the exchange kernels
   const int nseg = (inum + SEG - 1) / SEG;
   st.seg_count.reserve((size_t)(nseg + 1) * sizeof(int));
   st.seg_base.reserve((size_t)(nseg + 2) * sizeof(int));
@@ -925,13 +945,16 @@ bool fusedlx_run(Model &m, const ComputeArgs &a, std::string *why) {
   A.f = a.f; A.eatom = a.eatom; A.partial = st.partial.as<double>();
   {
     StageTimer tm(m, "model_fused", s);
+#define LX_LAUNCH(UTV, NLV, PROFV) hipLaunchKernelGGL((k_fused_lx<2, UTV, NW, NLV, PROFV>), dim3(grid), dim3(NW * 64), 0, s, A)
+#define LX_LAUNCH_NL(UTV) do { if (A.NL == 3) LX_LAUNCH(UTV, 3, false); else if (A.NL == 2) LX_LAUNCH(UTV, 2, false); else LX_LAUNCH(UTV, 1, false); } while (0)
     if (st.prof_on && A.NL == 3) {
       AHIP_CHECK(hipMemsetAsync(st.prof.p, 0, 64 * sizeof(long long), s));
       A.prof = st.prof.as<long long>();
-      hipLaunchKernelGGL((k_fused_lx<2, 4, NW, 3, true>), dim3(grid), dim3(NW * 64), 0, s, A);
-    } else if (A.NL == 3) hipLaunchKernelGGL((k_fused_lx<2, 4, NW, 3, false>), dim3(grid), dim3(NW * 64), 0, s, A);
-    else if (A.NL == 2) hipLaunchKernelGGL((k_fused_lx<2, 4, NW, 2, false>), dim3(grid), dim3(NW * 64), 0, s, A);
-    else hipLaunchKernelGGL((k_fused_lx<2, 4, NW, 1, false>), dim3(grid), dim3(NW * 64), 0, s, A);
+      if (st.UT == 4) LX_LAUNCH(4, 3, true); else LX_LAUNCH(2, 3, true);
+    } else if (st.UT == 4) LX_LAUNCH_NL(4);
+    else LX_LAUNCH_NL(2);
+#undef LX_LAUNCH_NL
+#undef LX_LAUNCH
   }
   AHIP_CHECK(hipGetLastError());
   AHIP_CHECK(prim_sum_columns_f64(m.prim, st.partial.as<double>(), grid, 7, a.engvir, s));

@@ -110,6 +110,10 @@ class Simulation:
         nranks = int(grid[0]) * int(grid[1]) * int(grid[2])
         self.overlap = (nranks > 1 if overlap is None else bool(overlap)) and hasattr(backend, "compute_range")
         self.comm_stream = torch.cuda.Stream(device) if (self.overlap and device.type == "cuda") else None
+        if self.comm_stream is not None and nranks > 1 and hasattr(backend, "model"):
+            # the fused kernels are persistent and fill every CU: leave a few workgroup slots free, otherwise the pack / unpack
+            # and RCCL kernels of the exchange stream could only start when the force kernel ends
+            backend.model.set_option("reserve_wgs", 8)
         self.n_int = 0
         self.n_half = 0
         self._flag_host = None

@@ -8,10 +8,10 @@ lib = capi.Library()
 g = util.load_golden("CuPd-cubic-big_r5")
 symbols = ["O" if s == "Cu" else "H" for s in g["symbols"]]
 nb = float(len(util.glue.brute_force_edges(g["cell"], g["pos"], 5.0)[0])) / len(g["pos"])
-for nl in (1, 2, 3):
-    cfg = model_file.model_L(avg_num_neighbors=nb, num_layers=nl)
+for nl, U in ((1, 64), (2, 64), (3, 64), (1, 32), (2, 32), (3, 32)):
+    cfg = model_file.model_L(avg_num_neighbors=nb, num_layers=nl, num_tensor_features=U)
     w = model_file.init_weights(cfg)
-    path = f"/tmp/modelL_{nl}.nequip.pth"
+    path = f"/tmp/modelL_{nl}_{U}.nequip.pth"
     allegro_torch.export_nequip_pth(path, cfg, w)
     names = sorted(set(symbols))
     types = np.array([names.index(s) + 1 for s in symbols], dtype=np.int32)
@@ -21,7 +21,7 @@ for nl in (1, 2, 3):
         res = util.run_pair(lib, path, g["cell"], g["pos"], types, names, options={"path": "fused"})
     except Exception as e:
         print("fused failed:", e); continue
-    print(f"NL={nl} path={res['info']['path']} maxdeg={res['info']['max_degree']} max|dF| fused-oracle={np.abs(res['forces']-ref['forces']).max():.3e} "
+    print(f"NL={nl} U={U} path={res['info']['path']} maxdeg={res['info']['max_degree']} max|dF| fused-oracle={np.abs(res['forces']-ref['forces']).max():.3e} "
           f"generic-oracle={np.abs(gen['forces']-ref['forces']).max():.3e} |F|max={np.abs(ref['forces']).max():.3f} "
           f"dPE={abs(res['pe']-ref['pe']):.3e} dEatom={np.abs(res['eatom']-ref['eatom']).max():.3e} dvir={np.abs(res['virial']-ref['virial']).max():.3e}", flush=True)
 

@@ -112,7 +112,7 @@ def test_config5_water_parity_vs_oracle(hip_lib, model_dir):
     symbols = ["O" if t == 1 else "H" for t in types]
     path, cfg, w, types2, names, ref = _model_L_case(model_dir, "water_L", ["O", "H"], cell, pos, symbols)
     res = util.run_pair(hip_lib, path, cell, pos, types2, names)
-    assert res["info"]["path"] in ("fused_f32", "generic_f32")
+    assert res["info"]["path"] == "fused_f32"
     util.assert_close_to(res, ref, 5e-4, what="water model L vs f64 oracle")
     assert np.abs(res["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
 
@@ -122,7 +122,7 @@ def test_config5_full_size_properties_500k(hip_lib, model_dir):
     cell, pos, types = lmp_like.water(55)
     cfg = model_file.model_L(avg_num_neighbors=53.6)
     masses = [lmp_like.WATER_MASSES[s] for s in cfg["type_names"]]
-    _full_size_properties(hip_lib, model_dir, cfg, cell, pos, (types - 1).astype(np.int32), masses, ("fused_f32", "generic_f32"),
+    _full_size_properties(hip_lib, model_dir, cfg, cell, pos, (types - 1).astype(np.int32), masses, ("fused_f32",),
                           check_overlap=False)
 
 

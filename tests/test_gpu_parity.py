@@ -33,7 +33,8 @@ def test_chunked_equals_unchunked(hip_lib, model_dir):
 
 def test_model_L_shape_config5(hip_lib, model_dir):
     """BASELINE config 5's model shape (l_max = 2, 64 tensor features, 3 layers, two types O/H) on the generic float32 path
-    (MFMA GEMMs, unrolled tensor product) against the float64 oracle; the CuPd 256-atom box stands in for the geometry."""
+    (MFMA GEMMs, unrolled tensor product) against the float64 oracle; the CuPd 256-atom box stands in for the geometry.
+    (The default path for this shape is the wide fused kernel: tests/test_gpu_fused_lx.py.)"""
     from oracle import allegro_torch
     from pair_allegro_amd import model_file
     g = util.load_golden("CuPd-cubic-big_r5")
@@ -46,7 +47,7 @@ def test_model_L_shape_config5(hip_lib, model_dir):
     names = sorted(set(symbols))
     types = np.array([names.index(s) + 1 for s in symbols], dtype=np.int32)
     ref = util.oracle_run(dict(cfg, model_dtype="float64"), w, g["cell"], g["pos"], types, names)
-    res = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names)
+    res = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "generic"})
     assert res["info"]["path"] == "generic_f32"
     util.assert_close_to(res, ref, 5e-4, what="model L generic f32 vs f64 oracle")
     assert np.abs(res["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF

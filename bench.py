@@ -286,20 +286,57 @@ def cpu_baseline_and_parity(lib, config, device_index, ncell, path):
     mapper = np.array([cfg["type_names"].index(s) for s in names], dtype=np.int32)
     cm = np.full((len(names), len(names)), cfg["r_max"])
     oracle = torch.jit.script(allegro_torch.build(cfg, weights).eval())
-    inp = glue.preprocess(rs.x, rs.type, rs.nlocal, rs.ilist, rs.numneigh, rs.firstneigh, mapper, cm)
-    tin = {k: torch.from_numpy(v) for k, v in inp.items()}
-    for _ in range(3):                                                # warm-up (JIT profiling runs); SURVEY 8d: 3 warm-up
-        oracle(tin)
-    reps, t0 = 0, time.perf_counter()
-    while reps < 3 or (time.perf_counter() - t0 < 20.0 and reps < 10):    # >= 10 timed evaluations when they fit in ~20 s
-        oracle(tin)
-        reps += 1
-    t_eval = (time.perf_counter() - t0) / reps
     f_ref = np.zeros_like(rs.x)
     e_ref = np.zeros(len(rs.x))
-    tg = time.perf_counter()
     pe_ref, vir_ref, _ = glue.compute(oracle, rs.x, rs.type, rs.nlocal, rs.ilist, rs.numneigh, rs.firstneigh, mapper, cm, f_ref, e_ref)
-    t_glue_incl = time.perf_counter() - tg
+    harness = os.path.join(ROOT, "oracle", "_build", "cpu_baseline")
+    cpu = None
+    if os.path.exists(harness):
+        # SURVEY 8d protocol: the contract-conforming TorchScript file executed by libtorch (C++) with the reference's own call
+        # sequence (oracle/cpu_baseline.cpp: jit::load + freeze + preprocess -> forward(Dict) -> scatter), 3 warm-up + >= 10 timed
+        pth = os.path.join(tmpdir, "model.nequip.pth")
+        allegro_torch.export_nequip_pth(pth, cfg, weights)
+        runs = []
+        samples = [(wl["name"], rs)]
+        if config in (2, 4):                                          # SURVEY 8d sizes: 64 and 10 648 atoms
+            c64, p64, t64 = lmp_like.diamond_si(2)
+            samples.insert(0, ("64-atom bulk Si (config 1)", lmp_like.build_rank_system(c64, p64, t64, cfg["r_max"] + 1.0)))
+        for label, r in samples:
+            sysf = os.path.join(tmpdir, f"sys_{r.nlocal}.bin")
+            with open(sysf, "wb") as fh:
+                np.array([r.nlocal, r.nghost, len(names), int(r.offsets[-1])], dtype=np.int32).tofile(fh)
+                r.x.astype(np.float64).tofile(fh); r.type.astype(np.int32).tofile(fh); r.tag.astype(np.int32).tofile(fh)
+                r.numneigh.astype(np.int32).tofile(fh); r.flat.astype(np.int32).tofile(fh)
+            import subprocess
+            pr = subprocess.run([harness, sysf, pth, "--warmup", "3", "--reps", "10", "--budget", "25"] + list(names),
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            if pr.returncode == 0:
+                d = json.loads(pr.stdout.decode().strip().splitlines()[-1])
+                d["sample"] = label
+                runs.append(d)
+        if runs:
+            main_run = runs[-1]
+            cpu = {"value": round(main_run["nlocal"] / (main_run["ms_model"] * 1e-3), 1), "unit": "atom-steps/s", "cores": main_run["threads"],
+                   "kind": "port",
+                   "sample": f"{main_run['sample']}: libtorch C++ harness (oracle/cpu_baseline.cpp, the reference's load / freeze / "
+                             f"preprocess / forward(Dict) / scatter sequence) on the oracle's TorchScript export, float32 model, "
+                             f"{main_run['warmup']} warm-up + {main_run['reps']} timed evaluations, {main_run['ms_model']:.0f} ms each (model only), "
+                             f"{main_run['ms_total']:.0f} ms with preprocess + scatter",
+                   "value_glue_inclusive": round(main_run["nlocal"] / (main_run["ms_total"] * 1e-3), 1),
+                   "runs": [{k: r[k] for k in ("sample", "nlocal", "nedges", "threads", "reps", "ms_model", "ms_total")} for r in runs]}
+    if cpu is None:
+        inp = glue.preprocess(rs.x, rs.type, rs.nlocal, rs.ilist, rs.numneigh, rs.firstneigh, mapper, cm)
+        tin = {k: torch.from_numpy(v) for k, v in inp.items()}
+        for _ in range(3):
+            oracle(tin)
+        reps, t0 = 0, time.perf_counter()
+        while reps < 3 or (time.perf_counter() - t0 < 20.0 and reps < 10):
+            oracle(tin)
+            reps += 1
+        t_eval = (time.perf_counter() - t0) / reps
+        cpu = {"value": round(rs.nlocal / t_eval, 1), "unit": "atom-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"{wl['name']}: 3 warm-up + {reps} timed force evaluations of the TorchScript oracle through torch (Python; the C++ "
+                         f"harness oracle/_build/cpu_baseline was not built), {t_eval*1e3:.0f} ms each (model only)"}
     m = capi.Model(model_path, device_index, lib)
     m.set_option("path", path)
     m.neigh_update_csr(rs.nall, rs.ilist, rs.offsets, rs.flat)
@@ -314,11 +351,6 @@ def cpu_baseline_and_parity(lib, config, device_index, ncell, path):
               "abs_dPE_per_atom": float(abs(pe - pe_ref) / rs.nlocal),
               "max_abs_dvirial_per_atom": float(np.abs(vir - vir_ref).max() / rs.nlocal), "atoms": int(rs.nlocal),
               "kernel_path": used, "sample": wl["name"]}
-    cpu = {"value": round(rs.nlocal / t_eval, 1), "unit": "atom-steps/s", "cores": torch.get_num_threads(),
-           "kind": "port", "sample": f"{wl['name']}: 3 warm-up + {reps} timed force evaluations of the TorchScript oracle (float32 model, "
-                                     f"autograd forces) on torch CPU threads, {t_eval*1e3:.0f} ms each (model only); "
-                                     f"{t_glue_incl*1e3:.0f} ms with preprocess + scatter (python glue)",
-           "value_glue_inclusive": round(rs.nlocal / t_glue_incl, 1)}
     return cpu, parity
 
 

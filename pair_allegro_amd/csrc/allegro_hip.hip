@@ -204,6 +204,8 @@ static void install_list_host(ahip_model *m, int inum, int nall) {
   m->d_nloff = m->b_nloff.as<int>();
   m->d_nlj = m->b_nlj.as<int>();
   m->inum = inum; m->nall = nall; m->nneigh = (long long)nn; m->have_list = true;
+  m->max_list_row = 0;
+  for (int ii = 0; ii < inum; ++ii) m->max_list_row = std::max(m->max_list_row, m->h_off32[ii + 1] - m->h_off32[ii]);
 }
 
 static void check_list_dims(int inum, int nall) {
@@ -278,6 +280,7 @@ int ahip_neigh_update_dev(ahip_model *m, int inum, int nall, const int *ilist_de
     if (inum > 0 && (!ilist_dev || !offsets_dev)) throw ArgError("ahip_neigh_update_dev: NULL list pointer");
     m->d_ilist = ilist_dev; m->d_nloff = offsets_dev; m->d_nlj = neigh_dev;
     m->inum = inum; m->nall = nall; m->nneigh = nneigh_total; m->have_list = true;
+    m->max_list_row = -1;
   });
 }
 

@@ -19,7 +19,8 @@ namespace ahip {
 
 static constexpr int EB_ATOMS = 32;      // centres per block
 static constexpr int EB_PER_WAVE = 8;    // centres per wave
-static constexpr int EB_CHUNKS = 2;      // 64-entry chunks per row held in registers
+// EB_CHUNKS (template parameter): 64-entry chunks of a list row held in registers: 1 when no row of the installed list is longer
+// than 64 entries (half the registers: 5 instead of 3 waves per SIMD in flight for this latency-bound gather), else 2
 
 // {x, y, z, types} per atom, 32-byte aligned: ONE sector per gathered neighbour instead of two or three (the 24-byte position
 // straddles sectors, the type sits in another array).  Rewritten every step by k_pack_xt (a 60 MB stream at 1 M atoms).
@@ -37,6 +38,7 @@ __global__ void __launch_bounds__(256) k_pack_xt(int nall, const double *__restr
 
 __device__ __forceinline__ unsigned long long pack_state(unsigned long long state, unsigned long long v) { return (state << 62) | v; }
 
+template <int EB_CHUNKS>
 __global__ void __launch_bounds__(256) k_build_edges(int inum, const int *__restrict__ ilist, const int *__restrict__ nl_off,
                                                        const int *__restrict__ nl_j, const AtomXT *__restrict__ xt,
                                                        const double *__restrict__ cutsq, int nft,
@@ -125,25 +127,37 @@ __global__ void __launch_bounds__(256) k_build_edges(int inum, const int *__rest
     if (tid == 0 && mx > 0) atomicMax(maxdeg, mx);
   }
   __syncthreads();
-  if (tid == 0) {
+  if (tid < 64) {
+    // decoupled look-back, one WAVE wide: lane l polls predecessor b-1-l; the window closes at the nearest predecessor that has
+    // published its inclusive prefix (state 2), everything nearer contributes its aggregate (state 1).  (A one-lane walk costs
+    // one dependent global load per predecessor: with ~1000 blocks resident the chain was the kernel's critical path.)
     const unsigned long long agg = (unsigned long long)s_base[EB_ATOMS];
+    const unsigned long long VMASK = (1ull << 62) - 1;
     unsigned long long prefix = 0;
     if (b == 0) {
-      __hip_atomic_store(&status[0], pack_state(2, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_store(&status[0], pack_state(2, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      __hip_atomic_store(&status[b], pack_state(1, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int k = b - 1;; --k) {
-        unsigned long long v;
-        do {
-          v = __hip_atomic_load(&status[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((v >> 62) == 0) __builtin_amdgcn_s_sleep(1);
-        } while ((v >> 62) == 0);
-        prefix += v & ((1ull << 62) - 1);
-        if ((v >> 62) == 2) break;
+      if (lane == 0) __hip_atomic_store(&status[b], pack_state(1, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int base = b - 1;
+      for (;;) {
+        const int k = base - lane;
+        const unsigned long long v = k >= 0 ? __hip_atomic_load(&status[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pack_state(2, 0);
+        const unsigned st2 = (unsigned)(v >> 62);
+        const unsigned long long ready = __ballot(st2 != 0), incl = __ballot(st2 == 2);
+        const int first2 = incl ? __builtin_ctzll(incl) : 64;                 // nearest predecessor with an inclusive prefix
+        const unsigned long long need = first2 < 63 ? ((2ull << first2) - 1) : ~0ull;
+        if ((ready & need) == need) {
+          unsigned long long c = lane <= first2 ? (v & VMASK) : 0ull;
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+          prefix += c;
+          if (first2 < 64) break;
+          base -= 64;
+        } else __builtin_amdgcn_s_sleep(1);
       }
-      __hip_atomic_store(&status[b], pack_state(2, prefix + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_store(&status[b], pack_state(2, prefix + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    s_prefix = (long long)prefix;
+    if (lane == 0) s_prefix = (long long)prefix;
   }
   __syncthreads();
   const long long gbase = s_prefix;
@@ -236,10 +250,12 @@ bool edges_build_f32(Model &m, const ComputeArgs &a) {
   const int nall = std::max(m.nall, 1);
   st.xt.reserve((size_t)nall * sizeof(AtomXT));
   hipLaunchKernelGGL(k_pack_xt, dim3((nall + 255) / 256), dim3(256), 0, a.stream, m.nall, a.x, a.ftype, a.mtype, (AtomXT *)st.xt.p);
-  hipLaunchKernelGGL(k_build_edges, dim3(nblocks), dim3(256), 0, a.stream, inum, m.d_ilist, m.d_nloff, m.d_nlj, (const AtomXT *)st.xt.p,
-                     a.cutsq, a.nft, (unsigned int *)hdr, (unsigned long long *)((char *)st.flags.p + 64), m.b_eoff.as<int>(),
-                     m.b_eii.as<int>(), m.b_ej.as<int>(), m.b_rvec.as<float>(), hdr + 1, hdr + 2, m.b_ett.as<unsigned char>(),
-                     m.heavy_thresh, hdr + 3, st.heavy.as<int>());
+#define EB_LAUNCH(CH) hipLaunchKernelGGL(k_build_edges<CH>, dim3(nblocks), dim3(256), 0, a.stream, inum, m.d_ilist, m.d_nloff, m.d_nlj,       \
+                     (const AtomXT *)st.xt.p, a.cutsq, a.nft, (unsigned int *)hdr, (unsigned long long *)((char *)st.flags.p + 64),   \
+                     m.b_eoff.as<int>(), m.b_eii.as<int>(), m.b_ej.as<int>(), m.b_rvec.as<float>(), hdr + 1, hdr + 2,                \
+                     m.b_ett.as<unsigned char>(), m.heavy_thresh, hdr + 3, st.heavy.as<int>())
+  if (m.max_list_row >= 0 && m.max_list_row <= 64) EB_LAUNCH(1); else EB_LAUNCH(2);
+#undef EB_LAUNCH
   AHIP_CHECK(hipGetLastError());
   int h3[4] = {0, 0, 0, 0}, tot = 0;
   // the scalar read-back per step (the Kokkos path has the same one: pair_nequip_allegro_kokkos.cpp:203-206)

@@ -102,6 +102,7 @@ struct Model {
   int inum = 0, nall = 0;
   long long nneigh = 0;
   bool have_list = false;
+  int max_list_row = -1;                     // longest row of the installed list (-1: unknown, e.g. a caller-owned device list)
   const int *d_ilist = nullptr, *d_nloff = nullptr, *d_nlj = nullptr;   // current (owned or borrowed)
   DevBuf b_ilist, b_nloff, b_nlj;
   std::vector<int> h_flat_j, h_off32, h_ilist;

@@ -220,28 +220,32 @@ __device__ __forceinline__ f32x2 bload_half(__amdgpu_buffer_rsrc_t r, int voff, 
 __device__ __forceinline__ float hsum4(const f32x4 &v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 
 // Per-centre sum of one staged K-tile: env[a][lm][16 t + f] = scale * sum_{slots of a} stage[slot][lm][f].
-// Two adjacent lanes share an output (even / odd slots) and combine with one cross-lane add: 2 * na * D * 16 work items.
+// Work item = (centre, 4-feature column); its 8 adjacent lanes take every 8th slot with 16-byte LDS reads (all of a lane's reads
+// are in flight together) and combine with three cross-lane adds -- a fixed order, so the sums are reproducible.
 template <int L, int UT, int NW>
 __device__ __forceinline__ void reduce_stage_x(const float *stg, const int *aoff, float *dst, int na, float scale, int t, int tid) {
   using S = ShapeX<L, UT, NW>;
-  constexpr int PER = S::D * 16;
-  const int part = tid & 1;
-  for (int o = tid >> 1; o < ((na * PER + 127) & ~127); o += NW * 32) {       // whole waves keep iterating together (shuffle below)
-    const bool live = o < na * PER;
-    const int a = live ? o / PER : 0, r = live ? o - a * PER : 0;
-    const int s0 = aoff[a] + part, s1 = live ? aoff[a + 1] : 0;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-    int sl = s0;
-    for (; sl + 6 < s1; sl += 8) {
-      acc0 += stg[sl * S::STG_LD + r];
-      acc1 += stg[(sl + 2) * S::STG_LD + r];
-      acc2 += stg[(sl + 4) * S::STG_LD + r];
-      acc3 += stg[(sl + 6) * S::STG_LD + r];
+  constexpr int NC = S::D * 4, PER_ROUND = NW * 64 / 8;
+  const int p = tid & 7;
+  for (int it = tid >> 3; it < ((na * NC + PER_ROUND - 1) / PER_ROUND) * PER_ROUND; it += PER_ROUND) {   // whole waves iterate together
+    const bool live = it < na * NC;
+    const int a = live ? it / NC : 0, c = live ? it - a * NC : 0;
+    const int s0 = aoff[a] + p, s1 = live ? aoff[a + 1] : 0;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < S::SLOTS / 8; ++k) {
+      const int sl = s0 + 8 * k;
+      if (sl < s1) acc += *(const f32x4 *)(stg + sl * S::STG_LD + 4 * c);
     }
-    for (; sl < s1; sl += 2) acc0 += stg[sl * S::STG_LD + r];
-    float sum = (acc0 + acc1) + (acc2 + acc3);
-    sum += __shfl_xor(sum, 1, 64);
-    if (live && part == 0) dst[a * S::ENVA + (r >> 4) * S::U + 16 * t + (r & 15)] = scale * sum;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = acc[r];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      acc[r] = v * scale;
+    }
+    if (live && p == 0) *(f32x4 *)(dst + a * S::ENVA + (c >> 2) * S::U + 16 * t + 4 * (c & 3)) = acc;
   }
 }
 

@@ -197,8 +197,8 @@ HostModel load_model_file(const std::string &path) {
   std::string err;
   if (!zip_find_member(buf, "extra/allegro_hip.bin", off, len, err))
     throw std::runtime_error(path + ": " + err +
-                             " -- this model file carries no allegro-hip weight section; "
-                             "export it with the allegro-hip exporter (see INTEGRATION.md)");
+                             " -- this model file carries no allegro-hip weight section; add one with "
+                             "`python -m pair_allegro_amd.tools.convert_nequip <in>.nequip.pth <out>.nequip.pth` (INTEGRATION.md section 2)");
   return parse_blob(buf.data() + off, len, path);
 }
 

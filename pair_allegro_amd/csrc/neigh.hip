@@ -133,8 +133,11 @@ void neigh_build(Model &m, int nlocal, int nall, const double *x_dev, const doub
     hipLaunchKernelGGL(k_iota, grid(nlocal), dim3(B), 0, s, nlocal, st.ilist.as<int>());
   }
   AHIP_CHECK(prim_exclusive_scan_i32(m.prim, st.cnt.as<int>(), st.off.as<int>(), nlocal, s));
-  int tot = 0;
+  int tot = 0, maxrow = 0;
+  st.box.reserve(64);
+  AHIP_CHECK(prim_max_i32(st.cnt.as<int>(), nlocal, st.box.as<int>(), s));
   AHIP_CHECK(hipMemcpyAsync(&tot, st.off.as<int>() + nlocal, sizeof(int), hipMemcpyDeviceToHost, s));
+  AHIP_CHECK(hipMemcpyAsync(&maxrow, st.box.as<int>(), sizeof(int), hipMemcpyDeviceToHost, s));
   AHIP_CHECK(hipStreamSynchronize(s));
   st.nlj.reserve((size_t)std::max(tot, 1) * sizeof(int));
   if (nlocal > 0)
@@ -144,6 +147,7 @@ void neigh_build(Model &m, int nlocal, int nall, const double *x_dev, const doub
   m.d_nloff = st.off.as<int>();
   m.d_nlj = st.nlj.as<int>();
   m.inum = nlocal; m.nall = nall; m.nneigh = tot; m.have_list = true;
+  m.max_list_row = maxrow;
   m.h_ilist.clear();
 }
 

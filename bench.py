@@ -266,7 +266,7 @@ def cpu_sample(config: int, ncell: int):
         cell, pos, types = lmp_like.li3po4((3, 5, 6))         # 2 880 atoms, same cell
         mapper = np.array([wl["cfg"]["type_names"].index(s) for s in wl["lammps_names"]], dtype=np.int32)
         return dict(wl, name="2880-atom Li3PO4 (3x5x6 cells)", cell=cell, pos=pos, lammps_types=types, mtype=mapper[types - 1])
-    return workload(5, 12)                                    # 5 184-atom water, model L
+    return workload(5, 6)                                     # 648-atom water, model L (a CPU evaluation of model L costs ~20 ms per atom)
 
 
 def cpu_baseline_and_parity(lib, config, device_index, ncell, path):
@@ -308,7 +308,10 @@ def cpu_baseline_and_parity(lib, config, device_index, ncell, path):
                 r.x.astype(np.float64).tofile(fh); r.type.astype(np.int32).tofile(fh); r.tag.astype(np.int32).tofile(fh)
                 r.numneigh.astype(np.int32).tofile(fh); r.flat.astype(np.int32).tofile(fh)
             import subprocess
-            pr = subprocess.run([harness, sysf, pth, "--warmup", "3", "--reps", "10", "--budget", "25"] + list(names),
+            # 3 warm-up + >= 10 timed where that fits ~25 s; a sample whose single evaluation takes tens of seconds
+            # (model L on CPU: ~20 ms per atom) gets 1 warm-up + 3 timed
+            heavy = cfg["l_max"] >= 2 or r.nlocal > 4000
+            pr = subprocess.run([harness, sysf, pth, "--warmup", "1" if heavy else "3", "--reps", "3" if heavy else "10", "--budget", "25"] + list(names),
                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             if pr.returncode == 0:
                 d = json.loads(pr.stdout.decode().strip().splitlines()[-1])

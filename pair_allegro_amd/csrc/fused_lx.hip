@@ -599,13 +599,15 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
             f32x2 vin[D], a[D], b[D], ee[D];
 #pragma unroll
             for (int lm = 0; lm < D; ++lm) vin[lm] = vpre[lm];
-            __builtin_amdgcn_sched_barrier(0);
-            if (2 * t + h + 1 < 2 * UT) request_vin(h == 1 ? t + 1 : t, h ^ 1);
 #pragma unroll
             for (int lm = 0; lm < D; ++lm) ee[lm] = *(const f32x2 *)(en + 16 * t + 2 * h + lm * U);
             f32x2 pwh[NP];          // path weights of this half pass: one batch of LDS reads, one wait
 #pragma unroll
             for (int pth = 0; pth < NP; ++pth) pwh[pth] = *(const f32x2 *)(tp + 16 * t + 2 * h + pth * U);
+            __builtin_amdgcn_sched_barrier(0);
+            // next half pass's rows: requested AFTER this half pass's LDS reads -- a spilled LDS address reloaded between the
+            // request and those reads would wait on vmcnt(0), i.e. on the rows just requested (loads return in order)
+            if (2 * t + h + 1 < 2 * UT) request_vin(h == 1 ? t + 1 : t, h ^ 1);
             __builtin_amdgcn_sched_barrier(0);
             if (!last) {
               f32x2 gg[D];

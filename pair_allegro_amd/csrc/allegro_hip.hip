@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -341,6 +342,8 @@ static void run_model(ahip_model *m, const ComputeArgs &a) {
   m->nheavy = 0;
   m->heavy_thresh = (m->opt_path != "generic" && !fused_model_supported(*m, nullptr) && fusedlx_model_supported(*m, nullptr)) ? 64 : 0;
   if (!edges_build_f32(*m, a)) { m->nheavy = 0; m->heavy_thresh = 0; build_edges<float>(*m, a); }
+  static const bool edges_only = std::getenv("AHIP_EDGES_ONLY") != nullptr;     // timing experiments on the edge build alone
+  if (edges_only) { m->last_path = "edges_only"; return; }
   std::string why;
   bool fused_ok = false;
   if (m->opt_path != "generic") {

@@ -17,7 +17,12 @@
 
 namespace ahip {
 
-static constexpr int EB_ATOMS = 32;      // centres per block
+static constexpr int EB_ATOMS = 32;      // centres per scan unit (one status word each)
+// The kernel is PERSISTENT: a grid of resident workgroups (<= 4 per CU, below the 5 its registers admit; 2 per CU for the
+// two-chunk instance) each takes one ticket and then handles the scan units ticket, ticket + G, ticket + 2 G, ...  One ticket per
+// 32 centres cost 0.35 ms at 1 M atoms (a single device-scope word takes ~88 atomics per microsecond).  The look-back of unit u
+// waits for unit u - 1 = the previous ticket in the same round (or the last ticket of the previous round): all G workgroups are
+// resident, so every predecessor is running -- a grid larger than the residency would deadlock here.
 static constexpr int EB_PER_WAVE = 8;    // centres per wave
 // EB_CHUNKS (template parameter): 64-entry chunks of a list row held in registers: 1 when no row of the installed list is longer
 // than 64 entries (half the registers: 5 instead of 3 waves per SIMD in flight for this latency-bound gather), else 2
@@ -41,7 +46,7 @@ __device__ __forceinline__ unsigned long long pack_state(unsigned long long stat
 template <int EB_CHUNKS>
 __global__ void __launch_bounds__(256) k_build_edges(int inum, const int *__restrict__ ilist, const int *__restrict__ nl_off,
                                                        const int *__restrict__ nl_j, const AtomXT *__restrict__ xt,
-                                                       const double *__restrict__ cutsq, int nft,
+                                                       const double *__restrict__ cutsq, int nft, int nunits,
                                                        unsigned int *ticket, unsigned long long *status, int *eoff, int *e_ii,
                                                        int *e_j, float *rvec, int *maxdeg, int *overflow,
                                                        unsigned char *e_tt, int heavy_thresh,
@@ -53,7 +58,8 @@ __global__ void __launch_bounds__(256) k_build_edges(int inum, const int *__rest
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) s_blk = (int)atomicAdd(ticket, 1u);
   __syncthreads();
-  const int b = s_blk;
+  const int b0 = s_blk;
+  for (int b = b0; b < nunits; b += (int)gridDim.x) {
   const int a_begin = b * EB_ATOMS;
 
   // ---- gather + filter: results stay in registers -------------------------------------------------
@@ -124,7 +130,7 @@ __global__ void __launch_bounds__(256) k_build_edges(int inum, const int *__rest
     int mx = v;
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
-    if (tid == 0 && mx > 0) atomicMax(maxdeg, mx);
+    if (tid == 0 && mx > __hip_atomic_load(maxdeg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxdeg, mx);
   }
   __syncthreads();
   if (tid < 64) {
@@ -182,6 +188,8 @@ __global__ void __launch_bounds__(256) k_build_edges(int inum, const int *__rest
       }
     }
   }
+  __syncthreads();                       // the LDS counters are reused by the next unit
+  }
 }
 
 struct EdgeState { DevBuf flags, heavy, hoff, xt; };
@@ -231,11 +239,15 @@ void edges_compact_heavy(Model &m, const ComputeArgs &a) {
 bool edges_build_f32(Model &m, const ComputeArgs &a) {
   StageTimer tm(m, "edge_build", a.stream);
   const int inum = m.inum;
-  const int nblocks = (inum + EB_ATOMS - 1) / EB_ATOMS;
+  const int nunits = (inum + EB_ATOMS - 1) / EB_ATOMS;
+  int ncu = 256;
+  { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, m.device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
+  const bool one_chunk = m.max_list_row >= 0 && m.max_list_row <= 64;
+  const int nblocks = std::min(nunits, ncu * (one_chunk ? 4 : 2));          // resident grid, see k_build_edges
   if (!m.edge_state) m.edge_state = new EdgeState();
   EdgeState &st = *(EdgeState *)m.edge_state;
   // header: [0] ticket (u32), [1] maxdeg, [2] overflow, [3] number of heavy centres; status array starts at byte 64
-  const size_t bytes = 64 + (size_t)nblocks * sizeof(unsigned long long);
+  const size_t bytes = 64 + (size_t)nunits * sizeof(unsigned long long);
   st.flags.reserve(bytes);
   AHIP_CHECK(hipMemsetAsync(st.flags.p, 0, bytes, a.stream));
   const size_t cap = (size_t)std::max<long long>(m.nneigh, 1);            // upper bound: every list entry survives
@@ -251,10 +263,10 @@ bool edges_build_f32(Model &m, const ComputeArgs &a) {
   st.xt.reserve((size_t)nall * sizeof(AtomXT));
   hipLaunchKernelGGL(k_pack_xt, dim3((nall + 255) / 256), dim3(256), 0, a.stream, m.nall, a.x, a.ftype, a.mtype, (AtomXT *)st.xt.p);
 #define EB_LAUNCH(CH) hipLaunchKernelGGL(k_build_edges<CH>, dim3(nblocks), dim3(256), 0, a.stream, inum, m.d_ilist, m.d_nloff, m.d_nlj,       \
-                     (const AtomXT *)st.xt.p, a.cutsq, a.nft, (unsigned int *)hdr, (unsigned long long *)((char *)st.flags.p + 64),   \
+                     (const AtomXT *)st.xt.p, a.cutsq, a.nft, nunits, (unsigned int *)hdr, (unsigned long long *)((char *)st.flags.p + 64),   \
                      m.b_eoff.as<int>(), m.b_eii.as<int>(), m.b_ej.as<int>(), m.b_rvec.as<float>(), hdr + 1, hdr + 2,                \
                      m.b_ett.as<unsigned char>(), m.heavy_thresh, hdr + 3, st.heavy.as<int>())
-  if (m.max_list_row >= 0 && m.max_list_row <= 64) EB_LAUNCH(1); else EB_LAUNCH(2);
+  if (one_chunk) EB_LAUNCH(1); else EB_LAUNCH(2);
 #undef EB_LAUNCH
   AHIP_CHECK(hipGetLastError());
   int h3[4] = {0, 0, 0, 0}, tot = 0;

@@ -13,6 +13,15 @@
 using namespace LAMMPS_NS;
 
 static Pair *allegro_pair_creator(LAMMPS *lmp) { return new PairAllegroHIP(lmp); }
+// `pair_style nequip` (the reference builds it from the same template, pair_nequip_allegro.cpp:86-89,150,535-556): not part of
+// this build -- NequIP message passing needs ghost-to-ghost edges and a different model graph.  The style name is registered so
+// that a deck asking for it stops with a clear message instead of "Unrecognized pair style".
+static Pair *nequip_pair_creator(LAMMPS *lmp)
+{
+  lmp->error->all(FLERR, "pair_style nequip is not provided by the MI355X-native allegro-hip build: only pair_style allegro "
+                         "(strictly local Allegro models) is implemented; run NequIP models with the reference pair style");
+  return nullptr;
+}
 static Compute *allegro_compute_creator(LAMMPS *lmp, int argc, char **argv) { return new ComputeAllegroHIP<0>(lmp, argc, argv); }
 static Compute *allegro_atom_compute_creator(LAMMPS *lmp, int argc, char **argv) { return new ComputeAllegroHIP<1>(lmp, argc, argv); }
 
@@ -29,6 +38,11 @@ extern "C" void lammpsplugin_init(void *lmp, void *handle, void *regfunc)
   plugin.name = "allegro";
   plugin.info = "Allegro pair style on AMD MI355X (HIP kernels, liballegro_hip.so)";
   plugin.creator.v1 = (lammpsplugin_factory1 *) &allegro_pair_creator;
+  (*register_plugin)(&plugin, lmp);
+
+  plugin.name = "nequip";
+  plugin.info = "placeholder: stops with a clear message (only pair_style allegro is implemented on the HIP path)";
+  plugin.creator.v1 = (lammpsplugin_factory1 *) &nequip_pair_creator;
   (*register_plugin)(&plugin, lmp);
 
   plugin.style = "compute";

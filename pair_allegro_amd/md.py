@@ -99,7 +99,8 @@ class _Swap:
 class Simulation:
     def __init__(self, backend, box: Sequence[float], r_max: float, skin: float, x_global: np.ndarray,
                  mtype_global: np.ndarray, v_global: Optional[np.ndarray], device: torch.device,
-                 grid: Tuple[int, int, int] = (1, 1, 1), rank: int = 0, dist=None, dt: float = 0.001, overlap: Optional[bool] = None):
+                 grid: Tuple[int, int, int] = (1, 1, 1), rank: int = 0, dist=None, dt: float = 0.001, overlap: Optional[bool] = None,
+                 neigh_every: int = 1, neigh_delay: int = 0, neigh_check: bool = True):
         self.backend = backend
         # Overlapped schedule: local atoms are ordered interior-first at every re-neighboring; the first half of
         # the interior centres is evaluated while ghost positions travel (forward comm), then the boundary centres, and the
@@ -114,6 +115,14 @@ class Simulation:
             # the fused kernels are persistent and fill every CU: leave a few workgroup slots free, otherwise the pack / unpack
             # and RCCL kernels of the exchange stream could only start when the force kernel ends
             backend.model.set_option("reserve_wgs", 8)
+        # LAMMPS `neigh_modify every N delay M check yes|no` (the reference decks use the defaults `every 1 delay 0 check yes`
+        # via `neighbor 1.0 bin`, tests/test_python_repro_allegro.py:84-120): a rebuild is considered only on steps that are a
+        # multiple of `every` and at least `delay` steps after the last build; with `check` it happens only if some atom moved
+        # more than skin/2 since then, without it unconditionally.
+        if neigh_every < 1 or neigh_delay < 0:
+            raise ValueError("neigh_modify: every must be >= 1 and delay >= 0")
+        self.neigh_every, self.neigh_delay, self.neigh_check = int(neigh_every), int(neigh_delay), bool(neigh_check)
+        self.ago = 0                 # steps since the last build (LAMMPS neighbor->ago)
         self.n_int = 0
         self.n_half = 0
         self._flag_host = None
@@ -291,6 +300,7 @@ class Simulation:
         self.backend.build_neighbors(self.x, self.nlocal, lo, hi, self.rc)
         self.x_hold = self.x[: self.nlocal].clone()
         self.nrebuild += 1
+        self.ago = 0
 
     # ---- per-step communication -------------------------------------------------------------------
     def forward_comm(self) -> None:
@@ -340,7 +350,12 @@ class Simulation:
             self._flag_host = flag.clone()
 
     def needs_rebuild(self) -> bool:
-        """The flag posted during the previous step (False on the first step after a build)."""
+        """`neigh_modify every / delay / check`, with the displacement flag posted during the previous step."""
+        self.ago += 1
+        if self.ago < self.neigh_delay or self.ago % self.neigh_every:
+            return False
+        if not self.neigh_check:
+            return True
         if self._flag_host is None or not self._flag_posted:
             return False
         if self._flag_event is not None:

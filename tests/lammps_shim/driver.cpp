@@ -18,10 +18,11 @@ template <typename T> static std::vector<T> rd(FILE *f, size_t n) { std::vector<
 #include "lammpsplugin.h"
 #include <string>
 static std::vector<std::string> g_registered;
-static lammpsplugin_factory1 *g_pair_factory = nullptr;
+static lammpsplugin_factory1 *g_pair_factory = nullptr, *g_nequip_factory = nullptr;
 static void collect_plugin(lammpsplugin_t *p, void *) {
   g_registered.push_back(std::string(p->style) + ":" + p->name);
-  if (std::string(p->style) == "pair") g_pair_factory = p->creator.v1;
+  if (std::string(p->style) == "pair" && std::string(p->name) == "allegro") g_pair_factory = p->creator.v1;
+  if (std::string(p->style) == "pair" && std::string(p->name) == "nequip") g_nequip_factory = p->creator.v1;
 }
 
 int main(int argc, char **argv) {
@@ -34,7 +35,9 @@ int main(int argc, char **argv) {
     Pair *p = g_pair_factory ? (Pair *) g_pair_factory(&lmp) : nullptr;      // the factory builds a working pair style object
     printf("pair object %s restartinfo=%d manybody=%d\n", p ? "ok" : "null", p ? p->restartinfo : -1, p ? p->manybody_flag : -1);
     delete p;
-    return g_registered.size() == 3 && p ? 0 : 1;
+    try { if (g_nequip_factory) g_nequip_factory(&lmp); printf("pair_style nequip: no error raised\n"); }
+    catch (const LammpsAbort &e) { printf("pair_style nequip -> error->all: %s\n", e.what()); }
+    return g_registered.size() == 4 && p ? 0 : 1;
   }
   if (argc < 5) { fprintf(stderr, "usage: driver system.bin out.bin model names...\n"); return 2; }
   FILE *f = fopen(argv[1], "rb");

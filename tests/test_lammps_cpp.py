@@ -119,3 +119,5 @@ def test_cpp_plugin_registers_the_three_styles(driver):
     for name in ("registered pair:allegro", "registered compute:allegro", "registered compute:allegro/atom"):
         assert name in text
     assert "pair object ok restartinfo=0 manybody=1" in text
+    # `pair_style nequip` (pair_nequip_allegro.cpp:86-89): registered only to stop with a clear message
+    assert "registered pair:nequip" in text and "pair_style nequip -> error->all: pair_style nequip is not provided" in text

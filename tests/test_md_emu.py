@@ -105,3 +105,38 @@ def test_interior_boundary_split_equals_one_call(emu_lib, model_dir):
     np.testing.assert_allclose(out[True][1]["virial"], out[False][1]["virial"], atol=1e-10)
     np.testing.assert_allclose(out[True][2], out[False][2], atol=1e-10)
     np.testing.assert_allclose(out[True][3]["pe"], out[False][3]["pe"], rtol=1e-12)
+
+
+def test_neigh_modify_every_delay_check(emu_lib, model_dir):
+    """`neigh_modify every N delay M check yes|no` (SURVEY 8f-4): with `check no` the list is rebuilt exactly on the allowed steps;
+    with `check yes` and a generous skin never within a few steps; forces stay those of the always-fresh list."""
+    cfg = _small_cfg()
+    w = model_file.init_weights(cfg)
+    path = os.path.join(model_dir, "md_small_nm.ahip")
+    model_file.save_ahip(path, cfg, w)
+    cell, pos, _ = lmp_like.diamond_si(3)
+    vel = md.maxwell_boltzmann(len(pos), np.full(len(pos), 28.0855), 300.0, 3)
+
+    def run(**kw):
+        model = capi.Model(path, 0, emu_lib)
+        sim = md.Simulation(md.HipBackend(model, [28.0855]), np.diag(cell), cfg["r_max"], 1.0, pos, np.zeros(len(pos), np.int32),
+                            vel, torch.device("cpu"), dt=0.001, **kw)
+        sim.setup()
+        builds = []
+        for _ in range(8):
+            n0 = sim.nrebuild
+            sim.step()
+            builds.append(sim.nrebuild - n0)
+        f = sim.gather_forces()
+        model.close()
+        return builds, f
+
+    b_default, f_default = run()
+    assert sum(b_default) == 0                                        # 8 fs at 300 K: nobody moves skin/2 = 0.5 A
+    b_every, f_every = run(neigh_every=3, neigh_delay=0, neigh_check=False)
+    assert b_every == [0, 0, 1, 0, 0, 1, 0, 0]
+    b_delay, _ = run(neigh_every=1, neigh_delay=4, neigh_check=False)
+    assert b_delay == [0, 0, 0, 1, 0, 0, 0, 1]
+    np.testing.assert_allclose(f_every, f_default, atol=1e-9)         # a fresher list changes nothing while the skin holds
+    with pytest.raises(ValueError):
+        run(neigh_every=0)

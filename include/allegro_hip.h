@@ -66,6 +66,8 @@ int ahip_model_meta(const ahip_model *m, double *r_max, int *num_types, const ch
  *   "chunk_edges" = "<n>"                        max edges processed per pass (workspace bound)
  *   "reserve_wgs" = "<n>"                        half-CU workgroup slots the persistent fused kernels leave unoccupied, so that
  *                                                 kernels launched on OTHER streams (ghost exchange) can run beside them (default 0)
+ *   "cutoff_compare" = "le" | "lt"               edge kept iff rsq <= cut^2 (default; pair_nequip_allegro.cpp:507) or rsq < cut^2
+ *                                                 (the KOKKOS path of the reference, pair_nequip_allegro_kokkos.cpp:174)
  */
 int ahip_set_option(ahip_model *m, const char *key, const char *value);
 
@@ -88,6 +90,21 @@ int ahip_neigh_update_csr(ahip_model *m, int inum, int nall, const int *ilist,
  * -- the caller keeps it alive until the next update. */
 int ahip_neigh_update_dev(ahip_model *m, int inum, int nall, const int *ilist_dev,
                           const int *offsets_dev, const int *neigh_dev, long long nneigh_total);
+
+/* Same, from the device-resident list of the LAMMPS KOKKOS package: a padded 2-D table d_neighbors(i, jj) addressed as
+ * neighbors_dev[i * stride_atom + jj * stride_slot] (column-major on a GPU build: stride_atom = 1), numneigh_dev indexed by ATOM
+ * index, ilist_dev [inum].  Replaces the per-step table walk of pair_nequip_allegro_kokkos.cpp:128-131,142-181 (there every
+ * step; here once per list rebuild: the table is compacted on the device into the library's own CSR rows, nothing is kept of
+ * the caller's arrays).  Synchronises `stream` (two 4-byte read-backs). */
+int ahip_neigh_update_dev_table(ahip_model *m, int inum, int nall, const int *ilist_dev, const int *numneigh_dev,
+                                const int *neighbors_dev, long long stride_atom, long long stride_slot, int neighmask,
+                                void *stream);
+
+/* LAMMPS types (1-based, device) -> model types (device) through the pair_coeff mapping `type_mapper` [ntypes] (host, -1 =
+ * unmapped); what pair_nequip_allegro_kokkos.cpp:222-223 does every step.  Fails if an atom carries an unmapped type.
+ * Synchronises `stream`; callers run it on list-rebuild steps (the type of an atom index cannot change in between). */
+int ahip_map_types_dev(ahip_model *m, int n, const int *type_dev, int ntypes, const int *type_mapper, int *mtype_dev,
+                       void *stream);
 
 /* One force evaluation = PairNequIPAllegro<false>::compute (pair_nequip_allegro.cpp:333-407).
  *   x            [nall][3] f64 positions, locals first then ghosts (atom->x)

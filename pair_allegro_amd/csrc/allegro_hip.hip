@@ -185,6 +185,10 @@ int ahip_set_option(ahip_model *m, const char *key, const char *value) {
       int n = std::atoi(value);
       if (n < 0 || n > 128) throw ArgError("option reserve_wgs: expected 0..128");
       m->reserve_wgs = n;
+    } else if (k == "cutoff_compare") {
+      if (v != "le" && v != "lt") throw ArgError("option cutoff_compare: expected le|lt");
+      m->cutoff_strict = v == "lt";
+      m->h_cutsq_dev.clear();
     } else if (k == "timing") {
       m->timing = (v == "1" || v == "on" || v == "true");
     } else throw ArgError("unknown option '" + k + "'");
@@ -302,6 +306,13 @@ static void collect_timings(ahip_model *m) {
   }
 }
 
+// The kernels keep an edge iff rsq <= bound.  bound = cut^2 gives the host path's `<=` (pair_nequip_allegro.cpp:507); the largest
+// double below cut^2 gives the KOKKOS path's strict `<` (pair_nequip_allegro_kokkos.cpp:174) without touching the kernels.
+static double cutsq_bound(const ahip_model *m, double c) {
+  const double c2 = c * c;
+  return m->cutoff_strict ? std::nextafter(c2, 0.0) : c2;
+}
+
 static __global__ void k_add7(double *dst, const double *src) { if (threadIdx.x < 7) dst[threadIdx.x] += src[threadIdx.x]; }
 
 // The few centres that do not fit a tile of the wide fused kernel: layer-at-a-time float32 kernels on a compact copy of their
@@ -397,7 +408,7 @@ int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const i
       m->h_ftype[i] = t - 1; m->h_mtype[i] = mt;
     }
     std::vector<double> cutsq((size_t)ntypes * ntypes);
-    for (size_t k = 0; k < cutsq.size(); ++k) cutsq[k] = cutoff_matrix[k] * cutoff_matrix[k];
+    for (size_t k = 0; k < cutsq.size(); ++k) cutsq[k] = cutsq_bound(m, cutoff_matrix[k]);
     m->b_x.reserve((size_t)nall * 3 * sizeof(double));
     m->b_ftype.reserve((size_t)nall * sizeof(int));
     m->b_mtype.reserve((size_t)nall * sizeof(int));
@@ -490,7 +501,7 @@ int ahip_compute_dev(ahip_model *m, int nlocal, int nghost, const double *x_dev,
     std::vector<double> cutsq((size_t)T * T);
     for (size_t k = 0; k < cutsq.size(); ++k) {
       double c = cutoff_matrix_model ? cutoff_matrix_model[k] : m->rcut_model_host[k];
-      cutsq[k] = c * c;
+      cutsq[k] = cutsq_bound(m, c);
     }
     if (cutsq != m->h_cutsq_dev) {                           // upload (and synchronise) only when the matrix changes
       m->b_cutsq.reserve(cutsq.size() * sizeof(double));
@@ -603,6 +614,27 @@ int ahip_build_neighbors_dev(ahip_model *m, int nlocal, int nall, const double *
     if (!x_dev || !lo || !hi || !(rc_list > 0)) throw ArgError("ahip_build_neighbors_dev: bad argument");
     AHIP_CHECK(hipSetDevice(m->device));
     neigh_build(*m, nlocal, nall, x_dev, lo, hi, rc_list, (hipStream_t)stream);
+  });
+}
+
+int ahip_neigh_update_dev_table(ahip_model *m, int inum, int nall, const int *ilist_dev, const int *numneigh_dev,
+                                const int *neighbors_dev, long long stride_atom, long long stride_slot, int neighmask, void *stream) {
+  return guarded([&] {
+    require_model(m);
+    check_list_dims(inum, nall);
+    if (inum > 0 && (!ilist_dev || !numneigh_dev || !neighbors_dev)) throw ArgError("ahip_neigh_update_dev_table: NULL list pointer");
+    if (stride_atom < 1 || stride_slot < 1) throw ArgError("ahip_neigh_update_dev_table: strides must be positive");
+    AHIP_CHECK(hipSetDevice(m->device));
+    neigh_from_table(*m, inum, nall, ilist_dev, numneigh_dev, neighbors_dev, stride_atom, stride_slot, neighmask, (hipStream_t)stream);
+  });
+}
+
+int ahip_map_types_dev(ahip_model *m, int n, const int *type_dev, int ntypes, const int *type_mapper, int *mtype_dev, void *stream) {
+  return guarded([&] {
+    require_model(m);
+    if (n < 0 || ntypes < 1 || !type_mapper || (n > 0 && (!type_dev || !mtype_dev))) throw ArgError("ahip_map_types_dev: bad argument");
+    AHIP_CHECK(hipSetDevice(m->device));
+    map_types(*m, n, type_dev, ntypes, type_mapper, mtype_dev, (hipStream_t)stream);
   });
 }
 

@@ -90,6 +90,7 @@ struct Model {
   long long chunk_edges = 2000000;
   int reserve_wgs = 0;                      // workgroup slots the persistent fused kernels leave free (for kernels of other streams)
   bool timing = false;
+  bool cutoff_strict = false;               // edge kept iff rsq < cut^2 (the KOKKOS reference path) instead of rsq <= cut^2 (the host path)
 
   // weights
   DeviceWeights<float> wf;
@@ -220,6 +221,9 @@ bool tp_bwd_f32(hipStream_t s, long long E, int L, bool scalar_only, int U, cons
 // ---- neighbor builder (neigh.hip; stubbed in the host-emulation build) -------------------------
 void neigh_build(Model &m, int nlocal, int nall, const double *x_dev, const double *lo, const double *hi,
                  double rc_list, hipStream_t s);
+void neigh_from_table(Model &m, int inum, int nall, const int *ilist_dev, const int *numneigh_dev, const int *table_dev,
+                      long long stride_atom, long long stride_slot, int mask, hipStream_t s);
+void map_types(Model &m, int n, const int *type_dev, int ntypes, const int *mapper_host, int *out_dev, hipStream_t s);
 void neigh_free(Model &m);
 void nve_step(int mode, int n, double *x, double *v, const double *f, const int *mtype, const double *mass_dev_or_host,
               int ntypes, double dt, double ftm2v, hipStream_t s);

@@ -11,7 +11,7 @@
 namespace ahip {
 
 struct NbState {
-  DevBuf bin_of, bin_cnt, bin_start, bin_fill, sorted, cnt, off, nlj, ilist, box;
+  DevBuf bin_of, bin_cnt, bin_start, bin_fill, sorted, cnt, off, nlj, ilist, box, mapper;
   long long cap_j = 0;
 };
 
@@ -151,10 +151,103 @@ void neigh_build(Model &m, int nlocal, int nall, const double *x_dev, const doub
   m.h_ilist.clear();
 }
 
+// ---------------------------------------------------------------- device-resident LAMMPS list (KOKKOS package layout)
+// The KOKKOS package keeps the full list as a padded 2-D table d_neighbors(i, jj) (column-major on a GPU build) with
+// d_numneigh[i] valid entries per ATOM index (pair_nequip_allegro_kokkos.cpp:128-131,157-163 reads exactly these).  On a
+// rebuild step it is compacted once into the CSR rows every later evaluation walks; the reference instead re-filters the whole
+// table every step into a second padded table (:142-181).
+__global__ void k_table_counts(int inum, int nall, const int *ilist, const int *numneigh, int *cnt, int *ilist_out, int *bad) {
+  long long ii = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ii >= inum) return;
+  const int i = ilist[ii];
+  if (i < 0 || i >= nall) { atomicMax(bad, 1); cnt[ii] = 0; ilist_out[ii] = 0; return; }
+  const int n = numneigh[i];
+  if (n < 0) atomicMax(bad, 2);
+  cnt[ii] = n < 0 ? 0 : n;
+  ilist_out[ii] = i;
+}
+__global__ void k_table_rows(int inum, int nall, const int *ilist, const int *cnt, const int *off, const int *table, long long stride_atom,
+                             long long stride_slot, int mask, int *nlj, int *bad) {
+  long long ii = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ii >= inum) return;
+  const int i = ilist[ii], n = cnt[ii];
+  const int *row = table + (long long)i * stride_atom;
+  int *dst = nlj + off[ii];
+  for (int jj = 0; jj < n; ++jj) {
+    const int j = row[jj * stride_slot] & mask;
+    if (j < 0 || j >= nall) atomicMax(bad, 3);
+    dst[jj] = j;
+  }
+}
+
+void neigh_from_table(Model &m, int inum, int nall, const int *ilist_dev, const int *numneigh_dev, const int *table_dev,
+                      long long stride_atom, long long stride_slot, int mask, hipStream_t s) {
+  if (!m.nb_state) m.nb_state = new NbState();
+  NbState &st = *(NbState *)m.nb_state;
+  const unsigned B = 256;
+  auto grid = [&](long long n) { return dim3((unsigned)((n + B - 1) / B)); };
+  st.cnt.reserve((size_t)(inum + 1) * sizeof(int));
+  st.off.reserve((size_t)(inum + 2) * sizeof(int));
+  st.ilist.reserve((size_t)std::max(inum, 1) * sizeof(int));
+  st.box.reserve(64);
+  int *bad = st.box.as<int>() + 1;
+  AHIP_CHECK(hipMemsetAsync(st.box.p, 0, 64, s));
+  if (inum > 0)
+    hipLaunchKernelGGL(k_table_counts, grid(inum), dim3(B), 0, s, inum, nall, ilist_dev, numneigh_dev, st.cnt.as<int>(), st.ilist.as<int>(), bad);
+  AHIP_CHECK(prim_exclusive_scan_i32(m.prim, st.cnt.as<int>(), st.off.as<int>(), inum, s));
+  AHIP_CHECK(prim_max_i32(st.cnt.as<int>(), inum, st.box.as<int>(), s));
+  int tot = 0, hb[2] = {0, 0};
+  AHIP_CHECK(hipMemcpyAsync(&tot, st.off.as<int>() + inum, sizeof(int), hipMemcpyDeviceToHost, s));
+  AHIP_CHECK(hipMemcpyAsync(hb, st.box.as<int>(), 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  AHIP_CHECK(hipStreamSynchronize(s));
+  if (hb[1] == 1) throw ArgError("neighbor list: ilist entry out of range");
+  if (hb[1] == 2) throw ArgError("neighbor list: negative numneigh");
+  st.nlj.reserve((size_t)std::max(tot, 1) * sizeof(int));
+  if (inum > 0)
+    hipLaunchKernelGGL(k_table_rows, grid(inum), dim3(B), 0, s, inum, nall, st.ilist.as<int>(), st.cnt.as<int>(), st.off.as<int>(), table_dev, stride_atom,
+                       stride_slot, mask, st.nlj.as<int>(), bad);
+  AHIP_CHECK(hipMemcpyAsync(hb, st.box.as<int>(), 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  AHIP_CHECK(hipStreamSynchronize(s));
+  AHIP_CHECK(hipGetLastError());
+  if (hb[1] == 3) throw ArgError("neighbor list: neighbour index out of range");
+  m.d_ilist = st.ilist.as<int>();
+  m.d_nloff = st.off.as<int>();
+  m.d_nlj = st.nlj.as<int>();
+  m.inum = inum; m.nall = nall; m.nneigh = tot; m.have_list = true;
+  m.max_list_row = hb[0];
+  m.h_ilist.clear();
+}
+
+// LAMMPS types (1-based) -> model types through the pair_coeff mapping (pair_nequip_allegro_kokkos.cpp:222-223 does this every
+// step; the types of an atom index only change when the list is rebuilt, so callers do it on those steps).
+__global__ void k_map_types(int n, const int *type, int ntypes, const int *mapper, int nmodel, int *out, int *bad) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int t = type[i];
+  int mt = (t >= 1 && t <= ntypes) ? mapper[t - 1] : -2;
+  if (mt < 0 || mt >= nmodel) { atomicMax(bad, mt == -2 ? 2 : 1); mt = 0; }
+  out[i] = mt;
+}
+void map_types(Model &m, int n, const int *type_dev, int ntypes, const int *mapper_host, int *out_dev, hipStream_t s) {
+  if (!m.nb_state) m.nb_state = new NbState();
+  NbState &st = *(NbState *)m.nb_state;
+  st.mapper.reserve((size_t)std::max(ntypes, 1) * sizeof(int) + 64);
+  int *bad = st.mapper.as<int>() + ntypes;
+  AHIP_CHECK(hipMemcpyAsync(st.mapper.p, mapper_host, (size_t)ntypes * sizeof(int), hipMemcpyHostToDevice, s));
+  AHIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), s));
+  AHIP_CHECK(hipStreamSynchronize(s));                        // mapper_host may be a temporary
+  if (n > 0) hipLaunchKernelGGL(k_map_types, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, type_dev, ntypes, st.mapper.as<int>(), m.hm.num_types, out_dev, bad);
+  int hb = 0;
+  AHIP_CHECK(hipMemcpyAsync(&hb, bad, sizeof(int), hipMemcpyDeviceToHost, s));
+  AHIP_CHECK(hipStreamSynchronize(s));
+  if (hb == 2) throw ArgError("ahip_map_types_dev: atom type out of range");
+  if (hb == 1) throw ArgError("ahip_map_types_dev: an atom has a LAMMPS type that is not mapped to a model type (all pair coeffs are not set)");
+}
+
 void neigh_free(Model &m) {
   if (!m.nb_state) return;
   NbState *st = (NbState *)m.nb_state;
-  for (DevBuf *b : {&st->bin_of, &st->bin_cnt, &st->bin_start, &st->bin_fill, &st->sorted, &st->cnt, &st->off, &st->nlj, &st->ilist, &st->box})
+  for (DevBuf *b : {&st->bin_of, &st->bin_cnt, &st->bin_start, &st->bin_fill, &st->sorted, &st->cnt, &st->off, &st->nlj, &st->ilist, &st->box, &st->mapper})
     b->release();
   delete st;
   m.nb_state = nullptr;

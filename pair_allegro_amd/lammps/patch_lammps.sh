@@ -9,6 +9,9 @@ repo_dir=${2:-$(cd "$(dirname "$0")/../.." && pwd)}
 cp "$repo_dir"/pair_allegro_amd/lammps/pair_allegro_hip.{h,cpp} "$lammps_dir/src/"
 cp "$repo_dir"/pair_allegro_amd/lammps/compute_allegro_hip.{h,cpp} "$lammps_dir/src/"      # compute allegro, compute allegro/atom
 cp "$repo_dir"/include/allegro_hip.h "$lammps_dir/src/"
+if [ -d "$lammps_dir/src/KOKKOS" ]; then      # pair_style allegro/kk (device-resident coupling, HIP backend of the KOKKOS package)
+  cp "$repo_dir"/pair_allegro_amd/lammps/pair_allegro_hip_kokkos.{h,cpp} "$lammps_dir/src/KOKKOS/"
+fi
 cat >> "$lammps_dir/cmake/CMakeLists.txt" <<CMAKE
 
 # --- allegro-hip: MI355X-native pair_style allegro -------------------------------------------

@@ -1,0 +1,1 @@
+#include "kokkos_shim.h"

@@ -42,7 +42,9 @@ class Memory {
   template <typename T> T *create(T *&a, int n, const char *) { a = new T[n](); return a; }
   template <typename T> void destroy(T *&a) { delete[] a; a = nullptr; }
 };
-class Atom { public: int tag_enable = 1, ntypes = 1, nlocal = 0, nghost = 0, nmax = 0; double **x = nullptr, **f = nullptr; int *type = nullptr; tagint *tag = nullptr; };
+enum ExecutionSpace { Host, Device };
+class AtomKokkos; class MemoryKokkos; class KokkosLMP;
+class Atom { public: virtual ~Atom() = default; int tag_enable = 1, ntypes = 1, nlocal = 0, nghost = 0, nmax = 0; double **x = nullptr, **f = nullptr; int *type = nullptr; tagint *tag = nullptr; };
 class Compute;
 class Pair;
 class Comm {
@@ -56,18 +58,21 @@ class Force { public: int newton_pair = 1; Pair *pair = nullptr; };
 class Update { public: bigint ntimestep = 0; };
 class NeighList { public: int inum = 0, gnum = 0; int *ilist = nullptr, *numneigh = nullptr; int **firstneigh = nullptr; };
 namespace NeighConst { enum { REQ_FULL = 1, REQ_GHOST = 2 }; }
-class Neighbor { public: bigint lastcall = 0; int ago = 0; int requested = 0; void add_request(Pair *, int flags) { requested = flags; } };
+class NeighRequest { public: int kokkos_host = -1, kokkos_device = -1; void set_kokkos_host(int v) { kokkos_host = v; } void set_kokkos_device(int v) { kokkos_device = v; } };
+class Neighbor { public: bigint lastcall = 0; int ago = 0; int requested = 0; NeighRequest request; void add_request(Pair *, int flags) { requested = flags; }
+                 NeighRequest *find_request(Pair *) { return &request; } };
 
 class LAMMPS {
  public:
   Atom *atom; Comm *comm; Force *force; Neighbor *neighbor; Error *error; Memory *memory; MPI_Comm world = 0;
   Update *update = nullptr;
+  AtomKokkos *atomKK = nullptr; MemoryKokkos *memoryKK = nullptr; KokkosLMP *kokkos = nullptr;     // KOKKOS package (kokkos_shim.h)
 };
 
 class Pair {
  public:
   explicit Pair(LAMMPS *l) : lmp(l), atom(l->atom), comm(l->comm), force(l->force), neighbor(l->neighbor), error(l->error),
-                             memory(l->memory), world(l->world) {}
+                             memory(l->memory), world(l->world), atomKK(l->atomKK), memoryKK(l->memoryKK) {}
   virtual ~Pair() = default;
   virtual void compute(int, int) = 0;
   virtual void settings(int, char **) = 0;
@@ -80,13 +85,17 @@ class Pair {
   NeighList *list = nullptr;
   double eng_vdwl = 0, virial[6] = {0, 0, 0, 0, 0, 0};
   double *eatom = nullptr;
-  int eflag_atom = 0, vflag_atom = 0, eflag_global = 0, vflag_global = 0;
-  void ev_init(int eflag, int vflag) {            // the part of Pair::ev_setup the subclass relies on
+  int eflag_atom = 0, vflag_atom = 0, eflag_global = 0, vflag_global = 0, vflag_fdotr = 0;
+  int respa_enable = 1, kokkosable = 0, maxeatom = 0;
+  ExecutionSpace execution_space = Host; unsigned int datamask_read = 0, datamask_modify = 0;
+  void ev_init(int eflag, int vflag, int /*alloc*/ = 1) {            // the part of Pair::ev_setup the subclass relies on
+    if ((eflag & 2) && atom->nmax > maxeatom) maxeatom = atom->nmax;
     eflag_global = eflag & 1; eflag_atom = (eflag & 2) ? 1 : 0; vflag_global = vflag & 3; vflag_atom = (vflag & 4) ? 1 : 0;
     eng_vdwl = 0; for (double &v : virial) v = 0;
   }
  protected:
   LAMMPS *lmp; Atom *atom; Comm *comm; Force *force; Neighbor *neighbor; Error *error; Memory *memory; MPI_Comm world;
+  AtomKokkos *atomKK; MemoryKokkos *memoryKK;
 };
 
 class Compute {

@@ -4,9 +4,10 @@
 //
 //  * one wave per centre row: the row's neighbour indices are read coalesced (64 per instruction), the
 //    gathered x_j / type_j are the only random traffic; `rsq <= cut^2` in float64 (host-path semantics);
-//  * survivors are compacted with ballot/mbcnt and kept in registers (8 centres per wave);
-//  * the global edge offsets come from a decoupled look-back scan over 32-centre blocks (block order taken
-//    from an atomic ticket, so a block's predecessors have always started), so the neighbour data is
+//  * survivors are compacted with ballot/mbcnt and kept in registers (8 centres per wave), the loads of the 8 centres are
+//    issued together (8 gathers per lane in flight) and the next unit's row bounds / indices are requested a unit ahead;
+//  * the global edge offsets come from a decoupled look-back scan over 64-centre units (unit order taken
+//    from an atomic ticket, so a unit's predecessors have always started), so the neighbour data is
 //    gathered ONCE -- the two-pass version (generic_kernels.h) gathers it twice;
 //  * every block then writes its edges to one contiguous range of e_ii / e_j / rvec.
 // Output layout is identical to k_count_edges + scan + k_fill_edges: edges grouped by centre, list order.
@@ -17,10 +18,13 @@
 
 namespace ahip {
 
-static constexpr int EB_ATOMS = 32;      // centres per scan unit (one status word each)
-// The kernel is PERSISTENT: a grid of resident workgroups (<= 4 per CU, below the 5 its registers admit; 2 per CU for the
-// two-chunk instance) each takes one ticket and then handles the scan units ticket, ticket + G, ticket + 2 G, ...  One ticket per
-// 32 centres cost 0.35 ms at 1 M atoms (a single device-scope word takes ~88 atomics per microsecond).  The look-back of unit u
+static constexpr int EB_ATOMS = 64;      // centres per scan unit (one status word each): 8 waves x 8 centres
+static constexpr int EB_THREADS = EB_ATOMS / 8 * 64;
+static constexpr int LB_PER_LANE = 1;   // look-back window = 64 * LB_PER_LANE predecessors per poll (8: 0.93 ms instead of 0.70 -- the polls themselves load the L2)
+// The kernel is PERSISTENT: a grid of resident 8-wave workgroups (2 per CU = the 4 waves per SIMD its registers admit; 1 per CU
+// for the two-chunk instance) each takes one ticket and then handles the scan units ticket, ticket + G, ticket + 2 G, ...  One
+// ticket per unit cost 0.35 ms at 1 M atoms (a single device-scope word takes ~88 atomics per microsecond).  The look-back
+// costs (units) x (half the resident grid / 64) dependent polls in total, i.e. it shrinks with the unit size: 64 centres.  The look-back of unit u
 // waits for unit u - 1 = the previous ticket in the same round (or the last ticket of the previous round): all G workgroups are
 // resident, so every predecessor is running -- a grid larger than the residency would deadlock here.
 static constexpr int EB_PER_WAVE = 8;    // centres per wave
@@ -44,84 +48,135 @@ __global__ void __launch_bounds__(256) k_pack_xt(int nall, const double *__restr
 __device__ __forceinline__ unsigned long long pack_state(unsigned long long state, unsigned long long v) { return (state << 62) | v; }
 
 template <int EB_CHUNKS>
-__global__ void __launch_bounds__(256) k_build_edges(int inum, const int *__restrict__ ilist, const int *__restrict__ nl_off,
+__global__ void __launch_bounds__(EB_THREADS) k_build_edges(int inum, const int *__restrict__ ilist, const int *__restrict__ nl_off,
                                                        const int *__restrict__ nl_j, const AtomXT *__restrict__ xt,
                                                        const double *__restrict__ cutsq, int nft, int nunits,
                                                        unsigned int *ticket, unsigned long long *status, int *eoff, int *e_ii,
                                                        int *e_j, float *rvec, int *maxdeg, int *overflow,
                                                        unsigned char *e_tt, int heavy_thresh,
                                                        int *heavy_cnt, int *heavy_list) {
-  __shared__ int s_cnt[EB_ATOMS];
-  __shared__ int s_base[EB_ATOMS + 1];
+  __shared__ int s_cnt2[2][EB_ATOMS];          // counters of two consecutive units (no barrier between the stores of one and the
+  __shared__ int s_base2[2][EB_ATOMS + 1];     // counting of the next)
   __shared__ int s_blk;
-  __shared__ long long s_prefix;
+  __shared__ long long s_prefix2[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) s_blk = (int)atomicAdd(ticket, 1u);
   __syncthreads();
   const int b0 = s_blk;
-  for (int b = b0; b < nunits; b += (int)gridDim.x) {
+  const int uwave = __builtin_amdgcn_readfirstlane(wave);
+  int run_max = 0;                       // largest edge count seen by this workgroup (thread 0), published once at the end
+  constexpr int NB = EB_CHUNKS == 1 ? EB_PER_WAVE : 2;
+  // Row bounds, centre indices and the first batch's neighbour indices of the NEXT unit are requested while the current one is
+  // in its scan / look-back / store phases: at the top of the loop only the gathers (one memory round trip) are still to be
+  // issued instead of a chain of three.
+  int n_ci[EB_PER_WAVE], n_p0[EB_PER_WAVE], n_p1[EB_PER_WAVE], n_js[NB][EB_CHUNKS];
+  int l_il = 0, l_off = 0;
+  auto request_rows = [&](int bb) {      // lanes 0..7: centre indices, lanes 0..8: row offsets (clamped: past the end = empty rows)
+    const int ii0 = bb * EB_ATOMS + uwave * EB_PER_WAVE;
+    l_il = ilist[min(ii0 + min(lane, EB_PER_WAVE - 1), inum - 1)];
+    l_off = nl_off[min(ii0 + min(lane, EB_PER_WAVE), inum)];
+  };
+  auto take_rows = [&]() {
+#pragma unroll
+    for (int q = 0; q < EB_PER_WAVE; ++q) {
+      n_ci[q] = __builtin_amdgcn_readlane(l_il, q);
+      n_p0[q] = __builtin_amdgcn_readlane(l_off, q);
+      n_p1[q] = __builtin_amdgcn_readlane(l_off, q + 1);
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+      for (int c = 0; c < EB_CHUNKS; ++c) {
+        const int p = n_p0[q] + c * 64 + lane;
+        n_js[q][c] = p < n_p1[q] ? nl_j[p] : n_ci[q];          // lanes past the row end gather the centre itself (and drop it)
+      }
+  };
+  request_rows(b0);
+  take_rows();
+  int par = 0;
+  for (int b = b0; b < nunits; b += (int)gridDim.x, par ^= 1) {
   const int a_begin = b * EB_ATOMS;
+  int *s_cnt = s_cnt2[par], *s_base = s_base2[par];
+  long long &s_prefix = s_prefix2[par];
 
   // ---- gather + filter: results stay in registers -------------------------------------------------
+  // Loads are issued in BATCHES of NB centres (8 gathers per lane in flight): first the row bounds and the centre records of
+  // the batch (wave-uniform: scalar loads), then all neighbour indices, then all gathers, and only then the arithmetic and the
+  // ballots.  One centre at a time (load -> dependent load -> ballot) left a single four-deep dependent chain per wave in flight
+  // and made the kernel latency-bound at half its run time.
   int jj[EB_PER_WAVE][EB_CHUNKS];
   float dxs[EB_PER_WAVE][EB_CHUNKS], dys[EB_PER_WAVE][EB_CHUNKS], dzs[EB_PER_WAVE][EB_CHUNKS];
   int rank[EB_PER_WAVE][EB_CHUNKS];      // -1 = dropped, else position inside the centre's edge range
   int tts[EB_PER_WAVE][EB_CHUNKS];       // (model type of centre) << 4 | (model type of neighbour), for the fused kernel
   int kept_k[EB_PER_WAVE];
+  int c_ci[EB_PER_WAVE], c_p0[EB_PER_WAVE], c_p1[EB_PER_WAVE];
 #pragma unroll
-  for (int k = 0; k < EB_PER_WAVE; ++k) {
-    const int la = wave * EB_PER_WAVE + k;
-    const int ii = a_begin + la;
-    int kept = 0;
-    if (ii < inum) {
-      const int i = ilist[ii];
-      const AtomXT ci = xt[i];
-      const double xi = ci.x, yi = ci.y, zi = ci.z;
-      const double *crow = cutsq + (size_t)ci.ft * nft;
-      const int mti = ci.mt;
-      const int p0 = nl_off[ii], p1 = nl_off[ii + 1];
-      if (p1 - p0 > 64 * EB_CHUNKS && lane == 0) atomicOr(overflow, 1);
+  for (int q = 0; q < EB_PER_WAVE; ++q) { c_ci[q] = n_ci[q]; c_p0[q] = n_p0[q]; c_p1[q] = n_p1[q]; }
+#pragma unroll
+  for (int kb = 0; kb < EB_PER_WAVE; kb += NB) {
+    int ci_i[NB], p0s[NB], p1s[NB];
+    AtomXT cis[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) { ci_i[q] = c_ci[kb + q]; p0s[q] = c_p0[kb + q]; p1s[q] = c_p1[kb + q]; }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) cis[q] = xt[ci_i[q]];
+    int js[NB][EB_CHUNKS];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      if (p1s[q] - p0s[q] > 64 * EB_CHUNKS && lane == 0) atomicOr(overflow, 1);
 #pragma unroll
       for (int c = 0; c < EB_CHUNKS; ++c) {
-        const int p = p0 + c * 64 + lane;
-        const bool valid = p < p1;
-        int j = 0, tt = 0;
-        bool keep = false;
-        float fx = 0.f, fy = 0.f, fz = 0.f;
-        if (valid) {
-          j = nl_j[p];
-          const AtomXT cj = xt[j];                              // two 16-byte loads of one 32-byte sector
-          const double ddx = cj.x - xi, ddy = cj.y - yi, ddz = cj.z - zi;
-          const double rsq = ddx * ddx + ddy * ddy + ddz * ddz;
-          keep = rsq <= crow[cj.ft];
-          tt = (mti << 4) | cj.mt;
-          fx = (float)ddx; fy = (float)ddy; fz = (float)ddz;       // neighbour - centre, f64 difference cast to f32
+        if (kb == 0) js[q][c] = n_js[q][c];                    // requested during the previous unit
+        else {
+          const int p = p0s[q] + c * 64 + lane;
+          js[q][c] = p < p1s[q] ? nl_j[p] : ci_i[q];
         }
+      }
+    }
+    AtomXT cjs[NB][EB_CHUNKS];
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+      for (int c = 0; c < EB_CHUNKS; ++c) cjs[q][c] = xt[js[q][c]];    // two 16-byte loads of one 32-byte sector
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int k = kb + q;
+      const double xi = cis[q].x, yi = cis[q].y, zi = cis[q].z;
+      const double *crow = cutsq + (size_t)cis[q].ft * nft;
+      const int mti = cis[q].mt;
+      int kept = 0;
+#pragma unroll
+      for (int c = 0; c < EB_CHUNKS; ++c) {
+        const bool valid = p0s[q] + c * 64 + lane < p1s[q];
+        const AtomXT cj = cjs[q][c];
+        const double ddx = cj.x - xi, ddy = cj.y - yi, ddz = cj.z - zi;
+        const double rsq = ddx * ddx + ddy * ddy + ddz * ddz;
+        const bool keep = valid && rsq <= crow[cj.ft];
         const unsigned long long mask = __ballot(keep);
         const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-        jj[k][c] = j; dxs[k][c] = fx; dys[k][c] = fy; dzs[k][c] = fz; tts[k][c] = tt;
+        jj[k][c] = js[q][c]; tts[k][c] = (mti << 4) | cj.mt;
+        dxs[k][c] = (float)ddx; dys[k][c] = (float)ddy; dzs[k][c] = (float)ddz;       // neighbour - centre, f64 difference cast to f32
         rank[k][c] = keep ? kept + below : -1;
         kept += __popcll(mask);
       }
-    } else {
-#pragma unroll
-      for (int c = 0; c < EB_CHUNKS; ++c) { jj[k][c] = 0; dxs[k][c] = dys[k][c] = dzs[k][c] = 0.f; rank[k][c] = -1; tts[k][c] = 0; }
-    }
-    kept_k[k] = kept;
-    if (lane == 0) {
-      s_cnt[la] = kept;
-      // centres with more edges than a tile of the wide fused kernel holds: listed for the layer-at-a-time kernels
-      if (heavy_thresh > 0 && kept > heavy_thresh) heavy_list[atomicAdd(heavy_cnt, 1)] = ii;
+      kept_k[k] = kept;
+      if (lane == 0) {
+        const int la = uwave * EB_PER_WAVE + k;
+        s_cnt[la] = kept;
+        // centres with more edges than a tile of the wide fused kernel holds: listed for the layer-at-a-time kernels
+        if (heavy_thresh > 0 && kept > heavy_thresh) heavy_list[atomicAdd(heavy_cnt, 1)] = a_begin + la;
+      }
     }
   }
+  request_rows(b + (int)gridDim.x);      // answered during the scan and the look-back
   __syncthreads();
 
-  // ---- block scan of the 32 counts, then decoupled look-back for the block's global offset ----------
+  // ---- block scan of the 64 counts, then decoupled look-back for the block's global offset ----------
   if (tid < 64) {
     int v = tid < EB_ATOMS ? s_cnt[tid] : 0;
     int inc = v;
 #pragma unroll
-    for (int off = 1; off < 32; off <<= 1) {
+    for (int off = 1; off < EB_ATOMS; off <<= 1) {
       int t = __shfl_up(inc, off, 64);
       if (lane >= off) inc += t;
     }
@@ -129,15 +184,12 @@ __global__ void __launch_bounds__(256) k_build_edges(int inum, const int *__rest
     if (tid == 0) s_base[0] = 0;
     int mx = v;
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
-    if (tid == 0 && mx > __hip_atomic_load(maxdeg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxdeg, mx);
-  }
-  __syncthreads();
-  if (tid < 64) {
+    for (int off = EB_ATOMS / 2; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+    run_max = max(run_max, mx);
     // decoupled look-back, one WAVE wide: lane l polls predecessor b-1-l; the window closes at the nearest predecessor that has
     // published its inclusive prefix (state 2), everything nearer contributes its aggregate (state 1).  (A one-lane walk costs
     // one dependent global load per predecessor: with ~1000 blocks resident the chain was the kernel's critical path.)
-    const unsigned long long agg = (unsigned long long)s_base[EB_ATOMS];
+    const unsigned long long agg = (unsigned long long)__shfl(inc, EB_ATOMS - 1, 64);
     const unsigned long long VMASK = (1ull << 62) - 1;
     unsigned long long prefix = 0;
     if (b == 0) {
@@ -146,19 +198,32 @@ __global__ void __launch_bounds__(256) k_build_edges(int inum, const int *__rest
       if (lane == 0) __hip_atomic_store(&status[b], pack_state(1, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int base = b - 1;
       for (;;) {
-        const int k = base - lane;
-        const unsigned long long v = k >= 0 ? __hip_atomic_load(&status[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pack_state(2, 0);
-        const unsigned st2 = (unsigned)(v >> 62);
-        const unsigned long long ready = __ballot(st2 != 0), incl = __ballot(st2 == 2);
-        const int first2 = incl ? __builtin_ctzll(incl) : 64;                 // nearest predecessor with an inclusive prefix
+        // lane l polls the LB_PER_LANE predecessors base - LB_PER_LANE * l - q (independent loads, one round trip for a window of
+        // 64 * LB_PER_LANE units = a whole round of the resident grid: the units of a round publish their aggregates at about
+        // the same time, so a 64-wide window walked the round in ~8 dependent round trips)
+        unsigned long long sum_pref = 0;
+        bool ready_pref = true, has2 = false;
+        unsigned long long v[LB_PER_LANE];
+#pragma unroll
+        for (int q = 0; q < LB_PER_LANE; ++q) {
+          const int k = base - (lane * LB_PER_LANE + q);
+          v[q] = k >= 0 ? __hip_atomic_load(&status[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pack_state(2, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < LB_PER_LANE; ++q) {
+          const unsigned st2 = (unsigned)(v[q] >> 62);
+          if (!has2) { ready_pref = ready_pref && st2 != 0; sum_pref += v[q] & VMASK; has2 = st2 == 2; }
+        }
+        const unsigned long long incl = __ballot(has2), ready = __ballot(ready_pref);
+        const int first2 = incl ? __builtin_ctzll(incl) : 64;                 // lane holding the nearest inclusive prefix
         const unsigned long long need = first2 < 63 ? ((2ull << first2) - 1) : ~0ull;
         if ((ready & need) == need) {
-          unsigned long long c = lane <= first2 ? (v & VMASK) : 0ull;
+          unsigned long long c = lane <= first2 ? sum_pref : 0ull;
 #pragma unroll
           for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
           prefix += c;
           if (first2 < 64) break;
-          base -= 64;
+          base -= 64 * LB_PER_LANE;
         } else __builtin_amdgcn_s_sleep(1);
       }
       if (lane == 0) __hip_atomic_store(&status[b], pack_state(2, prefix + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -169,6 +234,7 @@ __global__ void __launch_bounds__(256) k_build_edges(int inum, const int *__rest
   const long long gbase = s_prefix;
 
   // ---- offsets + edges -------------------------------------------------------------------------------
+  take_rows();                           // next unit's rows have arrived; its neighbour indices travel during the stores
   if (tid < EB_ATOMS && a_begin + tid < inum) eoff[a_begin + tid] = (int)(gbase + s_base[tid]);
   if (tid == 0 && a_begin + EB_ATOMS >= inum) eoff[inum] = (int)(gbase + s_base[min(EB_ATOMS, inum - a_begin)]);
 #pragma unroll
@@ -188,8 +254,8 @@ __global__ void __launch_bounds__(256) k_build_edges(int inum, const int *__rest
       }
     }
   }
-  __syncthreads();                       // the LDS counters are reused by the next unit
   }
+  if (tid == 0 && run_max > 0) atomicMax(maxdeg, run_max);
 }
 
 struct EdgeState { DevBuf flags, heavy, hoff, xt; };
@@ -243,7 +309,7 @@ bool edges_build_f32(Model &m, const ComputeArgs &a) {
   int ncu = 256;
   { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, m.device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
   const bool one_chunk = m.max_list_row >= 0 && m.max_list_row <= 64;
-  const int nblocks = std::min(nunits, ncu * (one_chunk ? 4 : 2));          // resident grid, see k_build_edges
+  const int nblocks = std::min(nunits, ncu * (one_chunk ? 2 : 1));          // resident grid, see k_build_edges
   if (!m.edge_state) m.edge_state = new EdgeState();
   EdgeState &st = *(EdgeState *)m.edge_state;
   // header: [0] ticket (u32), [1] maxdeg, [2] overflow, [3] number of heavy centres; status array starts at byte 64
@@ -262,7 +328,7 @@ bool edges_build_f32(Model &m, const ComputeArgs &a) {
   const int nall = std::max(m.nall, 1);
   st.xt.reserve((size_t)nall * sizeof(AtomXT));
   hipLaunchKernelGGL(k_pack_xt, dim3((nall + 255) / 256), dim3(256), 0, a.stream, m.nall, a.x, a.ftype, a.mtype, (AtomXT *)st.xt.p);
-#define EB_LAUNCH(CH) hipLaunchKernelGGL(k_build_edges<CH>, dim3(nblocks), dim3(256), 0, a.stream, inum, m.d_ilist, m.d_nloff, m.d_nlj,       \
+#define EB_LAUNCH(CH) hipLaunchKernelGGL(k_build_edges<CH>, dim3(nblocks), dim3(EB_THREADS), 0, a.stream, inum, m.d_ilist, m.d_nloff, m.d_nlj,       \
                      (const AtomXT *)st.xt.p, a.cutsq, a.nft, nunits, (unsigned int *)hdr, (unsigned long long *)((char *)st.flags.p + 64),   \
                      m.b_eoff.as<int>(), m.b_eii.as<int>(), m.b_ej.as<int>(), m.b_rvec.as<float>(), hdr + 1, hdr + 2,                \
                      m.b_ett.as<unsigned char>(), m.heavy_thresh, hdr + 3, st.heavy.as<int>())

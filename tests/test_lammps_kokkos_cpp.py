@@ -134,6 +134,6 @@ def test_table_list_and_strict_cutoff_on_the_emulation(emu_lib, model_dir):
 @pytest.mark.gpu
 def test_kokkos_pair_style_on_device_pointers(hip_lib, tmp_path, model_dir):
     """Same driver, views in hipMalloc'ed memory, real liballegro_hip.so: the class hands genuine device pointers of x, f, type and
-    of the column-major neighbor table to the `_dev` entry points; float32 model on the fused kernel."""
+    of the column-major neighbor table to the `_dev` entry points (float32 model)."""
     _build("kk_hip")
     _run_and_check(os.path.join(SHIM, "_build", "driver_kk_hip"), tmp_path, model_dir, "float32", 2e-5, 1e-5)

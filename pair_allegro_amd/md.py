@@ -438,6 +438,52 @@ class Simulation:
         return out.cpu().numpy()
 
 
+class HostStagedDist:
+    """Debug transport: the subset of `torch.distributed` that :class:`Simulation` uses, for CUDA tensors over a process group
+    that only moves CPU tensors (gloo).  Every message is staged through host memory.  It exists so that the multi-rank GPU code
+    path (interior / boundary split on HIP streams, ghost exchange between the range evaluations, migration) can be exercised
+    with several processes sharing ONE GPU, where RCCL refuses to form a communicator; production runs pass `torch.distributed`
+    itself (backend nccl = RCCL over xGMI)."""
+
+    class _Done:
+        def __init__(self, works, backs):
+            self.works, self.backs = works, backs
+
+        def wait(self):
+            for w in self.works:
+                w.wait()
+            for t, c in self.backs:
+                t.copy_(c)
+            self.works, self.backs = [], []
+
+    def __init__(self, dist):
+        self.d = dist
+        self.ReduceOp = dist.ReduceOp
+        self.isend, self.irecv = dist.isend, dist.irecv
+
+    def P2POp(self, op, tensor, peer, tag=0):
+        return (op, tensor, peer, tag)
+
+    def batch_isend_irecv(self, ops):
+        real, backs = [], []
+        for op, t, peer, tag in ops:
+            if op is self.d.isend:
+                real.append(self.d.P2POp(self.d.isend, t.detach().cpu().contiguous(), peer, tag=tag))
+            else:
+                c = torch.empty(tuple(t.shape), dtype=t.dtype)
+                backs.append((t, c))
+                real.append(self.d.P2POp(self.d.irecv, c, peer, tag=tag))
+        return [HostStagedDist._Done(self.d.batch_isend_irecv(real), backs)]
+
+    def all_reduce(self, t, op=None):
+        c = t.detach().cpu()
+        self.d.all_reduce(c, op=op if op is not None else self.d.ReduceOp.SUM)
+        t.copy_(c)
+
+    def barrier(self):
+        self.d.barrier()
+
+
 def maxwell_boltzmann(n: int, mass: np.ndarray, temperature: float, seed: int) -> np.ndarray:
     rng = np.random.RandomState(seed)
     sigma = np.sqrt(KB * temperature / (mass * MVV2E))

@@ -126,7 +126,8 @@ int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const i
  * cutoff_matrix_model is a HOST [num_types^2] matrix in model-type index (NULL = r_max).
  * Forces are accumulated into f_dev; eng_vir_dev receives 7 doubles {eng, xx,yy,zz,xy,xz,yz}.
  * Asynchronous on `stream` (a hipStream_t, NULL = default) except for one 4-byte read-back of
- * the edge count (the Kokkos path has the same one, :203-206). */
+ * the edge count (the Kokkos path has the same one, :203-206).  With outputs registered through ahip_output_register the
+ * call additionally keeps host copies of them (pair_nequip_allegro_kokkos.cpp:342-344) and synchronises the stream. */
 int ahip_compute_dev(ahip_model *m, int nlocal, int nghost, const double *x_dev, const int *mtype_dev,
                      const double *cutoff_matrix_model, double *f_dev, double *eatom_dev,
                      double *eng_vir_dev, void *stream);

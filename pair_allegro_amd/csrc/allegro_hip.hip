@@ -313,6 +313,14 @@ static double cutsq_bound(const ahip_model *m, double c) {
   return m->cutoff_strict ? std::nextafter(c2, 0.0) : c2;
 }
 
+static __global__ void k_add_n(long long n, double *dst, const double *src) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) dst[t] += src[t];
+}
+static __global__ void k_copy_centres(int inum, const int *ilist, double *dst, const double *src) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < inum) dst[ilist[t]] = src[ilist[t]];
+}
 static __global__ void k_add7(double *dst, const double *src) { if (threadIdx.x < 7) dst[threadIdx.x] += src[threadIdx.x]; }
 
 // The few centres that do not fit a tile of the wide fused kernel: layer-at-a-time float32 kernels on a compact copy of their
@@ -477,8 +485,8 @@ int ahip_output_get(ahip_model *m, const char *name, double *out, long long capa
     if (!name || !count) throw ArgError("ahip_output_get: NULL name/count");
     auto it = m->custom_out.find(name);
     if (it == m->custom_out.end())
-      throw StateError(std::string("output '") + name + "' is not stored: register it with ahip_output_register before ahip_compute "
-                       "(host-pointer call, nlocal > 0)");
+      throw StateError(std::string("output '") + name + "' is not stored: register it with ahip_output_register before ahip_compute / "
+                       "ahip_compute_dev (nlocal > 0)");
     *count = (long long)it->second.size();
     if (!out) return;
     if (capacity < *count) throw ArgError("ahip_output_get: buffer too small");
@@ -509,8 +517,49 @@ int ahip_compute_dev(ahip_model *m, int nlocal, int nghost, const double *x_dev,
       AHIP_CHECK(hipStreamSynchronize(s));                   // cutsq is a stack vector
       m->h_cutsq_dev = cutsq;
     }
-    ComputeArgs a{nlocal, nghost, x_dev, mtype_dev, m->b_cutsq.as<double>(), T, mtype_dev, f_dev, eatom_dev, eng_vir_dev, s};
-    run_model(m, a);
+    if (m->custom_names.empty()) {
+      ComputeArgs a{nlocal, nghost, x_dev, mtype_dev, m->b_cutsq.as<double>(), T, mtype_dev, f_dev, eatom_dev, eng_vir_dev, s};
+      run_model(m, a);
+    } else {
+      // `compute allegro` on the device path (the reference's Kokkos class keeps output.at(name) too,
+      // pair_nequip_allegro_kokkos.cpp:342-344): evaluate into the library's own zeroed force / energy arrays, add them to the
+      // caller's, and keep host copies of the named entries.  Costs two extra array passes and a read-back, only when a
+      // compute is registered.
+      for (const std::string &nm : m->custom_names)
+        if (nm != "atomic_energy" && nm != "forces" && nm != "virial" && nm != "total_energy")
+          throw ArgError("model output '" + nm + "' not found (this model returns atomic_energy, forces, virial, total_energy)");
+      m->b_f.reserve((size_t)std::max(nall, 1) * 3 * sizeof(double));
+      m->b_eatom.reserve((size_t)std::max(nall, 1) * sizeof(double));
+      AHIP_CHECK(hipMemsetAsync(m->b_f.p, 0, (size_t)nall * 3 * sizeof(double), s));
+      AHIP_CHECK(hipMemsetAsync(m->b_eatom.p, 0, (size_t)nall * sizeof(double), s));
+      ComputeArgs a{nlocal, nghost, x_dev, mtype_dev, m->b_cutsq.as<double>(), T, mtype_dev, m->b_f.as<double>(), m->b_eatom.as<double>(), eng_vir_dev, s};
+      run_model(m, a);
+      const int inum = m->inum;
+      if (nall > 0) hipLaunchKernelGGL(k_add_n, dim3((unsigned)((3LL * nall + 255) / 256)), dim3(256), 0, s, 3LL * nall, f_dev, m->b_f.as<double>());
+      if (eatom_dev && inum > 0) hipLaunchKernelGGL(k_copy_centres, dim3((unsigned)((inum + 255) / 256)), dim3(256), 0, s, inum, m->d_ilist, eatom_dev, m->b_eatom.as<double>());
+      AHIP_CHECK(hipGetLastError());
+      m->h_f.resize((size_t)nall * 3); m->h_eatom.resize(nall); m->h_mtype.resize(nall);
+      std::vector<int> il(inum);
+      double ev[7];
+      AHIP_CHECK(hipMemcpyAsync(m->h_f.data(), m->b_f.p, (size_t)nall * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+      AHIP_CHECK(hipMemcpyAsync(m->h_eatom.data(), m->b_eatom.p, (size_t)nall * sizeof(double), hipMemcpyDeviceToHost, s));
+      AHIP_CHECK(hipMemcpyAsync(m->h_mtype.data(), mtype_dev, (size_t)nall * sizeof(int), hipMemcpyDeviceToHost, s));
+      if (inum > 0) AHIP_CHECK(hipMemcpyAsync(il.data(), m->d_ilist, (size_t)inum * sizeof(int), hipMemcpyDeviceToHost, s));
+      AHIP_CHECK(hipMemcpyAsync(ev, eng_vir_dev, 7 * sizeof(double), hipMemcpyDeviceToHost, s));
+      AHIP_CHECK(hipStreamSynchronize(s));
+      std::vector<double> ae(nall);
+      const HostTensor &shift = m->hm.get("shift");
+      for (int i = 0; i < nall; ++i) ae[i] = shift.data[m->h_mtype[i]];        // ghosts: no centre edges -> shift only
+      for (int ii = 0; ii < inum; ++ii) ae[il[ii]] = m->h_eatom[il[ii]];
+      double tot = 0;
+      for (double v : ae) tot += v;
+      for (const std::string &nm : m->custom_names) {
+        if (nm == "atomic_energy") m->custom_out[nm] = ae;
+        else if (nm == "forces") m->custom_out[nm] = m->h_f;
+        else if (nm == "total_energy") m->custom_out[nm] = {tot};
+        else m->custom_out[nm] = {ev[1], ev[4], ev[5], ev[4], ev[2], ev[6], ev[5], ev[6], ev[3]};
+      }
+    }
     collect_timings(m);
   });
 }
@@ -523,6 +572,7 @@ int ahip_compute_dev_range(ahip_model *m, int centre_begin, int centre_end, int 
     if (!m->have_list) throw StateError("ahip_compute_dev_range called before a neighbor list was installed");
     if (centre_begin < 0 || centre_end < centre_begin || centre_end > m->inum)
       throw ArgError("ahip_compute_dev_range: need 0 <= centre_begin <= centre_end <= inum");
+    if (!m->custom_names.empty()) throw StateError("ahip_compute_dev_range: registered model outputs (compute allegro) need the whole-list call ahip_compute_dev");
     // narrow the installed CSR list to the centre range (offsets are absolute into the neighbour array), evaluate, restore
     const int inum = m->inum;
     const int *il = m->d_ilist, *off = m->d_nloff;

@@ -70,9 +70,6 @@ void PairAllegroHIPKokkos::compute(int eflag_in, int vflag_in)
 {
   ev_init(eflag_in, vflag_in, 0);
   if (vflag_atom) error->all(FLERR, "Pair style Allegro does not support per-atom virial");    // :336-338
-  if (!custom_output_names.empty())
-    error->all(FLERR, "compute allegro is not available with pair_style allegro/kk: the device path keeps no per-call "
-                      "copy of the model outputs; use pair_style allegro");
 
   if (eflag_atom) {    // :97-101
     memoryKK->destroy_kokkos(k_eatom, eatom);

@@ -3,6 +3,7 @@
 // kokkos_shim.h: dual views for x / f / type / tag, a column-major padded neighbor table with special-bond bits set on some
 // entries, atomKK->sync / modified masks.  Same output file as driver.cpp.
 #include "pair_allegro_hip_kokkos.h"
+#include "compute_allegro_hip.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -76,6 +77,12 @@ int main(int argc, char **argv) {
     for (int k = 3; k < argc; k++) args.push_back(argv[k]);
     pair.coeff((int)args.size(), args.data());
     force.pair = &pair;
+    // `compute allegro/atom forces 3 1` and `compute allegro virial 9` next to the /kk pair style (env DRIVER_COMPUTES)
+    const bool with_computes = std::getenv("DRIVER_COMPUTES") != nullptr;
+    char c_id[] = "c", c_all[] = "all", c_v[] = "allegro", c_a[] = "allegro/atom", q_vir[] = "virial", q_f[] = "forces", n9[] = "9", n3[] = "3", n1[] = "1";
+    char *av[] = {c_id, c_all, c_v, q_vir, n9}, *af[] = {c_id, c_all, c_a, q_f, n3, n1};
+    ComputeAllegroHIP<0> *cvir = with_computes ? new ComputeAllegroHIP<0>(&lmp, 5, av) : nullptr;
+    ComputeAllegroHIP<1> *cfor = with_computes ? new ComputeAllegroHIP<1>(&lmp, 6, af) : nullptr;
     pair.init_style();
     if (neighbor.requested != (NeighConst::REQ_FULL | NeighConst::REQ_GHOST) || neighbor.request.kokkos_device != 1 || neighbor.request.kokkos_host != 0) {
       fprintf(stderr, "bad neighbor request\n"); return 4;
@@ -101,6 +108,13 @@ int main(int argc, char **argv) {
     fwrite(fr.data(), sizeof(double), fr.size(), o);
     fwrite(ea.data(), sizeof(double), ea.size(), o);
     fwrite(&pair.eng_vdwl, sizeof(double), 1, o);
+    if (with_computes) {
+      cfor->compute_peratom();                  // forces of the LAST call, ghost rows folded in (newton 1)
+      for (int i = 0; i < nlocal; i++) fwrite(cfor->array_atom[i], sizeof(double), 3, o);
+      cvir->compute_vector();
+      fwrite(cvir->vector, sizeof(double), 9, o);
+      delete cvir; delete cfor;
+    }
     fclose(o);
     printf("restartinfo=%d manybody=%d no_fdotr=%d respa=%d kokkosable=%d\n", pair.restartinfo, pair.manybody_flag, pair.no_virial_fdotr_compute, pair.respa_enable, pair.kokkosable);
   } catch (const LammpsAbort &e) { printf("LAMMPS error->all: %s\n", e.what()); rc = 10; }

@@ -39,7 +39,7 @@ def _run_and_check(drv, tmp_path, model_dir, dtype, atol_f, rtol_e):
     rs = lmp_like.build_rank_system(g["cell"], g["pos"], types, 6.0)
     sysf, outf = str(tmp_path / "sys.bin"), str(tmp_path / "out.bin")
     _write_system(sysf, rs, len(names))
-    r = subprocess.run([drv, sysf, outf, mpath] + names, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    r = subprocess.run([drv, sysf, outf, mpath] + names, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, DRIVER_COMPUTES="1"))
     text = r.stdout.decode()
     assert r.returncode == 0, text
     assert "restartinfo=0 manybody=1 no_fdotr=1 respa=0 kokkosable=1" in text
@@ -48,6 +48,8 @@ def _run_and_check(drv, tmp_path, model_dir, dtype, atol_f, rtol_e):
     f = out[8:8 + 3 * rs.nall].reshape(-1, 3)
     eatom = out[8 + 3 * rs.nall: 8 + 4 * rs.nall]
     eng2 = out[8 + 4 * rs.nall]
+    c_f = out[9 + 4 * rs.nall: 9 + 4 * rs.nall + 3 * rs.nlocal].reshape(-1, 3)     # compute allegro/atom forces 3 1 (device path)
+    c_vir = out[9 + 4 * rs.nall + 3 * rs.nlocal:].reshape(3, 3)                        # compute allegro virial 9
     ref = util.oracle_run(cfg, w, g["cell"], g["pos"], types, names)
     forces = np.zeros_like(ref["forces"])
     np.add.at(forces, rs.tag - 1, f)
@@ -57,6 +59,9 @@ def _run_and_check(drv, tmp_path, model_dir, dtype, atol_f, rtol_e):
     np.testing.assert_allclose(eng2, ref["pe"], rtol=rtol_e)
     np.testing.assert_allclose(vir, ref["virial"], atol=100 * atol_f)         # virial of the first call (the second had vflag = 0)
     np.testing.assert_allclose(eatom[: rs.nlocal], ref["eatom"][rs.tag[: rs.nlocal] - 1], atol=10 * atol_f)
+    np.testing.assert_allclose(c_f, ref["forces"][rs.tag[: rs.nlocal] - 1], atol=atol_f)
+    xx, yy, zz, xy, xz, yz = ref["virial"]
+    np.testing.assert_allclose(c_vir, [[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]], atol=100 * atol_f)
 
 
 def test_kokkos_pair_style_matches_oracle(driver_kk, tmp_path, model_dir):

@@ -220,30 +220,45 @@ __device__ __forceinline__ f32x2 bload_half(__amdgpu_buffer_rsrc_t r, int voff, 
 __device__ __forceinline__ float hsum4(const f32x4 &v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 
 // Per-centre sum of one staged K-tile: env[a][lm][16 t + f] = scale * sum_{slots of a} stage[slot][lm][f].
-// Work item = (centre, 4-feature column); its 8 adjacent lanes take every 8th slot with 16-byte LDS reads (all of a lane's reads
-// are in flight together) and combine with three cross-lane adds -- a fixed order, so the sums are reproducible.
+// Work item = (centre, 4-feature column); its LPI adjacent lanes take every LPI-th slot with 16-byte LDS reads (all of a lane's reads
+// are in flight together) and combine with log2(LPI) cross-lane adds -- a fixed order, so the sums are reproducible.
+// The thread index is recomputed here from the hardware lane counter (and the wave index the caller keeps in an SGPR): a value
+// derived from threadIdx at kernel entry is live across the whole tile and ends up in a scratch slot, whose reload at this point
+// waits (vmcnt(0), loads return in order) for the saved rows the caller has just requested from HBM.
+__device__ __forceinline__ int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 template <int L, int UT, int NW>
-__device__ __forceinline__ void reduce_stage_x(const float *stg, const int *aoff, float *dst, int na, float scale, int t, int tid) {
+__device__ __forceinline__ void reduce_stage_x(const float *stg, const int *aoff, float *dst, int na, float scale, int t, int uwave) {
   using S = ShapeX<L, UT, NW>;
-  constexpr int NC = S::D * 4, PER_ROUND = NW * 64 / 8;
-  const int p = tid & 7;
-  for (int it = tid >> 3; it < ((na * NC + PER_ROUND - 1) / PER_ROUND) * PER_ROUND; it += PER_ROUND) {   // whole waves iterate together
+  constexpr int LPI = 4;                    // lanes per work item: 36 columns x 4 lanes = one round for a tile that holds one centre
+  constexpr int NC = S::D * 4, PER_ROUND = NW * 64 / LPI, NRD = S::SLOTS / LPI;
+  const int tid = uwave * 64 + fresh_lane();
+  const int p = tid & (LPI - 1);
+  for (int it = tid / LPI; it < ((na * NC + PER_ROUND - 1) / PER_ROUND) * PER_ROUND; it += PER_ROUND) {   // whole waves iterate together
     const bool live = it < na * NC;
     const int a = live ? it / NC : 0, c = live ? it - a * NC : 0;
     const int s0 = aoff[a] + p, s1 = live ? aoff[a + 1] : 0;
+    // all reads are issued before the first is used: addresses past the centre's last slot are clamped to slot 0 of the stage
+    // (always mapped) and their values discarded -- a conditional read per slot costs one LDS round trip each
+    f32x4 v[NRD];
+#pragma unroll
+    for (int k = 0; k < NRD; ++k) {
+      const int sl = s0 + LPI * k;
+      v[k] = *(const f32x4 *)(stg + (sl < s1 ? sl : 0) * S::STG_LD + 4 * c);
+    }
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < S::SLOTS / 8; ++k) {
-      const int sl = s0 + 8 * k;
-      if (sl < s1) acc += *(const f32x4 *)(stg + sl * S::STG_LD + 4 * c);
-    }
+    for (int k = 0; k < NRD; ++k)
+      if ((s0 + LPI * k) < s1) acc += v[k];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float v = acc[r];
-      v += __shfl_xor(v, 1, 64);
-      v += __shfl_xor(v, 2, 64);
-      v += __shfl_xor(v, 4, 64);
-      acc[r] = v * scale;
+      float v1 = acc[r];
+#pragma unroll
+      for (int m = 1; m < LPI; m <<= 1) v1 += __shfl_xor(v1, m, 64);
+      acc[r] = v1 * scale;
     }
     if (live && p == 0) *(f32x4 *)(dst + a * S::ENVA + (c >> 2) * S::U + 16 * t + 4 * (c & 3)) = acc;
   }
@@ -291,6 +306,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
   constexpr int NTHREADS = NW * 64, D = S::D, U = S::U, EW = S::EW, MAXA = S::MAXA, STG_LD = S::STG_LD, ENVA = S::ENVA, NP = S::NP;
   __shared__ LdsX<L, UT, NW> lds;
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
+  const int uwave = __builtin_amdgcn_readfirstlane(wave);
   const int v16 = lane * 16;
   __amdgpu_buffer_rsrc_t SB, WB;
   {
@@ -429,7 +445,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
 #pragma unroll
           for (int lm = 0; lm < D; ++lm) *(f32x4 *)(sp + lm * 16) = lm == 0 ? om[t] : om[l_of_lm(lm) * UT + t] * Y[lm];
           __syncthreads();
-          reduce_stage_x<L, UT, NW>(lds.stage[t & 1], aoffp, envk, na, A.cenv, t, tid);
+          reduce_stage_x<L, UT, NW>(lds.stage[t & 1], aoffp, envk, na, A.cenv, t, uwave);
           __builtin_amdgcn_sched_barrier(0);
         }
 #endif
@@ -579,18 +595,22 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
         const float *tp = lds.tp[kk] + 4 * g;
         // the saved input rows V^{kk}[.][t] (w0 rows for the first layer) of half pass (t, h) are requested one half pass
         // ahead: their round trip (L2 miss: 1-2 us) runs under the previous half pass
-        f32x2 vpre[D];
+        // saved input rows of half pass i = 2 t + h live in vpre2[i & 1] and are requested TWO half passes ahead (an HBM round trip
+        // under load is ~2 us, one half pass ~1 us)
+        f32x2 vpre2[2][D];
         f32x4 omall[L * UT];      // omega rows of l >= 1 (all K-tiles) for the step after this one: requested before the last reduction
-        auto request_vin = [&](int t, int h) {
+        auto request_vin = [&](int i) {
+          const int t = i >> 1, h = i & 1;
           if (kk > 0) {
 #pragma unroll
-            for (int lm = 0; lm < D; ++lm) vpre[lm] = bload_half(SB, v16 + 8 * h, (RL + S::O_VIN + lm * UT + t) * ROW * 4);
+            for (int lm = 0; lm < D; ++lm) vpre2[i & 1][lm] = bload_half(SB, v16 + 8 * h, (RL + S::O_VIN + lm * UT + t) * ROW * 4);
           } else {
 #pragma unroll
-            for (int l = 0; l <= L; ++l) vpre[l] = bload_half(SB, v16 + 8 * h, (S::R_W0 + l * UT + t) * ROW * 4);
+            for (int l = 0; l <= L; ++l) vpre2[i & 1][l] = bload_half(SB, v16 + 8 * h, (S::R_W0 + l * UT + t) * ROW * 4);
           }
         };
-        request_vin(0, 0);
+        request_vin(0);
+        request_vin(1);
 #pragma unroll
         for (int t = 0; t < UT; ++t) {
           float *const sp = (t & 1) ? st1 : st0;
@@ -598,7 +618,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
           for (int h = 0; h < 2; ++h) {
             f32x2 vin[D], a[D], b[D], ee[D];
 #pragma unroll
-            for (int lm = 0; lm < D; ++lm) vin[lm] = vpre[lm];
+            for (int lm = 0; lm < D; ++lm) vin[lm] = vpre2[h][lm];
 #pragma unroll
             for (int lm = 0; lm < D; ++lm) ee[lm] = *(const f32x2 *)(en + 16 * t + 2 * h + lm * U);
             f32x2 pwh[NP];          // path weights of this half pass: one batch of LDS reads, one wait
@@ -607,7 +627,10 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
             __builtin_amdgcn_sched_barrier(0);
             // next half pass's rows: requested AFTER this half pass's LDS reads -- a spilled LDS address reloaded between the
             // request and those reads would wait on vmcnt(0), i.e. on the rows just requested (loads return in order)
-            if (2 * t + h + 1 < 2 * UT) request_vin(h == 1 ? t + 1 : t, h ^ 1);
+            // the stage pointer is needed after the tensor-product arithmetic: if it sits in a scratch slot, reload it NOW -- after
+            // the request below a reload waits (vmcnt(0), in-order return) for the rows coming from HBM
+            asm volatile("" ::"v"(sp));
+            if (2 * t + h + 2 < 2 * UT) request_vin(2 * t + h + 2);
             __builtin_amdgcn_sched_barrier(0);
             if (!last) {
               f32x2 gg[D];
@@ -637,7 +660,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
           }
           if (t == UT - 1) load_rows<L * UT>(SB, RL + S::O_OM + UT, omall, v16);
           __syncthreads();
-          reduce_stage_x<L, UT, NW>(lds.stage[t & 1], aoffp, lds.denv, na, A.cenv, t, tid);
+          reduce_stage_x<L, UT, NW>(lds.stage[t & 1], aoffp, lds.denv, na, A.cenv, t, uwave);
           __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();

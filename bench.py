@@ -228,6 +228,11 @@ def main():
                 roof["neighbor_gather"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
                                            "frac": round(gbs / 8000.0, 4), "avg_ms": round(stage_avg["edge_build"], 4),
                                            "algorithmic_bytes": nb}
+                if os.path.exists(tj) and world == 1:         # HBM-side bytes of k_build_edges from the committed --pmc passes
+                    ent = json.load(open(tj)).get(f"config{args.config}:k_build_edges:{natoms}")
+                    if ent:
+                        roof["neighbor_gather"]["traffic"] = ent["traffic_bytes_per_launch"]
+                        roof["neighbor_gather"]["traffic_source"] = ent["source"]
         # ---- CPU baseline + max|dF| on a bounded sample --------------------------------------
         cpu = None
         max_df = None

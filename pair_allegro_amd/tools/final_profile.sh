@@ -15,14 +15,15 @@ cd $root
 python3 - "$out" <<'PY'
 import sys, glob, csv, collections
 out = sys.argv[1]
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    per = collections.defaultdict(float)
-    for f in glob.glob(out + f'/pmc_{c}/**/*counter_collection.csv', recursive=True):
-        for r in csv.DictReader(open(f)):
-            if 'k_fused' in r['Kernel_Name'] and r['Counter_Name'] == c:
-                per[r['Dispatch_Id']] += float(r['Counter_Value'])
-    v = list(per.values())
-    print(c, 'dispatches', len(v), 'avg', sum(v) / max(len(v), 1))
+for kern in ("k_fused", "k_build_edges"):
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        per = collections.defaultdict(float)
+        for f in glob.glob(out + f'/pmc_{c}/**/*counter_collection.csv', recursive=True):
+            for r in csv.DictReader(open(f)):
+                if kern in r['Kernel_Name'] and r['Counter_Name'] == c:
+                    per[r['Dispatch_Id']] += float(r['Counter_Value'])
+        v = list(per.values())
+        print(kern, c, 'dispatches', len(v), 'avg', sum(v) / max(len(v), 1))
 PY
 tail -1 $out/trace.log | cut -c1-300
 python bench.py $bargs > $out/bench_default.json 2> $out/bench_default.err; tail -1 $out/bench_default.json

@@ -142,3 +142,31 @@ def test_kokkos_pair_style_on_device_pointers(hip_lib, tmp_path, model_dir):
     of the column-major neighbor table to the `_dev` entry points (float32 model)."""
     _build("kk_hip")
     _run_and_check(os.path.join(SHIM, "_build", "driver_kk_hip"), tmp_path, model_dir, "float32", 2e-5, 1e-5)
+
+
+def test_table_list_rejects_bad_input(emu_lib, model_dir):
+    """ahip_neigh_update_dev_table / ahip_map_types_dev validate on the device and report through ahip_last_error: an out-of-range neighbour,
+    an out-of-range centre, non-positive strides, an unmapped type."""
+    cfg = model_file.model_S(model_dtype="float64", num_scalar_features=16, num_tensor_features=8, mlp_width=16, readout_width=8)
+    p = os.path.join(model_dir, "kk_bad.nequip.pth")
+    allegro_torch.export_nequip_pth(p, cfg)
+    m = capi.Model(p, 0, emu_lib)
+    il = np.arange(3, dtype=np.int32); nn = np.full(3, 2, dtype=np.int32)
+    tab = np.array([[1, 2], [0, 7], [0, 1]], dtype=np.int32)            # neighbour 7 of a 3-atom system
+    with pytest.raises(capi.AhipError, match="neighbour index out of range"):
+        m.neigh_update_dev_table(3, 3, il.ctypes.data, nn.ctypes.data, tab.ctypes.data, 2, 1)
+    bad_il = np.array([0, 1, 5], dtype=np.int32)
+    tab[1, 1] = 2
+    with pytest.raises(capi.AhipError, match="ilist entry out of range"):
+        m.neigh_update_dev_table(3, 3, bad_il.ctypes.data, nn.ctypes.data, tab.ctypes.data, 2, 1)
+    with pytest.raises(capi.AhipError, match="strides must be positive"):
+        m.neigh_update_dev_table(3, 3, il.ctypes.data, nn.ctypes.data, tab.ctypes.data, 0, 1)
+    m.neigh_update_dev_table(3, 3, il.ctypes.data, nn.ctypes.data, tab.ctypes.data, 2, 1)      # the corrected table installs
+    assert m.nneigh() == 6
+    types = np.array([1, 2, 1], dtype=np.int32); out = np.zeros(3, dtype=np.int32)
+    with pytest.raises(capi.AhipError, match="not mapped"):
+        m.map_types_dev(3, types.ctypes.data, np.array([0, -1], dtype=np.int32), out.ctypes.data)
+    with pytest.raises(capi.AhipError, match="out of range"):
+        m.map_types_dev(3, np.array([1, 3, 1], dtype=np.int32).ctypes.data, np.array([0, 0], dtype=np.int32), out.ctypes.data)
+    m.map_types_dev(3, types.ctypes.data, np.array([0, 0], dtype=np.int32), out.ctypes.data)
+    assert out.tolist() == [0, 0, 0]

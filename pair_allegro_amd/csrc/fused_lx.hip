@@ -400,6 +400,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
     // ---------------- two-body embedding x0(d; type pair) from the spline table ----------------
     f32x4 x[4];
     {
+      ring_prime(WB, wp, v16, ring);        // RING_DROP: not carried through the finish / geometry phases of the tile boundary either
       const float tb_invh = (float)A.tb_nk / rc;
       const float sft = d * tb_invh;
       const int kq = min((int)sft, A.tb_nk - 1);
@@ -452,7 +453,9 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
         __syncthreads();
       }
       PHASEX(PX_ENV);
-      // tensor product, in place per K-tile
+      // tensor product, in place per K-tile.  RING_DROP: the weight-fragment ring is NOT carried through the tensor-product phases (no
+      // linear runs in them): the fragments prefetched by the previous linear's tail are dropped and requested again under the last
+      // half pass, which frees 32 registers where the pressure peaks (one extra L2 round trip per phase, hidden by that half pass)
       f32x4 sc[UT];            // scalar outputs (l3 = 0) of the tensor product: the latent MLP's second input
       {
         const float *en = envk + envoff;
@@ -466,6 +469,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
               f32x2 vin[D], out[D];
 #pragma unroll
               for (int lm = 0; lm < D; ++lm) vin[lm] = acc_get2(V[lm][t], h);
+              if (t == UT - 1 && h == 1) ring_prime(WB, wp, v16, ring);      // see RING_DROP below
               tp_fwd_x<L, false, U>(vin, en + 16 * t + 2 * h, tp + 16 * t + 2 * h, out);
 #pragma unroll
               for (int lm = 0; lm < D; ++lm) acc_put2(V[lm][t], h, out[lm]);
@@ -481,6 +485,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
               f32x2 vin[D], out[1];
 #pragma unroll
               for (int lm = 0; lm < D; ++lm) vin[lm] = acc_get2(V[lm][t], h);
+              if (t == UT - 1 && h == 1) ring_prime(WB, wp, v16, ring);
               tp_fwd_x<L, true, U>(vin, en + 16 * t + 2 * h, tp + 16 * t + 2 * h, out);
               set_half(sc[t], h, out[0]);
               __builtin_amdgcn_sched_barrier(0);
@@ -664,6 +669,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
           __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
+        ring_prime(WB, wp, v16, ring);                                        // RING_DROP: requested again after the tensor-product gradient
       PHASEX(PX_BTP);
       // environment weights backward: d omega[l][u] = sum_m denv[lm][u] Y[lm];  dY[lm] += sum_u denv[lm][u] omega[l][u]
         f32x4 dom[EW];

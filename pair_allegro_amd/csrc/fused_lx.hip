@@ -669,7 +669,6 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
           __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
-        ring_prime(WB, wp, v16, ring);                                        // RING_DROP: requested again after the tensor-product gradient
       PHASEX(PX_BTP);
       // environment weights backward: d omega[l][u] = sum_m denv[lm][u] Y[lm];  dY[lm] += sum_u denv[lm][u] omega[l][u]
         f32x4 dom[EW];
@@ -692,6 +691,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
           }
           __builtin_amdgcn_sched_barrier(0);
         }
+        ring_prime(WB, wp, v16, ring);          // RING_DROP: requested again only now -- the d omega / dY arithmetic above needs the registers
         // next iteration's u / silu'(z2) rows (or the l >= 1 embedding weights for the last step) under this linear
         if (kk > 0) {
           load_rows<4>(SB, S::R_LAYER(kk - 1) + S::O_U, upre, v16);

@@ -235,9 +235,13 @@ __device__ __forceinline__ void reduce_stage_x(const float *stg, const int *aoff
   using S = ShapeX<L, UT, NW>;
   constexpr int LPI = 4;                    // lanes per work item: 36 columns x 4 lanes = one round for a tile that holds one centre
   constexpr int NC = S::D * 4, PER_ROUND = NW * 64 / LPI, NRD = S::SLOTS / LPI;
-  const int tid = uwave * 64 + fresh_lane();
-  const int p = tid & (LPI - 1);
-  for (int it = tid / LPI; it < ((na * NC + PER_ROUND - 1) / PER_ROUND) * PER_ROUND; it += PER_ROUND) {   // whole waves iterate together
+  // lane -> (item, part): part = lane / 16, item = 16 * wave + lane % 16.  The 16 lanes of one 16-byte LDS read phase then hold 16
+  // consecutive 4-feature columns of the same slot: distinct banks.  (Adjacent lanes = the parts of one item hit rows 148 floats
+  // apart with 16-byte reads: SQ_LDS_BANK_CONFLICT was 76 % of the LDS-active cycles.)
+  static_assert(LPI == 4, "four 16-lane groups");
+  const int lane = fresh_lane();
+  const int p = lane >> 4;
+  for (int it = uwave * 16 + (lane & 15); it < ((na * NC + PER_ROUND - 1) / PER_ROUND) * PER_ROUND; it += PER_ROUND) {   // whole waves iterate together
     const bool live = it < na * NC;
     const int a = live ? it / NC : 0, c = live ? it - a * NC : 0;
     const int s0 = aoff[a] + p, s1 = live ? aoff[a + 1] : 0;
@@ -256,8 +260,8 @@ __device__ __forceinline__ void reduce_stage_x(const float *stg, const int *aoff
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float v1 = acc[r];
-#pragma unroll
-      for (int m = 1; m < LPI; m <<= 1) v1 += __shfl_xor(v1, m, 64);
+      v1 += __shfl_xor(v1, 16, 64);
+      v1 += __shfl_xor(v1, 32, 64);
       acc[r] = v1 * scale;
     }
     if (live && p == 0) *(f32x4 *)(dst + a * S::ENVA + (c >> 2) * S::U + 16 * t + 4 * (c & 3)) = acc;

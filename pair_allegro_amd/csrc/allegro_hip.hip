@@ -361,8 +361,10 @@ static void run_model(ahip_model *m, const ComputeArgs &a) {
   m->nheavy = 0;
   m->heavy_thresh = (m->opt_path != "generic" && !fused_model_supported(*m, nullptr) && fusedlx_model_supported(*m, nullptr)) ? 64 : 0;
   if (!edges_build_f32(*m, a)) { m->nheavy = 0; m->heavy_thresh = 0; build_edges<float>(*m, a); }
+#ifdef AHIP_EXPERIMENT_SWITCHES      // never in the product build: a switch that skips the model returns no forces
   static const bool edges_only = std::getenv("AHIP_EDGES_ONLY") != nullptr;     // timing experiments on the edge build alone
   if (edges_only) { m->last_path = "edges_only"; return; }
+#endif
   std::string why;
   bool fused_ok = false;
   if (m->opt_path != "generic") {

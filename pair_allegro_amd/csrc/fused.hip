@@ -63,7 +63,8 @@ struct FusedArgs {
   int T, NL, p;
   float cenv;
   // tiles
-  unsigned int *tile_counter;    // dynamic tile schedule (zeroed by k_pack_finish)
+  unsigned int *tile_counter;
+  int tchunk;                    // tiles per claim of the dynamic schedule (1 for small systems: a workgroup's last claim sets the makespan)    // dynamic tile schedule (zeroed by k_pack_finish)
   const int *tile_a0, *tile_e0, *ntiles;   // tile t = centres [tile_a0[t], tile_a0[t+1]), edges [tile_e0[t], tile_e0[t+1])
   // weights (offsets in floats into wbase)
   const float *wbase;
@@ -304,7 +305,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
   // Dynamic tile schedule: workgroups claim chunks of TCHUNK consecutive tiles from a global counter (workgroup
   // speeds differ by +-12 % across the chip, a static round-robin leaves the slowest one 13 % behind the average).
   // The next chunk is claimed while the first tile of the current one runs.
-  if (tid == 0) lds.chunk[0] = (int)atomicAdd(A.tile_counter, (unsigned)TCHUNK);
+  if (tid == 0) lds.chunk[0] = (int)atomicAdd(A.tile_counter, (unsigned)A.tchunk);
   __syncthreads();
   int par = 0, cpar = 0, ck = 0;
   int cbase = __builtin_amdgcn_readfirstlane(lds.chunk[0]);
@@ -313,7 +314,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     const int tile = cbase + ck;
     if (tile >= ntiles) break;
     int claimed = 0;
-    if (ck == 0 && tid == 0) claimed = (int)atomicAdd(A.tile_counter, (unsigned)TCHUNK);
+    if (ck == 0 && tid == 0) claimed = (int)atomicAdd(A.tile_counter, (unsigned)A.tchunk);
     // Everything a tile reads from the lists is ONE level of loads behind the (scalar) tile bounds: the edge
     // build packs the type pair per edge and k_tile_info the centre index/type, so no dependent chain
     // (edge -> centre -> type) is exposed here.
@@ -758,7 +759,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       }
     }
     PHASE(PH_FIN);
-    if (++ck == TCHUNK) { ck = 0; cpar ^= 1; cbase = __builtin_amdgcn_readfirstlane(lds.chunk[cpar]); }
+    if (++ck == A.tchunk) { ck = 0; cpar ^= 1; cbase = __builtin_amdgcn_readfirstlane(lds.chunk[cpar]); }
   }
   __syncthreads();
   if (tid == 0) {
@@ -1013,6 +1014,9 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
   A.e_tt = m.b_ett.as<unsigned char>(); A.centre = st.centre.as<int2>(); A.rvec = m.b_rvec.as<float>(); A.rcut = m.rcut_model_dev;
   A.tile_a0 = st.tile_a0.as<int>(); A.tile_e0 = st.tile_e0.as<int>(); A.ntiles = st.ntiles.as<int>();
   A.tile_counter = (unsigned int *)(st.ntiles.as<int>() + 1);
+  // claims of TCHUNK tiles amortise the counter's round trip; with few tiles per workgroup the last claim decides the makespan
+  // (10 648 Si atoms: 4 659 tiles on 512 workgroups = 12 instead of 10 tile times with claims of 4)
+  A.tchunk = (m.nedges / tile_slots > (long long)grid * 256) ? TCHUNK : 1;
   A.f = a.f; A.eatom = a.eatom; A.partial = st.partial.as<double>();
   {
     StageTimer tm(m, "model_fused", s);

@@ -53,6 +53,7 @@ struct FusedLxArgs {
   float cenv;
   // tiles
   unsigned int *tile_counter;
+  int tchunk;                    // tiles per claim of the dynamic schedule (1 for small systems: a workgroup's last claim sets the makespan)
   const int *tile_a0, *tile_e0, *ntiles;
   // weights (offsets in floats into wbase)
   const float *wbase;
@@ -342,7 +343,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
 
   const int s = wave * 16 + j;                 // this lane's edge slot
   const int ca = tid >> 4;                     // centre slot served by this thread in the per-centre output step
-  if (tid == 0) lds.chunk[0] = (int)atomicAdd(A.tile_counter, (unsigned)TCHUNK);
+  if (tid == 0) lds.chunk[0] = (int)atomicAdd(A.tile_counter, (unsigned)A.tchunk);
   __syncthreads();
   int par = 0, cpar = 0, ck = 0;
   int cbase = __builtin_amdgcn_readfirstlane(lds.chunk[0]);
@@ -351,7 +352,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
     const int tile = cbase + ck;
     if (tile >= ntiles) break;
     int claimed = 0;
-    if (ck == 0 && tid == 0) claimed = (int)atomicAdd(A.tile_counter, (unsigned)TCHUNK);
+    if (ck == 0 && tid == 0) claimed = (int)atomicAdd(A.tile_counter, (unsigned)A.tchunk);
     const int a0 = A.tile_a0[tile], a1 = A.tile_a0[tile + 1], e0 = A.tile_e0[tile], e1 = A.tile_e0[tile + 1];
     const int na = a1 - a0;
     if (e1 - e0 > S::SLOTS) {
@@ -359,7 +360,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
       // evaluated by the layer-at-a-time kernels afterwards (heavy_generic, allegro_hip.hip)
       if (ck == 0 && tid == 0) lds.chunk[cpar ^ 1] = claimed;
       __syncthreads();
-      if (++ck == TCHUNK) { ck = 0; cpar ^= 1; cbase = __builtin_amdgcn_readfirstlane(lds.chunk[cpar]); }
+      if (++ck == A.tchunk) { ck = 0; cpar ^= 1; cbase = __builtin_amdgcn_readfirstlane(lds.chunk[cpar]); }
       continue;
     }
     par ^= 1;
@@ -800,7 +801,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
     }
     // no trailing barrier: the next tile's first staging write sits behind the barrier after its embedding linear
     PHASEX(PX_FIN);
-    if (++ck == TCHUNK) { ck = 0; cpar ^= 1; cbase = __builtin_amdgcn_readfirstlane(lds.chunk[cpar]); }
+    if (++ck == A.tchunk) { ck = 0; cpar ^= 1; cbase = __builtin_amdgcn_readfirstlane(lds.chunk[cpar]); }
   }
   __syncthreads();
   if (tid == 0) {
@@ -981,6 +982,9 @@ bool fusedlx_run(Model &m, const ComputeArgs &a, std::string *why) {
   A.e_tt = m.b_ett.as<unsigned char>(); A.centre = st.centre.as<int2>(); A.rvec = m.b_rvec.as<float>(); A.rcut = m.rcut_model_dev;
   A.tile_a0 = st.tile_a0.as<int>(); A.tile_e0 = st.tile_e0.as<int>(); A.ntiles = st.ntiles.as<int>();
   A.tile_counter = (unsigned int *)(st.ntiles.as<int>() + 1);
+  // claims of TCHUNK tiles amortise the counter's round trip; with few tiles per workgroup the last claim decides the makespan
+  // (10 648 Si atoms: 4 659 tiles on 512 workgroups = 12 instead of 10 tile times with claims of 4)
+  A.tchunk = (m.nedges / 64 > (long long)grid * 256) ? TCHUNK : 1;
   A.f = a.f; A.eatom = a.eatom; A.partial = st.partial.as<double>();
   {
     StageTimer tm(m, "model_fused", s);

@@ -273,4 +273,4 @@ def test_device_call_with_a_changing_cutoff_matrix(hip_lib, model_dir):
         np.testing.assert_allclose(got[1], want[1], rtol=1e-9, atol=1e-9)
     assert seq[3][2] > fw[2]                                           # more edges pass the filter ...
     np.testing.assert_allclose(seq[3][0], fw[0], atol=1e-6)           # ... and contribute nothing beyond the model cutoff
-    np.testing.assert_allclose(seq[3][1][0], fw[1][0], rtol=1e-9)
+    np.testing.assert_allclose(seq[3][1][0], fw[1][0], rtol=1e-7)     # float32 sums: the extra (zero-valued) slots shift the summation order

@@ -191,6 +191,12 @@ int ahip_debug_fused_edges(ahip_model *m, float *out, long long nedges);
 int ahip_build_neighbors_dev(ahip_model *m, int nlocal, int nall, const double *x_dev,
                              const double *lo, const double *hi, double rc_list, void *stream);
 
+/* Re-neighboring criterion of a stand-alone driver (LAMMPS' `neigh_modify check yes` test, Neighbor::check_distance, evaluated
+ * one step ahead): flag_dev[0] = 1 iff max_i |x_i - xhold_i| + 2 dt max_i |v_i| > half_skin over the n local atoms.  Two launches on
+ * `stream`, no host synchronisation (the caller all-reduces the flag and reads it a step later). */
+int ahip_reneighbor_flag_dev(ahip_model *m, int n, const double *x_dev, const double *xhold_dev, const double *v_dev, double dt,
+                             double half_skin, int *flag_dev, void *stream);
+
 /* v += dtf*f/m ; x += dt*v  style velocity-Verlet half steps on device arrays (NVE).
  *   mode 0: v += 0.5*dt*f*ftm2v/mass[type]; x += dt*v      (initial_integrate)
  *   mode 1: v += 0.5*dt*f*ftm2v/mass[type]                  (final_integrate)  */

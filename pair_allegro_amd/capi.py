@@ -22,7 +22,7 @@ SYMBOLS = [
     "ahip_last_error", "ahip_device_count", "ahip_model_load", "ahip_model_free", "ahip_model_meta",
     "ahip_set_option", "ahip_neigh_update", "ahip_neigh_update_csr", "ahip_neigh_update_dev",
     "ahip_compute", "ahip_compute_dev", "ahip_output_register", "ahip_output_get", "ahip_get_edges", "ahip_debug_dump_edges", "ahip_get_timings",
-    "ahip_compute_dev_range", "ahip_last_list_size", "ahip_neigh_update_dev_table", "ahip_map_types_dev",
+    "ahip_compute_dev_range", "ahip_last_list_size", "ahip_neigh_update_dev_table", "ahip_map_types_dev", "ahip_reneighbor_flag_dev",
     "ahip_last_path", "ahip_last_max_degree", "ahip_debug_fused_linear", "ahip_debug_fused_edges", "ahip_build_neighbors_dev", "ahip_nve_dev",
 ]
 
@@ -77,6 +77,7 @@ class Library:
         L.ahip_last_list_size.argtypes = [C.c_void_p]
         L.ahip_neigh_update_dev_table.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong,
                                                   C.c_int, C.c_void_p]
+        L.ahip_reneighbor_flag_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
         L.ahip_map_types_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
         L.ahip_last_list_size.restype = C.c_longlong
         L.ahip_get_edges.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
@@ -183,6 +184,9 @@ class Model:
     def map_types_dev(self, n: int, type_ptr: int, type_mapper: np.ndarray, mtype_ptr: int, stream: int = 0) -> None:
         tm = np.ascontiguousarray(type_mapper, dtype=np.int32)
         self.L.check(self.L.lib.ahip_map_types_dev(self.h, n, type_ptr, len(tm), _p(tm, C.c_int), mtype_ptr, stream))
+
+    def reneighbor_flag_dev(self, n: int, x_ptr: int, xhold_ptr: int, v_ptr: int, dt: float, half_skin: float, flag_ptr: int, stream: int = 0) -> None:
+        self.L.check(self.L.lib.ahip_reneighbor_flag_dev(self.h, n, x_ptr, xhold_ptr, v_ptr, dt, half_skin, flag_ptr, stream or None))
 
     def build_neighbors_dev(self, nlocal: int, nall: int, x_ptr: int, lo, hi, rc_list: float, stream: int = 0) -> None:
         lo = np.ascontiguousarray(lo, dtype=np.float64)

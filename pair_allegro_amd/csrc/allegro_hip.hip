@@ -135,7 +135,7 @@ void ahip_model_free(ahip_model *m) {
   free_weights(m->wd);
   if (m->cg_dev) (void)hipFree(m->cg_dev);
   if (m->rcut_model_dev) (void)hipFree(m->rcut_model_dev);
-  for (DevBuf *b : {&m->b_ilist, &m->b_nloff, &m->b_nlj, &m->b_x, &m->b_ftype, &m->b_mtype, &m->b_f, &m->b_eatom,
+  for (DevBuf *b : {&m->b_flagwork, &m->b_ilist, &m->b_nloff, &m->b_nlj, &m->b_x, &m->b_ftype, &m->b_mtype, &m->b_f, &m->b_eatom,
                     &m->b_engvir, &m->b_cutsq, &m->b_cnt, &m->b_eoff, &m->b_eii, &m->b_ej, &m->b_rvec, &m->b_ett, &m->b_partial,
                     &m->b_ws, &m->b_misc, &m->hv_eoff, &m->hv_eii, &m->hv_ej, &m->hv_rvec, &m->hv_ilist, &m->hv_engvir})
     b->release();
@@ -687,6 +687,17 @@ int ahip_map_types_dev(ahip_model *m, int n, const int *type_dev, int ntypes, co
     if (n < 0 || ntypes < 1 || !type_mapper || (n > 0 && (!type_dev || !mtype_dev))) throw ArgError("ahip_map_types_dev: bad argument");
     AHIP_CHECK(hipSetDevice(m->device));
     map_types(*m, n, type_dev, ntypes, type_mapper, mtype_dev, (hipStream_t)stream);
+  });
+}
+
+int ahip_reneighbor_flag_dev(ahip_model *m, int n, const double *x_dev, const double *xhold_dev, const double *v_dev, double dt,
+                             double half_skin, int *flag_dev, void *stream) {
+  return guarded([&] {
+    require_model(m);
+    if (n < 0 || !flag_dev || (n > 0 && (!x_dev || !xhold_dev || !v_dev))) throw ArgError("ahip_reneighbor_flag_dev: bad argument");
+    AHIP_CHECK(hipSetDevice(m->device));
+    m->b_flagwork.reserve(64);
+    AHIP_CHECK(prim_reneighbor_flag(x_dev, xhold_dev, v_dev, n, dt, half_skin, m->b_flagwork.as<unsigned int>(), flag_dev, (hipStream_t)stream));
   });
 }
 

@@ -109,7 +109,7 @@ struct Model {
   std::vector<int> h_flat_j, h_off32, h_ilist;
 
   // per-call host-path staging
-  DevBuf b_x, b_ftype, b_mtype, b_f, b_eatom, b_engvir, b_cutsq;
+  DevBuf b_x, b_ftype, b_mtype, b_f, b_eatom, b_engvir, b_cutsq, b_flagwork;
   std::vector<int> h_ftype, h_mtype;
   std::vector<double> h_f, h_eatom, h_cutsq_dev;      // h_cutsq_dev: what b_cutsq currently holds (device path)
 

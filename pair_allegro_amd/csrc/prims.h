@@ -20,6 +20,10 @@ struct PrimScratch {
 hipError_t prim_exclusive_scan_i32(PrimScratch &ps, const int *in, int *out, int n, hipStream_t s);
 // out[c] = sum_r in[r*ncol + c], r < nrow  (deterministic two-stage tree), ncol <= 8.
 hipError_t prim_sum_columns_f64(PrimScratch &ps, const double *in, long long nrow, int ncol, double *out, hipStream_t s);
+// Re-neighboring criterion of the stand-alone MD driver: flag[0] = (max_i |x_i - xhold_i| + 2 dt max_i |v_i| > half_skin) ? 1 : 0
+// (f64 positions / velocities [n][3]); work[2] is an unsigned scratch pair owned by the caller (the two maxima as float bits).
+hipError_t prim_reneighbor_flag(const double *x, const double *xhold, const double *v, int n, double dt, double half_skin,
+                                unsigned int *work, int *flag, hipStream_t s);
 // max over in[0..n) -> out[0]
 hipError_t prim_max_i32(const int *in, int n, int *out, hipStream_t s);
 }  // namespace ahip

@@ -169,4 +169,35 @@ hipError_t prim_max_i32(const int *in, int n, int *out, hipStream_t s) {
   return hipGetLastError();
 }
 
+__global__ void __launch_bounds__(256) k_disp_max(const double *x, const double *xh, const double *v, int n, unsigned int *work) {
+  float md = 0.f, mv = 0.f;                  // squared lengths; non-negative floats order like their bit patterns
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const double dx = x[3 * i] - xh[3 * i], dy = x[3 * i + 1] - xh[3 * i + 1], dz = x[3 * i + 2] - xh[3 * i + 2];
+    const double vx = v[3 * i], vy = v[3 * i + 1], vz = v[3 * i + 2];
+    md = fmaxf(md, (float)(dx * dx + dy * dy + dz * dz) * 1.000001f);      // rounded up: the criterion must not miss
+    mv = fmaxf(mv, (float)(vx * vx + vy * vy + vz * vz) * 1.000001f);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { md = fmaxf(md, __shfl_down(md, off, 64)); mv = fmaxf(mv, __shfl_down(mv, off, 64)); }
+  if ((threadIdx.x & 63) == 0) { atomicMax(&work[0], __float_as_uint(md)); atomicMax(&work[1], __float_as_uint(mv)); }
+}
+__global__ void k_disp_flag(const unsigned int *work, double dt, double half_skin, int *flag) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const double reach = sqrt((double)__uint_as_float(work[0])) + 2.0 * dt * sqrt((double)__uint_as_float(work[1]));
+    flag[0] = reach > half_skin ? 1 : 0;
+  }
+}
+hipError_t prim_reneighbor_flag(const double *x, const double *xhold, const double *v, int n, double dt, double half_skin,
+                                unsigned int *work, int *flag, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(work, 0, 2 * sizeof(unsigned int), s);
+  if (e != hipSuccess) return e;
+  if (n > 0) {
+    int nb = (n + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_disp_max, dim3(nb), dim3(256), 0, s, x, xhold, v, n, work);
+  }
+  hipLaunchKernelGGL(k_disp_flag, dim3(1), dim3(64), 0, s, work, dt, half_skin, flag);
+  return hipGetLastError();
+}
+
 }  // namespace ahip

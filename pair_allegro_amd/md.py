@@ -82,6 +82,10 @@ class HipBackend:
     def nve(self, mode: int, n: int, x, v, f, mtype, dt: float) -> None:
         self.model.nve_dev(mode, n, x.data_ptr(), v.data_ptr(), f.data_ptr(), mtype.data_ptr(), self.mass, dt, FTM2V)
 
+    def reneighbor_flag(self, n: int, x, x_hold, v, dt: float, half_skin: float, flag) -> None:
+        """flag[0] = max displacement since the last build + 2 dt max|v| > half_skin (ahip_reneighbor_flag_dev)."""
+        self.model.reneighbor_flag_dev(n, x.data_ptr(), x_hold.data_ptr() if n else 0, v.data_ptr(), dt, half_skin, flag.data_ptr())
+
 
 @dataclass
 class _Swap:
@@ -330,14 +334,20 @@ class Simulation:
         """max displacement since the last build > skin/2 (any rank)?  Evaluated on the device, all-reduced there, copied to
         pinned host memory asynchronously and READ ONE STEP LATER, so no step waits on a device->host round trip; the
         criterion therefore includes the motion of the step in between (2 dt max|v|)."""
-        if self.nlocal:
-            d = self.x[: self.nlocal] - self.x_hold
-            v = self.v[: self.nlocal]
-            # displacement now + twice the fastest atom's next step (the flag is acted on one step late)
-            reach = (d * d).sum(dim=1).max().sqrt() + 2.0 * self.dt * (v * v).sum(dim=1).max().sqrt()
+        if hasattr(self.backend, "reneighbor_flag"):
+            # one library call (two launches) instead of a dozen elementwise / reduction kernels per step
+            flag = self._flag_dev if getattr(self, "_flag_dev", None) is not None else torch.zeros(1, dtype=torch.int32, device=self.dev)
+            self._flag_dev = flag
+            self.backend.reneighbor_flag(self.nlocal, self.x, self.x_hold, self.v, self.dt, 0.5 * self.skin, flag)
         else:
-            reach = torch.zeros((), dtype=torch.float64, device=self.dev)
-        flag = (reach > 0.5 * self.skin).to(torch.int32).reshape(1)
+            if self.nlocal:
+                d = self.x[: self.nlocal] - self.x_hold
+                v = self.v[: self.nlocal]
+                # displacement now + twice the fastest atom's next step (the flag is acted on one step late)
+                reach = (d * d).sum(dim=1).max().sqrt() + 2.0 * self.dt * (v * v).sum(dim=1).max().sqrt()
+            else:
+                reach = torch.zeros((), dtype=torch.float64, device=self.dev)
+            flag = (reach > 0.5 * self.skin).to(torch.int32).reshape(1)
         if self.nranks > 1:
             self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
         if self.dev.type == "cuda":

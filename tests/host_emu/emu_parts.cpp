@@ -2,6 +2,9 @@
 // host-emulation build (see hip/hip_runtime.h).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
+
 #include "engine.h"
 #include "prims.h"
 
@@ -26,6 +29,17 @@ hipError_t prim_max_i32(const int *in, int n, int *out, hipStream_t) {
   int m = 0;
   for (int i = 0; i < n; ++i) m = std::max(m, in[i]);
   *out = m;
+  return hipSuccess;
+}
+hipError_t prim_reneighbor_flag(const double *x, const double *xh, const double *v, int n, double dt, double half_skin,
+                                unsigned int *, int *flag, hipStream_t) {
+  double md = 0, mv = 0;
+  for (int i = 0; i < n; ++i) {
+    double d = 0, w = 0;
+    for (int k = 0; k < 3; ++k) { const double a = x[3 * i + k] - xh[3 * i + k]; d += a * a; w += v[3 * i + k] * v[3 * i + k]; }
+    md = std::max(md, d); mv = std::max(mv, w);
+  }
+  flag[0] = std::sqrt(md) + 2.0 * dt * std::sqrt(mv) > half_skin ? 1 : 0;
   return hipSuccess;
 }
 bool fused_model_supported(const Model &, std::string *why) { if (why) *why = "host emulation has no MFMA"; return false; }

@@ -162,6 +162,7 @@ class Simulation:
         self.swaps: List[_Swap] = []
         self.nrebuild = 0
         self.x_hold = None
+        self._ghost_src = self._ghost_shift = None
         self._flag_posted = False
         self.rebuild()
 
@@ -278,6 +279,24 @@ class Simulation:
             x = torch.cat([x] + new_x); mt = torch.cat([mt] + new_mt)
         self.x, self.mtype = x.contiguous(), mt.contiguous()
         self.nall = self.x.shape[0]
+        # One rank: every ghost is a periodic image of a LOCAL atom.  Resolving the per-dimension chains (a ghost of a ghost ...) once
+        # per re-neighboring turns the six swaps of the per-step exchanges into one gather (positions) and one index_add (forces).
+        self._ghost_src = self._ghost_shift = None
+        if self.nranks == 1 and self.nall > self.nlocal:
+            nl = self.nlocal
+            src = torch.empty(self.nall - nl, dtype=torch.long, device=self.dev)
+            shv = torch.zeros((self.nall - nl, 3), dtype=torch.float64, device=self.dev)
+            for sw in self.swaps:                                  # in creation order: sources are locals or earlier ghosts
+                idx = sw.send_idx
+                isg = idx >= nl
+                g = (idx - nl).clamp(min=0)
+                s_fin = torch.where(isg, src[g], idx)
+                sh = torch.where(isg.unsqueeze(1), shv[g], torch.zeros((), dtype=torch.float64, device=self.dev))
+                sh = sh.clone(); sh[:, sw.dim] += sw.shift
+                a = sw.first_recv - nl
+                src[a: a + sw.nrecv] = s_fin
+                shv[a: a + sw.nrecv] = sh
+            self._ghost_src, self._ghost_shift = src, shv
 
     def _order_interior_first(self) -> None:
         """Local atoms farther than r_max+skin from every brick face come first: every list neighbour of such an atom is a
@@ -308,6 +327,9 @@ class Simulation:
 
     # ---- per-step communication -------------------------------------------------------------------
     def forward_comm(self) -> None:
+        if self._ghost_src is not None:                            # one rank: all ghosts are images of local atoms
+            self.x[self.nlocal:] = self.x[self._ghost_src] + self._ghost_shift
+            return
         for k in range(0, len(self.swaps), 2):
             pair = self.swaps[k: k + 2]
             bufs = []
@@ -320,6 +342,9 @@ class Simulation:
                 self.x[sw.first_recv: sw.first_recv + sw.nrecv] = rx
 
     def reverse_comm(self) -> None:
+        if self._ghost_src is not None:
+            self.f[: self.nlocal].index_add_(0, self._ghost_src, self.f[self.nlocal:])      # sources are local rows: disjoint from the ghost rows read
+            return
         for k in range(len(self.swaps) - 2, -1, -2):
             pair = self.swaps[k: k + 2]
             # both directions of a dimension read ghost rows received in that dimension and add into rows known before it

@@ -102,6 +102,14 @@ def main():
     # BASELINE config 1: 64-atom Si, model S
     cell, pos, _ = lmp_like.diamond_si(2)
     run_case("si64", cell, pos, ["Si"] * 64, ["Si"], 5.0, dict(l_max=1, num_layers=2, num_tensor_features=32), "Si64_r5")
+    # BASELINE config 3 / config 5 samples (generators of pair_allegro_amd/lmp_like.py, seeded): 128-atom Li3PO4 with model S,
+    # 192-atom water with model L (l_max 2, 64 tensor features, 3 layers)
+    cell, pos, lt = lmp_like.li3po4(reps=(1, 2, 2))
+    sym = [lmp_like.LI3PO4_LAMMPS_NAMES[t - 1] for t in lt]
+    run_case("li3po4", cell, pos, sym, ["Li", "P", "O"], 5.0, dict(l_max=1, num_layers=2, num_tensor_features=32), "Li3PO4_128_r5")
+    cell, pos, wt = lmp_like.water(m=4)
+    sym = [["O", "H"][t - 1] for t in wt]
+    run_case("water", cell, pos, sym, ["O", "H"], 5.0, dict(l_max=2, num_layers=3, num_tensor_features=64), "water_192_r5")
 
 
 if __name__ == "__main__":

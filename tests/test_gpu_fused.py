@@ -25,8 +25,10 @@ def test_mfma_linear_primitive(hip_lib, K, N, arith, monkeypatch):
     np.testing.assert_allclose(out, ref, atol=2e-5 * np.abs(ref).max(), rtol=1e-5)
 
 
-def test_fused_golden_si64(hip_lib, model_dir):
-    res, g = pc.check_golden(hip_lib, model_dir, "Si64_r5", "float32", options={"path": "fused"})
+@pytest.mark.parametrize("tag", ["Si64_r5", "Li3PO4_128_r5"])
+def test_fused_golden_si64(hip_lib, model_dir, tag):
+    """Committed float64 goldens of the model-S workloads (BASELINE config 1's 64-atom Si box, a 128-atom sample of config 3's Li3PO4)."""
+    res, g = pc.check_golden(hip_lib, model_dir, tag, "float32", options={"path": "fused"})
     assert res["info"]["path"] == "fused_f32"
     pc.check_edges_vs_brute_force(res, g)
 

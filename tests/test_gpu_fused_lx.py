@@ -12,10 +12,11 @@ from pair_allegro_amd import lmp_like, model_file
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("tag", ["Cu-cubic_r5", "Cu2AgO4_r5", "aspirin_r5", "aspirin_r15", "CuPd-cubic-big_r5"])
+@pytest.mark.parametrize("tag", ["Cu-cubic_r5", "Cu2AgO4_r5", "aspirin_r5", "aspirin_r15", "CuPd-cubic-big_r5", "water_192_r5"])
 def test_golden_yaml_shape_on_the_fused_kernel(hip_lib, model_dir, tag):
-    """The reference's four test geometries with its YAML's model shape (l_max 2, 32 tensor features, 3 layers): the default
-    path is the fused kernel; forces, per-atom energies, PE and virial against the committed float64 goldens."""
+    """The reference's four test geometries with its YAML's model shape (l_max 2, 32 tensor features, 3 layers) and the 192-atom
+    water sample of BASELINE config 5 with model L (64 tensor features): the default path is the fused kernel; forces, per-atom
+    energies, PE and virial against the committed float64 goldens."""
     res, g = pc.check_golden(hip_lib, model_dir, tag, "float32")
     assert res["info"]["path"] == "fused_f32"
     pc.check_edges_vs_brute_force(res, g)

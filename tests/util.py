@@ -10,7 +10,8 @@ from pair_allegro_amd import lmp_like, model_file
 from pair_allegro_amd.pair import PairAllegro, atom_from_rank_system, list_from_rank_system
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-GOLDEN_TAGS = ["Si64_r5", "Cu-cubic_r5", "Cu-cubic_r15", "Cu2AgO4_r5", "aspirin_r5", "aspirin_r15", "CuPd-cubic-big_r5"]
+GOLDEN_TAGS = ["Si64_r5", "Cu-cubic_r5", "Cu-cubic_r15", "Cu2AgO4_r5", "aspirin_r5", "aspirin_r15", "CuPd-cubic-big_r5",
+               "Li3PO4_128_r5", "water_192_r5"]        # the last two: samples of the BASELINE config 3 / 5 workloads (model S / model L)
 
 _model_cache = {}
 

@@ -202,6 +202,7 @@ void neigh_from_table(Model &m, int inum, int nall, const int *ilist_dev, const 
   AHIP_CHECK(hipStreamSynchronize(s));
   if (hb[1] == 1) throw ArgError("neighbor list: ilist entry out of range");
   if (hb[1] == 2) throw ArgError("neighbor list: negative numneigh");
+  if (tot < 0) throw ArgError("neighbor list: more than 2^31 - 1 entries (row offsets are 32-bit, like the reference's)");
   st.nlj.reserve((size_t)std::max(tot, 1) * sizeof(int));
   if (inum > 0)
     hipLaunchKernelGGL(k_table_rows, grid(inum), dim3(B), 0, s, inum, nall, st.ilist.as<int>(), st.cnt.as<int>(), st.off.as<int>(), table_dev, stride_atom,

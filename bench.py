@@ -220,6 +220,11 @@ def main():
                     "flops_per_edge": flops_per_edge, "executed_flops_per_edge": executed_flops_per_edge,
                     "frac_executed": round(ach / 157.3 * executed_flops_per_edge / flops_per_edge, 4),
                     "two_body": "table" if tb_tab else "mlp"}
+            if traffic:
+                # north-star wording: ">= 40 % of the HBM roofline on the neighbor-gather + tensor-product kernels": the model kernel's
+                # measured HBM bytes (committed --pmc passes) over its HIP-event time of this run, next to the MFMA figure above
+                hb = traffic / (stage_avg[dom] * 1e-3) / 1e9
+                roof["hbm_measured"] = {"achieved": round(hb, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(hb / 8000.0, 4)}
             if "edge_build" in stage_avg:
                 # the neighbor gather (HBM-bound): algorithmic bytes per list entry 4 (j) + 24 (x_j) + 4 (type_j), per edge 20
                 # (e_ii, e_j, rvec) + 1 (packed types) -- DESIGN.md 4.1

@@ -128,6 +128,7 @@ void ahip_model_free(ahip_model *m) {
   (void)hipDeviceSynchronize();
   fused_free(*m);
   fusedlx_free(*m);
+  fusedlx2_free(*m);
   neigh_free(*m);
   edges_free(*m);
   m->prim.release();

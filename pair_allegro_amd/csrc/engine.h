@@ -144,6 +144,7 @@ struct Model {
   // fused path private state (fused.hip: model S shape; fused_lx.hip: l_max = 2 shapes)
   void *fused_state = nullptr;
   void *fusedlx_state = nullptr;
+  void *fusedlx2_state = nullptr;            // wave-pair version of the 64-feature shape (fused_lx2.hip)
 
   // neighbor builder state
   void *nb_state = nullptr;
@@ -193,6 +194,9 @@ void fused_free(Model &m);
 bool fusedlx_model_supported(const Model &m, std::string *why);
 bool fusedlx_run(Model &m, const ComputeArgs &a, std::string *why);
 void fusedlx_free(Model &m);
+// wave-pair kernel for l_max = 2, 64 tensor features (fused_lx2.hip): two waves per SIMD, each wave half of the channels
+bool fusedlx2_run(Model &m, const ComputeArgs &a, std::string *why);
+void fusedlx2_free(Model &m);
 
 // ---- single-pass float32 edge build (edges.hip; the host-emulation build links a stub returning false) ----
 // Fills m.nedges, m.last_max_deg, b_eoff/b_eii/b_ej/b_rvec exactly like build_edges<float>; false = a list

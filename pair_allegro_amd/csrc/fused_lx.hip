@@ -27,46 +27,11 @@
 #ifndef AHIP_ROW_AUX
 #define AHIP_ROW_AUX 2          // saved rows: non-temporal (fused_common.h)
 #endif
-#include "cg_tables.h"
 #include "engine.h"
-#include "fused_common.h"
+#include "fused_lx_common.h"
 #include "prims.h"
 
 namespace ahip {
-
-static constexpr int LX_MAXNL = 3;
-
-template <int L> struct CgX;
-template <> struct CgX<1> { static constexpr const AhipCgEntry *tab = ahip_cg_l1; static constexpr int N = AHIP_CG_L1_N, NS = AHIP_CG_L1_NSCALAR, NP = AHIP_CG_L1_NPATHS, NPS = AHIP_CG_L1_NPATHS_SCALAR; };
-template <> struct CgX<2> { static constexpr const AhipCgEntry *tab = ahip_cg_l2; static constexpr int N = AHIP_CG_L2_N, NS = AHIP_CG_L2_NSCALAR, NP = AHIP_CG_L2_NPATHS, NPS = AHIP_CG_L2_NPATHS_SCALAR; };
-
-__host__ __device__ constexpr int l_of_lm(int lm) { return lm == 0 ? 0 : (lm < 4 ? 1 : 2); }
-
-struct FusedLxArgs {
-  // edge list
-  const int *eoff, *e_ii, *e_j;
-  const unsigned char *e_tt;     // per edge: (model type of centre) << 4 | (model type of neighbour)
-  const int2 *centre;            // per centre ii: {atom index ilist[ii], model type}
-  const float *rvec;
-  const double *rcut;            // [T*T]
-  int T, NL, p;
-  float cenv;
-  // tiles
-  unsigned int *tile_counter;
-  int tchunk;                    // tiles per claim of the dynamic schedule (1 for small systems: a workgroup's last claim sets the makespan)
-  const int *tile_a0, *tile_e0, *ntiles;
-  // weights (offsets in floats into wbase)
-  const float *wbase;
-  int wbytes;
-  int o_stream, o_tbtab, tb_nk, o_tpl, o_out1, o_scale, o_shift;
-  int o_res[LX_MAXNL];
-  // scratch
-  float *scratch;
-  long long wg_scratch, wave_scratch;     // floats
-  // outputs
-  double *f, *eatom, *partial;            // partial [gridDim.x][7]
-  long long *prof;
-};
 
 // Shapes of one instantiation
 template <int L, int UT, int NW> struct ShapeX {
@@ -98,139 +63,10 @@ template <int L, int UT, int NW> struct __attribute__((aligned(16))) LdsX {
   int chunk[2];
 };
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// scalar f32 helpers on 2-feature half rows: component indices written out (v_fmac_f32 with the CG constant as an inline
-// literal; packed f32 would hold every constant in an SGPR pair and the kernel runs out of SGPRs)
-#ifdef AHIP_LX_SCALAR_TP
-__device__ __forceinline__ f32x2 fma_cab(float c, const f32x2 &a, const f32x2 &b, const f32x2 &acc) {      // acc + c * (a * b)
-  f32x2 r;
-  r[0] = fmaf(c, a[0] * b[0], acc[0]); r[1] = fmaf(c, a[1] * b[1], acc[1]);
-  return r;
-}
-__device__ __forceinline__ f32x2 fma_cgo(float c, const f32x2 &gq, const f32x2 &o, const f32x2 &acc) {    // acc + (c * g) * o
-  f32x2 r;
-  r[0] = fmaf(c * gq[0], o[0], acc[0]); r[1] = fmaf(c * gq[1], o[1], acc[1]);
-  return r;
-}
-__device__ __forceinline__ f32x2 fma_rows(const f32x2 &a, const f32x2 &b, const f32x2 &acc) {              // acc + a * b
-  f32x2 r;
-  r[0] = fmaf(a[0], b[0], acc[0]); r[1] = fmaf(a[1], b[1], acc[1]);
-  return r;
-}
-__device__ __forceinline__ f32x2 mul_rows(const f32x2 &a, const f32x2 &b) {
-  f32x2 r;
-  r[0] = a[0] * b[0]; r[1] = a[1] * b[1];
-  return r;
-}
-#else
-// packed f32 (v_pk_mul_f32 / v_pk_fma_f32): a lone wave on a SIMD issues one instruction per 4 cycles whatever it is, so the
-// two-feature packed forms halve the tensor product's issue time
-__device__ __forceinline__ f32x2 fma_cab(float c, const f32x2 &a, const f32x2 &b, const f32x2 &acc) { return acc + c * (a * b); }
-__device__ __forceinline__ f32x2 fma_cgo(float c, const f32x2 &gq, const f32x2 &o, const f32x2 &acc) { return acc + (c * gq) * o; }
-__device__ __forceinline__ f32x2 fma_rows(const f32x2 &a, const f32x2 &b, const f32x2 &acc) { return acc + a * b; }
-__device__ __forceinline__ f32x2 mul_rows(const f32x2 &a, const f32x2 &b) { return a * b; }
-#endif
-
-// ---------------------------------------------------------------------------- tensor product, CG table unrolled
-// The tensor product is element-wise over features, so it is evaluated on HALF rows (2 of the lane's 4 features of a K-tile)
-// at a time: the row sets it keeps live (inputs, environment, outputs) are half as large, which is what lets the whole edge
-// tensor stay in registers next to them.
-// out[i3] += pw[path] * c * v[i1] * e[i2] over the table entries; every index is a compile-time constant.  The table is sorted
-// by path: the entries of one path accumulate (CG constants as literals) into at most 2 l3 + 1 partial rows, which are scaled
-// by the path weight once: two VALU operations per entry and feature.
-template <int L, bool SCALAR, int U>
-__device__ __forceinline__ void tp_fwd_x(const f32x2 (&v)[(L + 1) * (L + 1)], const float *en, const float *tp,
-                                         f32x2 (&out)[SCALAR ? 1 : (L + 1) * (L + 1)]) {
-  constexpr int D = (L + 1) * (L + 1), DOUT = SCALAR ? 1 : D, N = SCALAR ? CgX<L>::NS : CgX<L>::N;
-  f32x2 ee[D];
-#pragma unroll
-  for (int k = 0; k < D; ++k) ee[k] = *(const f32x2 *)(en + k * U);
-#pragma unroll
-  for (int k = 0; k < DOUT; ++k) out[k] = f32x2{0.f, 0.f};
-  f32x2 acc[2 * L + 1];
-#pragma unroll
-  for (int q = 0; q < N; ++q) {
-    constexpr const AhipCgEntry *tab = CgX<L>::tab;
-    const int p = tab[q].path, l3 = l_of_lm(tab[q].i3), b3 = l3 * l3;
-    if (q == 0 || tab[q - 1].path != p) {
-#pragma unroll
-      for (int k = 0; k < 2 * L + 1; ++k) acc[k] = f32x2{0.f, 0.f};
-    }
-    acc[tab[q].i3 - b3] = fma_cab((float)tab[q].c, v[tab[q].i1], ee[tab[q].i2], acc[tab[q].i3 - b3]);
-    if (q == N - 1 || tab[q + 1].path != p) {
-      const f32x2 pw = *(const f32x2 *)(tp + p * U);
-#pragma unroll
-      for (int k = 0; k < 2 * L + 1; ++k)
-        if (k < 2 * l3 + 1) out[b3 + k] = fma_rows(pw, acc[k], out[b3 + k]);
-      __builtin_amdgcn_sched_barrier(0);       // one path at a time: bounds the live products
-    }
-  }
-}
-// Gradient of the tensor product, as two passes over the table so that each pass keeps three row sets live instead of five:
-//   which = 0:  r[i1] += pw c g[i3] o[i2]   with o = environment rows (from LDS)     -> gradient w.r.t. the edge tensor
-//   which = 1:  r[i2] += pw c g[i3] o[i1]   with o = edge tensor rows (registers)   -> per-edge environment gradient
-// per path the output-gradient rows are scaled by the path weight once; two VALU operations per entry and feature.
-template <int L, bool SCALAR, int U, int WHICH>
-__device__ __forceinline__ void tp_bwd_half(const f32x2 (&o)[(L + 1) * (L + 1)], const f32x2 (&pw)[CgX<L>::NP],
-                                            const f32x2 (&g)[SCALAR ? 1 : (L + 1) * (L + 1)], f32x2 (&r)[(L + 1) * (L + 1)]) {
-  constexpr int D = (L + 1) * (L + 1), N = SCALAR ? CgX<L>::NS : CgX<L>::N;
-#pragma unroll
-  for (int k = 0; k < D; ++k) r[k] = f32x2{0.f, 0.f};
-  f32x2 gp[2 * L + 1];
-#pragma unroll
-  for (int q = 0; q < N; ++q) {
-    constexpr const AhipCgEntry *tab = CgX<L>::tab;
-    const int p = tab[q].path, l3 = l_of_lm(tab[q].i3), b3 = l3 * l3;
-    if (q == 0 || tab[q - 1].path != p) {
-#pragma unroll
-      for (int k = 0; k < 2 * L + 1; ++k)
-        if (k < 2 * l3 + 1) gp[k] = mul_rows(pw[p], g[SCALAR ? 0 : b3 + k]);
-    }
-    if (WHICH == 0) r[tab[q].i1] = fma_cgo((float)tab[q].c, gp[tab[q].i3 - b3], o[tab[q].i2], r[tab[q].i1]);
-    else r[tab[q].i2] = fma_cgo((float)tab[q].c, gp[tab[q].i3 - b3], o[tab[q].i1], r[tab[q].i2]);
-    if (q == N - 1 || tab[q + 1].path != p) __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// The edge tensor lives in the ACCUMULATOR half of the unified register file (AGPRs): its 144 registers then do not compete
-// with the arithmetic VGPRs in the register allocator.  A value is parked with v_accvgpr_write (inline asm: there is no
-// builtin); reads are plain uses, the compiler inserts v_accvgpr_read.  No MFMA reads a parked value within the next
-// instructions (every park is followed by VALU / memory work), so the asm needs no wait states of its own.
-__device__ __forceinline__ float acc_park(float x) {
-  float a;
-  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(x));
-  return a;
-}
-__device__ __forceinline__ void acc_put4(float (&dst)[4], const f32x4 &v) {
-  dst[0] = acc_park(v[0]); dst[1] = acc_park(v[1]); dst[2] = acc_park(v[2]); dst[3] = acc_park(v[3]);
-}
-__device__ __forceinline__ void acc_put2(float (&dst)[4], int h, const f32x2 &v) {
-  if (h == 0) { dst[0] = acc_park(v[0]); dst[1] = acc_park(v[1]); } else { dst[2] = acc_park(v[0]); dst[3] = acc_park(v[1]); }
-}
-__device__ __forceinline__ f32x4 acc_get4(const float (&src)[4]) { return f32x4{src[0], src[1], src[2], src[3]}; }
-__device__ __forceinline__ f32x2 acc_get2(const float (&src)[4], int h) { return h == 0 ? f32x2{src[0], src[1]} : f32x2{src[2], src[3]}; }
-
-__device__ __forceinline__ f32x2 half_of(const f32x4 &v, int h) { return h == 0 ? f32x2{v[0], v[1]} : f32x2{v[2], v[3]}; }
-__device__ __forceinline__ void set_half(f32x4 &v, int h, const f32x2 &x) { if (h == 0) { v[0] = x[0]; v[1] = x[1]; } else { v[2] = x[0]; v[3] = x[1]; } }
-// 8-byte half of a saved row image (row = [lane][4 floats])
-__device__ __forceinline__ f32x2 bload_half(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-  return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AHIP_ROW_AUX));
-}
-
-__device__ __forceinline__ float hsum4(const f32x4 &v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 
 // Per-centre sum of one staged K-tile: env[a][lm][16 t + f] = scale * sum_{slots of a} stage[slot][lm][f].
 // Work item = (centre, 4-feature column); its LPI adjacent lanes take every LPI-th slot with 16-byte LDS reads (all of a lane's reads
 // are in flight together) and combine with log2(LPI) cross-lane adds -- a fixed order, so the sums are reproducible.
-// The thread index is recomputed here from the hardware lane counter (and the wave index the caller keeps in an SGPR): a value
-// derived from threadIdx at kernel entry is live across the whole tile and ends up in a scratch slot, whose reload at this point
-// waits (vmcnt(0), loads return in order) for the saved rows the caller has just requested from HBM.
-__device__ __forceinline__ int fresh_lane() {
-  int l;
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-  return l;
-}
 template <int L, int UT, int NW>
 __device__ __forceinline__ void reduce_stage_x(const float *stg, const int *aoff, float *dst, int na, float scale, int t, int uwave) {
   using S = ShapeX<L, UT, NW>;
@@ -269,13 +105,6 @@ __device__ __forceinline__ void reduce_stage_x(const float *stg, const int *aoff
   }
 }
 
-// Saves only the first NMAX output tiles of a linear (the rest is zero padding of a ring-aligned fragment block)
-template <int NMAX> struct EpiSaveN {
-  __amdgpu_buffer_rsrc_t S; int row0, v16;
-  __device__ __forceinline__ void tile_done(int ot, const f32x4 &acc) const { if (ot < NMAX) bstore(S, v16, (row0 + ot) * ROW * 4, acc); }
-  __device__ __forceinline__ float apply(int, int, float v) const { return v; }
-  __device__ __forceinline__ void flush(int) const {}
-};
 // Channel mixing, one (l, m) row at a time, in place on the parked edge tensor: V[lm] <- V[lm] @ M_l (forward, output rows
 // saved as the next layer's V_in) or V[lm] <- V[lm] @ M_l^T (+ ds on the scalar row: backward).  With 32 tensor features a row
 // is 2 x 2 tiles = 4 weight fragments = half a ring: rows alternate the ring phase, and the last (ninth) row is zero-padded on
@@ -818,13 +647,6 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
 }
 
 // ---------------------------------------------------------------------------- host side
-struct FusedLxState {
-  DevBuf wbuf, scratch, seg_count, seg_base, tile_a0, tile_e0, centre, ntiles, partial, prof;
-  FusedLxArgs args;
-  bool ready = false, prof_on = false;
-  int ncu = 256;
-  int L = 0, UT = 0;
-};
 
 bool fusedlx_model_supported(const Model &m, std::string *why) {
   const HostModel &h = m.hm;
@@ -948,34 +770,18 @@ bool fusedlx_run(Model &m, const ComputeArgs &a, std::string *why) {
     return false;
   }
   if (m.edges_T_size != 4) { if (why) *why = "edge vectors are not float32"; return false; }
+  if (m.hm.U == 64) {
+    // 64 tensor features: the wave-pair kernel (fused_lx2.hip, two waves per SIMD); AHIP_LX_PAIR=0 keeps the one-wave-per-SIMD kernel (A/B runs)
+    static const bool pair_on = [] { const char *e = std::getenv("AHIP_LX_PAIR"); return !(e && e[0] == '0'); }();
+    if (pair_on) return fusedlx2_run(m, a, why);
+  }
   fusedlx_prepare(m);
   FusedLxState &st = *(FusedLxState *)m.fusedlx_state;
   hipStream_t s = a.stream;
   const int inum = m.inum;
   const int maxa = ShapeX<2, 4, NW>::MAXA;
   const int grid = std::max(1, st.ncu - (m.reserve_wgs + 1) / 2);      // see fused.hip: slots left free for the exchange kernels
-  const int nseg = (inum + SEG - 1) / SEG;
-  st.seg_count.reserve((size_t)(nseg + 1) * sizeof(int));
-  st.seg_base.reserve((size_t)(nseg + 2) * sizeof(int));
-  st.tile_a0.reserve((size_t)(inum + nseg + 2) * sizeof(int));
-  st.tile_e0.reserve((size_t)(inum + nseg + 2) * sizeof(int));
-  {
-    StageTimer tm(m, "tile_pack", s);
-    const unsigned B = 64;
-    hipLaunchKernelGGL(k_pack_tiles<false>, dim3((nseg + B - 1) / B), dim3(B), 0, s, inum, m.b_eoff.as<int>(), nseg, st.seg_count.as<int>(), (const int *)nullptr, (int *)nullptr, SLOTS, maxa);
-    AHIP_CHECK(prim_exclusive_scan_i32(m.prim, st.seg_count.as<int>(), st.seg_base.as<int>(), nseg, s));
-    hipLaunchKernelGGL(k_pack_tiles<true>, dim3((nseg + B - 1) / B), dim3(B), 0, s, inum, m.b_eoff.as<int>(), nseg, (int *)nullptr, st.seg_base.as<int>(), st.tile_a0.as<int>(), SLOTS, maxa);
-    hipLaunchKernelGGL(k_pack_finish, dim3(1), dim3(1), 0, s, inum, nseg, st.seg_base.as<int>(), st.tile_a0.as<int>(), st.ntiles.as<int>());
-    const int tcap = inum + nseg + 1;
-    st.centre.reserve((size_t)std::max(inum, 1) * sizeof(int2));
-    hipLaunchKernelGGL(k_centre_info, dim3((inum + 255) / 256), dim3(256), 0, s, inum, m.d_ilist, a.mtype, st.centre.as<int2>());
-    if (!m.have_ett) {
-      m.b_ett.reserve((size_t)std::max<long long>(m.nedges, 1));
-      hipLaunchKernelGGL(k_edge_types, dim3((unsigned)((m.nedges + 255) / 256)), dim3(256), 0, s, m.nedges, m.b_eii.as<int>(), m.b_ej.as<int>(), m.d_ilist, a.mtype, m.b_ett.as<unsigned char>());
-      m.have_ett = true;
-    }
-    hipLaunchKernelGGL(k_tile_e0, dim3((tcap + 255) / 256), dim3(256), 0, s, st.ntiles.as<int>(), st.tile_a0.as<int>(), m.b_eoff.as<int>(), st.tile_e0.as<int>());
-  }
+  lx_pack_tiles(m, st, a, SLOTS, maxa);
   FusedLxArgs A = st.args;
   A.wg_scratch = NW * A.wave_scratch;
   A.eoff = m.b_eoff.as<int>(); A.e_ii = m.b_eii.as<int>(); A.e_j = m.b_ej.as<int>();

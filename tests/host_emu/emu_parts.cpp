@@ -48,6 +48,8 @@ void fused_free(Model &) {}
 bool fusedlx_model_supported(const Model &, std::string *why) { if (why) *why = "host emulation has no MFMA"; return false; }
 bool fusedlx_run(Model &, const ComputeArgs &, std::string *why) { if (why) *why = "host emulation has no MFMA"; return false; }
 void fusedlx_free(Model &) {}
+bool fusedlx2_run(Model &, const ComputeArgs &, std::string *why) { if (why) *why = "host emulation has no MFMA"; return false; }
+void fusedlx2_free(Model &) {}
 void edges_compact_heavy(Model &, const ComputeArgs &) {}
 bool edges_build_f32(Model &, const ComputeArgs &) { return false; }   // emulation runs the two-pass kernels
 void edges_free(Model &) {}

@@ -377,6 +377,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) eps += silu1(zr[t][r]) * wo1[t][r];
     eps = gsum(eps);
+    pin(eps);
 
     // =========================== backward ===========================
     const float deps = valid ? lds.scale[ti] * A.cenv : 0.f;
@@ -414,6 +415,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) { du[t] = rbfc * dx[t]; dx[t] = ra * dx[t]; }
           dfc_part += rb * hsum4(accv);
+          pin(dfc_part);
         }
         linear_s<4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt});
         linear_s<4, 4, false, 0>(WB, wp, dh, du, v16, ring, EpiMulRows<4>{rows1});
@@ -523,6 +525,8 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
               dY[lm] += hsum4(dv * omr[l_of_lm(lm)]);
             }
           }
+#pragma unroll
+          for (int lm = 1; lm < D; ++lm) pin(dY[lm]);        // see pin(): keeps the sums where they are computed
           __builtin_amdgcn_sched_barrier(0);
         }
         ring_prime(WB, wp, v16, ring);          // RING_DROP: requested again only now -- the d omega / dY arithmetic above needs the registers
@@ -555,6 +559,8 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
             dY[lm] += hsum4(dv * w0r[l_of_lm(lm)]);
           }
         }
+#pragma unroll
+        for (int lm = 1; lm < D; ++lm) pin(dY[lm]);
         __builtin_amdgcn_sched_barrier(0);
       }
       linear_s<EW, 4, true, 0>(WB, wp, dw0, dx, v16, ring, EpiNone{});
@@ -570,6 +576,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
 #pragma unroll
       for (int t = 1; t < 4; ++t) accv += dx[t] * rows[t];
       dd_part = hsum4(accv);
+      pin(dd_part);
     }
     // ---------------- geometry backward, outputs ----------------
     {

@@ -67,6 +67,7 @@ struct __attribute__((aligned(16))) LdsP {
   float denv[S::MAXA * S::ENVA];
   float tp[LX_MAXNL][S::NP * S::U];          // tensor-product path weights [layer][path][u]
   float xch[S::NW][2][2 * ROW];              // pair hand-over: [wave][buffer][2 register images]
+  int aloc[64];                              // centre slot of every edge slot (parked here instead of a register that lives a whole tile)
   float ych[4][16][12];                      // per-edge channel sums of the second wave of a pair: dY[1..8], cutoff and distance parts
   double eacc[S::MAXA];
   double virw[4][6];
@@ -122,16 +123,17 @@ __device__ __forceinline__ void reduce_stage_p(const float *stg, const int *aoff
 struct Xch {
   float *mine;            // lds.xch[wave]
   const float *theirs;    // lds.xch[partner wave]
-  int lane4;
 };
 template <int NT> __device__ __forceinline__ void x_send(const Xch &X, int xb, const f32x4 (&v)[NT]) {
   static_assert(NT <= 2, "two images per buffer");
+  const int lane4 = fresh_lane() * 4;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) *(f32x4 *)(X.mine + (xb * 2 + t) * ROW + X.lane4) = v[t];
+  for (int t = 0; t < NT; ++t) *(f32x4 *)(X.mine + (xb * 2 + t) * ROW + lane4) = v[t];
 }
 template <int NT> __device__ __forceinline__ void x_recv(const Xch &X, int xb, f32x4 (&v)[NT]) {
+  const int lane4 = fresh_lane() * 4;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) v[t] = *(const f32x4 *)(X.theirs + (xb * 2 + t) * ROW + X.lane4);
+  for (int t = 0; t < NT; ++t) v[t] = *(const f32x4 *)(X.theirs + (xb * 2 + t) * ROW + lane4);
 }
 template <int NT> __device__ __forceinline__ void x_swap(const Xch &X, int &xb, const f32x4 (&out)[NT], f32x4 (&in)[NT]) {
   x_send<NT>(X, xb, out);
@@ -145,7 +147,7 @@ template <int NT> __device__ __forceinline__ void x_swap(const Xch &X, int &xb, 
 //   V[lm][own] <- the same with M_l^T (+ ds on the scalar row)  (backward)
 // Row lm + 1 is handed over before row lm's MFMAs are issued, so the partner's images are in LDS when the next barrier falls.
 template <int LM, bool FWD>
-__device__ __forceinline__ void mix_rows_p(float (&V)[9][2][4], __amdgpu_buffer_rsrc_t WB, int &wp, int v16, f32x4 (&ring)[RING],
+__device__ __forceinline__ void mix_rows_p(float (&V)[9][2][4], __amdgpu_buffer_rsrc_t WB, int &wp, f32x4 (&ring)[RING],
                                            __amdgpu_buffer_rsrc_t SB, int row0, const f32x4 (&ds)[2], const Xch &X, int &xb) {
   if constexpr (LM < 9) {
     f32x4 in[4], o[2];
@@ -165,20 +167,15 @@ __device__ __forceinline__ void mix_rows_p(float (&V)[9][2][4], __amdgpu_buffer_
       f32x4 nx[2] = {acc_get4(V[LM + 1][0]), acc_get4(V[LM + 1][1])};
       x_send<2>(X, xb, nx);
     }
+    const int v16 = fresh_lane() << 4;
     if constexpr (FWD) linear_s<4, 2, false, 0>(WB, wp, in, o, v16, ring, EpiSaveN<2>{SB, row0 + LM * 2, v16});
     else linear_s<4, 2, false, 0>(WB, wp, in, o, v16, ring, EpiNone{});
 #pragma unroll
     for (int t = 0; t < 2; ++t) acc_put4(V[LM][t], (!FWD && LM == 0) ? o[t] + ds[t] : o[t]);
     __builtin_amdgcn_sched_barrier(0);
-    mix_rows_p<LM + 1, FWD>(V, WB, wp, v16, ring, SB, row0, ds, X, xb);
+    mix_rows_p<LM + 1, FWD>(V, WB, wp, ring, SB, row0, ds, X, xb);
   }
 }
-
-// Pins a running per-edge sum where it is computed.  The sums over channels (dE/dY, the cutoff and distance derivatives, the edge energy) are
-// only consumed at the end of the tile; without the pin the optimiser SINKS their whole accumulation chains down to that use, which keeps
-// every operand row (LDS reads of the environment gradient, saved omega / w0 rows) alive until then -- in scratch: they were most of the
-// kernel's spill traffic (18 + 18 + 21 sixteen-byte reloads in the finish phase).
-__device__ __forceinline__ void pin(float &v) { asm volatile("" : "+v"(v)); }
 
 enum { PP_GEOM = 0, PP_EMB, PP_ENV, PP_TP, PP_LAT, PP_MIX, PP_OUT, PP_BLAT, PP_BMIX, PP_BTP, PP_BENV, PP_BEMB, PP_FIN, PP_N };
 #define PHASEP(id) do { if (PROF) { long long _t = clock64(); pacc[id] += _t - tprev; tprev = _t; } } while (0)
@@ -192,7 +189,10 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
   const int uwave = __builtin_amdgcn_readfirstlane(wave);
   const int hf = uwave >> 2, q = uwave & 3;            // wave half (channels 32 hf .. 32 hf + 31) and pair index (edge slots 16 q .. 16 q + 15)
-  const int v16 = lane * 16;
+  // Lane-derived addresses are RECOMPUTED where they are used (from the hardware lane counter and wave-uniform values) instead of kept in
+  // registers across the tile: a register that lives that long is spilled, and its reload -- `s_waitcnt vmcnt(0)`, loads return in order --
+  // waits for every saved row requested ahead from HBM.  The centre slot of the lane's edge is parked in LDS for the same reason.
+  auto V16 = [&]() { return fresh_lane() << 4; };
   __amdgpu_buffer_rsrc_t SB, WB;
   {
     unsigned long long b = (unsigned long long)(A.scratch + (size_t)blockIdx.x * A.wg_scratch + (size_t)wave * A.wave_scratch);
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
   f32x4 ring[RING];
   const int wp0 = hf ? A.o_stream_hi : A.o_stream;
   int wp = wp0;
-  ring_prime(WB, wp, v16, ring);
+  ring_prime(WB, wp, V16(), ring);
   if (tid < MAXA) lds.eacc[tid] = 0.0;
   if (hf == 0 && lane < 6) lds.virw[q][lane] = 0.0;
   if (tid < A.T * A.T) lds.rc[tid] = (float)A.rcut[tid];
@@ -228,7 +228,6 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
   Xch X;
   X.mine = &lds.xch[uwave][0][0];
   X.theirs = &lds.xch[uwave ^ 4][0][0];
-  X.lane4 = lane * 4;
   int xb = 0;
   if (tid == 0) lds.chunk[0] = (int)atomicAdd(A.tile_counter, (unsigned)A.tchunk);
   __syncthreads();
@@ -280,14 +279,17 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
     Y[1] = C3 * ny; Y[2] = C3 * nz; Y[3] = C3 * nx;
     Y[4] = C15 * nx * ny; Y[5] = C15 * ny * nz; Y[6] = C5H * (2.f * nz * nz - nx * nx - ny * ny);
     Y[7] = C15 * nx * nz; Y[8] = 0.5f * C15 * (nx * nx - ny * ny);
-    const int envoff = aloc * ENVA + 4 * g + choff;      // + kk * MAXA*ENVA (layer) + lm * U + 16 t
-    float *const stw = lds.stage[0] + hf * (S::SLOTS * STG_LD) + s * STG_LD + 4 * g;     // this lane's staging row in its half's K-tile
+    if (hf == 0 && g == 0) lds.aloc[s] = aloc;           // read back by ENVOFF() after the barrier that follows the embedding
+    // this lane's offset into an environment row set: + kk * MAXA*ENVA (layer) + lm * U + 16 t
+    auto ENVOFF = [&]() { const int ln = fresh_lane(); return lds.aloc[q * 16 + (ln & 15)] * ENVA + 4 * (ln >> 4) + choff; };
+    // this lane's staging row in its half's K-tile
+    auto STW = [&]() { const int ln = fresh_lane(); return lds.stage[0] + hf * (S::SLOTS * STG_LD) + (q * 16 + (ln & 15)) * STG_LD + 4 * (ln >> 4); };
     PHASEP(PP_GEOM);
 
     // ---------------- two-body embedding x0(d; type pair) from the spline table; local tile k = global tile (k + 2 hf) & 3 ----------------
     f32x4 x[4];
     {
-      ring_prime(WB, wp, v16, ring);        // the ring is not carried through the finish / geometry phases of the tile boundary
+      ring_prime(WB, wp, V16(), ring);        // the ring is not carried through the finish / geometry phases of the tile boundary
       const float tb_invh = (float)A.tb_nk / rc;
       const float sft = d * tb_invh;
       const int kq = min((int)sft, A.tb_nk - 1);
@@ -299,14 +301,14 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
         const float *te = tb_ent + (((t + 2 * hf) & 3) * 4) * 16;
         const f32x4 c0 = *(const f32x4 *)(te), c1 = *(const f32x4 *)(te + 16), c2 = *(const f32x4 *)(te + 32), c3 = *(const f32x4 *)(te + 48);
         x[t] = (c0 + tb_t * (c1 + tb_t * (c2 + tb_t * c3))) * vm;
-        bstore(SB, v16, (S::R_DX0 + t) * ROW * 4, (c1 + tb_t * (2.f * c2 + (3.f * tb_t) * c3)) * (vm * tb_invh));
+        bstore(SB, V16(), (S::R_DX0 + t) * ROW * 4, (c1 + tb_t * (2.f * c2 + (3.f * tb_t) * c3)) * (vm * tb_invh));
       }
     }
     // ---------------- tensor embedding V^0[lm][u] = w0[l][u] Y[lm], own channels ----------------
     float V[D][HT][4];       // own half of the edge tensor, forward; of its gradient, backward: parked in AGPRs (acc_park)
     {
       f32x4 w0[EWH];
-      linear_s<4, EWH, false, 0>(WB, wp, x, w0, v16, ring, EpiSave{SB, S::R_W0, v16});
+      linear_s<4, EWH, false, 0>(WB, wp, x, w0, V16(), ring, EpiSave{SB, S::R_W0, V16()});
 #pragma unroll
       for (int lm = 0; lm < D; ++lm)
 #pragma unroll
@@ -324,10 +326,11 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
       float *const envk = lds.env[kk];
       {
         f32x4 om[EWH];
-        linear_s<4, EWH, false, 0>(WB, wp, x, om, v16, ring, EpiSave{SB, RL + S::O_OM, v16});
+        linear_s<4, EWH, false, 0>(WB, wp, x, om, V16(), ring, EpiSave{SB, RL + S::O_OM, V16()});
         // environment sum over the centre's edges: both halves stage one own K-tile, all waves reduce both
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
+          float *const stw = STW();
 #pragma unroll
           for (int lm = 0; lm < D; ++lm) *(f32x4 *)(stw + lm * 16) = lm == 0 ? om[t] : om[l_of_lm(lm) * HT + t] * Y[lm];
           __syncthreads();
@@ -340,7 +343,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
       // tensor product, in place per own K-tile; the weight-fragment ring is dropped and requested again under the last half pass
       f32x4 sc[HT];            // scalar outputs (l3 = 0) of the tensor product, own channels
       {
-        const float *en = envk + envoff;
+        const float *en = envk + ENVOFF();
         const float *tp = lds.tp[kk] + 4 * g + choff;
         if (!last) {
 #pragma unroll
@@ -350,7 +353,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
               f32x2 vin[D], out[D];
 #pragma unroll
               for (int lm = 0; lm < D; ++lm) vin[lm] = acc_get2(V[lm][t], h);
-              if (t == HT - 1 && h == 1) ring_prime(WB, wp, v16, ring);
+              if (t == HT - 1 && h == 1) ring_prime(WB, wp, V16(), ring);
               tp_fwd_x<L, false, U>(vin, en + 16 * t + 2 * h, tp + 16 * t + 2 * h, out);
 #pragma unroll
               for (int lm = 0; lm < D; ++lm) acc_put2(V[lm][t], h, out[lm]);
@@ -366,7 +369,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
               f32x2 vin[D], out[1];
 #pragma unroll
               for (int lm = 0; lm < D; ++lm) vin[lm] = acc_get2(V[lm][t], h);
-              if (t == HT - 1 && h == 1) ring_prime(WB, wp, v16, ring);
+              if (t == HT - 1 && h == 1) ring_prime(WB, wp, V16(), ring);
               tp_fwd_x<L, true, U>(vin, en + 16 * t + 2 * h, tp + 16 * t + 2 * h, out);
               set_half(sc[t], h, out[0]);
               __builtin_amdgcn_sched_barrier(0);
@@ -382,31 +385,31 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
         for (int t = 0; t < 4; ++t) cat[t] = x[t];
         x_swap<2>(X, xb, sc, pr);
         cat[4] = sc[0]; cat[5] = sc[1]; cat[6] = pr[0]; cat[7] = pr[1];
-        linear_s<8, 2, false, 0>(WB, wp, cat, z, v16, ring, EpiSiluSaveD{SB, RL + S::O_Z1, v16});
+        linear_s<8, 2, false, 0>(WB, wp, cat, z, V16(), ring, EpiSiluSaveD{SB, RL + S::O_Z1, V16()});
         x_swap<2>(X, xb, z, pr);
         zin[0] = z[0]; zin[1] = z[1]; zin[2] = pr[0]; zin[3] = pr[1];
-        linear_s<4, 2, false, 0>(WB, wp, zin, z2, v16, ring, EpiSiluSaveD{SB, RL + S::O_Z2, v16});
+        linear_s<4, 2, false, 0>(WB, wp, zin, z2, V16(), ring, EpiSiluSaveD{SB, RL + S::O_Z2, V16()});
         x_swap<2>(X, xb, z2, pr);
         zin[0] = z2[0]; zin[1] = z2[1]; zin[2] = pr[0]; zin[3] = pr[1];
         const float ra = lds.res[kk][0], rbf = lds.res[kk][1] * fc;
         f32x4 xo[2] = {x[0], x[1]};
-        linear_s<4, 2, false, 0>(WB, wp, zin, xn, v16, ring, EpiResidual<2>{{SB, RL + S::O_U, v16}, xo, ra, rbf});
+        linear_s<4, 2, false, 0>(WB, wp, zin, xn, V16(), ring, EpiResidual<2>{{SB, RL + S::O_U, V16()}, xo, ra, rbf});
         x_swap<2>(X, xb, xn, pr);
         x[0] = xn[0]; x[1] = xn[1]; x[2] = pr[0]; x[3] = pr[1];
       }
       PHASEP(PP_LAT);
       // channel mixing, in place per (l, m) row -> V^{kk+1}, saved as the next layer's V_in rows
-      if (!last) mix_rows_p<0, true>(V, WB, wp, v16, ring, SB, S::R_LAYER(kk + 1) + S::O_VIN, sc, X, xb);
+      if (!last) mix_rows_p<0, true>(V, WB, wp, ring, SB, S::R_LAYER(kk + 1) + S::O_VIN, sc, X, xb);
       PHASEP(PP_MIX);
     }
 
     // ---------------- read-out (both waves of a pair evaluate it) ----------------
     f32x4 upre[2], zt[2], w0pre[L * HT];
-    load_rows<2>(SB, S::R_LAYER(NL - 1) + S::O_U, upre, v16);
-    load_rows<2>(SB, S::R_LAYER(NL - 1) + S::O_Z2, zt, v16);
+    load_rows<2>(SB, S::R_LAYER(NL - 1) + S::O_U, upre, V16());
+    load_rows<2>(SB, S::R_LAYER(NL - 1) + S::O_Z2, zt, V16());
     __builtin_amdgcn_sched_barrier(0);
     f32x4 zr[2];
-    linear_s<4, 2, false, 0>(WB, wp, x, zr, v16, ring, EpiNone{});
+    linear_s<4, 2, false, 0>(WB, wp, x, zr, V16(), ring, EpiNone{});
     f32x4 wo1[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) wo1[t] = *(const f32x4 *)(Wb + A.o_out1 + 16 * t + 4 * g);
@@ -427,7 +430,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dzr[t][r] = deps * wo1[t][r] * dsilu1(zr[t][r]);
-      linear_s<2, 4, false, 0>(WB, wp, dzr, dx, v16, ring, EpiNone{});
+      linear_s<2, 4, false, 0>(WB, wp, dzr, dx, V16(), ring, EpiNone{});
     }
     float dfc_part = 0.f;    // partial sums over the own channels / own latent tiles: they meet in lds.ych at the end of the tile
     float dY[D];
@@ -444,7 +447,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
       {
         f32x4 du[4], dh[2], din[4], pr[2];
         f32x4 rows1[2];
-        load_rows<2>(SB, RL + S::O_Z1, rows1, v16);            // silu'(z1), own tiles: first used one linear from here
+        load_rows<2>(SB, RL + S::O_Z1, rows1, V16());            // silu'(z1), own tiles: first used one linear from here
         __builtin_amdgcn_sched_barrier(0);
         {
           const float ra = lds.res[kk][0], rb = lds.res[kk][1];
@@ -457,24 +460,24 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
           dfc_part += rb * hsum4(accv);
           pin(dfc_part);
         }
-        linear_s<4, 2, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<2>{zt});
+        linear_s<4, 2, false, 0>(WB, wp, du, dh, V16(), ring, EpiMulRows<2>{zt});
         x_swap<2>(X, xb, dh, pr);
         din[0] = dh[0]; din[1] = dh[1]; din[2] = pr[0]; din[3] = pr[1];
-        linear_s<4, 2, false, 0>(WB, wp, din, dh, v16, ring, EpiMulRows<2>{rows1});
+        linear_s<4, 2, false, 0>(WB, wp, din, dh, V16(), ring, EpiMulRows<2>{rows1});
         x_swap<2>(X, xb, dh, pr);
         din[0] = dh[0]; din[1] = dh[1]; din[2] = pr[0]; din[3] = pr[1];
         f32x4 dcat[4];       // own x tiles (2), own scalar tiles (2)
-        linear_s<4, 4, false, 0>(WB, wp, din, dcat, v16, ring, EpiNone{});
+        linear_s<4, 4, false, 0>(WB, wp, din, dcat, V16(), ring, EpiNone{});
         P[0] += dcat[0]; P[1] += dcat[1];
         ds[0] = dcat[2]; ds[1] = dcat[3];
       }
       PHASEP(PP_BLAT);
       // mix^T in place per (l, m) row: V holds dE/dV^{kk+1}, becomes dE/dV' (tensor-product output gradient)
-      if (!last) mix_rows_p<0, false>(V, WB, wp, v16, ring, SB, 0, ds, X, xb);
+      if (!last) mix_rows_p<0, false>(V, WB, wp, ring, SB, 0, ds, X, xb);
       PHASEP(PP_BMIX);
       // tensor-product gradient in place per own K-tile; the per-edge environment gradient goes through the stage
       {
-        const float *en = lds.env[kk] + envoff;
+        const float *en = lds.env[kk] + ENVOFF();
         const float *tp = lds.tp[kk] + 4 * g + choff;
         // Saved input rows V^{kk}[.][t] (w0 rows for the first layer) of half pass i = 2 t + h: requested while half pass i - 1 computes its
         // environment gradient, consumed by half pass i's second table pass.  Register budget of a half pass: environment rows 18 + output
@@ -486,10 +489,10 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
           const int t = i >> 1, h = i & 1;
           if (kk > 0) {
 #pragma unroll
-            for (int lm = 0; lm < D; ++lm) vnext[lm] = bload_half(SB, v16 + 8 * h, (RL + S::O_VIN + lm * HT + t) * ROW * 4);
+            for (int lm = 0; lm < D; ++lm) vnext[lm] = bload_half(SB, V16() + 8 * h, (RL + S::O_VIN + lm * HT + t) * ROW * 4);
           } else {
 #pragma unroll
-            for (int l = 0; l <= L; ++l) vnext[l] = bload_half(SB, v16 + 8 * h, (S::R_W0 + l * HT + t) * ROW * 4);
+            for (int l = 0; l <= L; ++l) vnext[l] = bload_half(SB, V16() + 8 * h, (S::R_W0 + l * HT + t) * ROW * 4);
           }
         };
         request_vin(0);
@@ -539,11 +542,14 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
               }
               tp_bwd_half<L, true, U, 1>(vin, tph, gg, b);
             }
+            {
+              float *const stw = STW();
 #pragma unroll
-            for (int lm = 0; lm < D; ++lm) *(f32x2 *)(stw + lm * 16 + 2 * h) = b[lm];
+              for (int lm = 0; lm < D; ++lm) *(f32x2 *)(stw + lm * 16 + 2 * h) = b[lm];
+            }
             __builtin_amdgcn_sched_barrier(0);
           }
-          if (t == HT - 1) load_rows<L * HT>(SB, RL + S::O_OM + HT, omall, v16);
+          if (t == HT - 1) load_rows<L * HT>(SB, RL + S::O_OM + HT, omall, V16());
           __syncthreads();
           reduce_stage_p(lds.stage[0], aoffp, lds.denv, na, A.cenv, t, uwave);
           __builtin_amdgcn_sched_barrier(0);
@@ -552,7 +558,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
         PHASEP(PP_BTP);
         // environment weights backward, own channels: d omega[l][u] = sum_m denv[lm][u] Y[lm];  dY[lm] += sum_u denv[lm][u] omega[l][u]
         f32x4 dom[EWH];
-        const float *dn = lds.denv + envoff;
+        const float *dn = lds.denv + ENVOFF();
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
           f32x4 omr[L + 1];
@@ -573,13 +579,13 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
           for (int lm = 1; lm < D; ++lm) pin(dY[lm]);
           __builtin_amdgcn_sched_barrier(0);
         }
-        ring_prime(WB, wp, v16, ring);
+        ring_prime(WB, wp, V16(), ring);
         if (kk > 0) {
-          load_rows<2>(SB, S::R_LAYER(kk - 1) + S::O_U, upre, v16);
-          load_rows<2>(SB, S::R_LAYER(kk - 1) + S::O_Z2, zt, v16);
-        } else load_rows<L * HT>(SB, S::R_W0 + HT, w0pre, v16);
+          load_rows<2>(SB, S::R_LAYER(kk - 1) + S::O_U, upre, V16());
+          load_rows<2>(SB, S::R_LAYER(kk - 1) + S::O_Z2, zt, V16());
+        } else load_rows<L * HT>(SB, S::R_W0 + HT, w0pre, V16());
         __builtin_amdgcn_sched_barrier(0);
-        linear_s<EWH, 4, true, 0>(WB, wp, dom, P, v16, ring, EpiNone{});      // split by input tile: partial sums over the own channels
+        linear_s<EWH, 4, true, 0>(WB, wp, dom, P, V16(), ring, EpiNone{});      // split by input tile: partial sums over the own channels
       }
       if (kk > 0) {
         // dE/dx^{kk-1} = P + P(partner): reduce-scatter (each wave completes its own two tiles), then all-gather
@@ -618,7 +624,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
         for (int lm = 1; lm < D; ++lm) pin(dY[lm]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      linear_s<EWH, 4, true, 0>(WB, wp, dw0, dx, v16, ring, EpiNone{});
+      linear_s<EWH, 4, true, 0>(WB, wp, dw0, dx, V16(), ring, EpiNone{});
       wp = wp0;                                                            // last linear of the tile (wrap-around copy follows it)
     }
     PHASEP(PP_BEMB);
@@ -626,7 +632,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
     float dd_part;
     {
       f32x4 rows[4];
-      load_rows<4>(SB, S::R_DX0, rows, v16);
+      load_rows<4>(SB, S::R_DX0, rows, V16());
       f32x4 accv = dx[0] * rows[0];
 #pragma unroll
       for (int t = 1; t < 4; ++t) accv += dx[t] * rows[t];

@@ -230,6 +230,12 @@ __device__ __forceinline__ f32x2 bload_half(__amdgpu_buffer_rsrc_t r, int voff, 
   return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AHIP_ROW_AUX));
 }
 
+// Pins a running per-edge sum where it is computed.  The sums over channels (dE/dY, the cutoff and distance derivatives, the edge energy) are
+// only consumed at the end of the tile; without the pin the optimiser SINKS their whole accumulation chains down to that use, which keeps
+// every operand row (LDS reads of the environment gradient, saved omega / w0 rows) alive until then -- in scratch: they were most of the
+// kernel's spill traffic (18 + 18 + 21 sixteen-byte reloads in the finish phase).
+__device__ __forceinline__ void pin(float &v) { asm volatile("" : "+v"(v)); }
+
 __device__ __forceinline__ float hsum4(const f32x4 &v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 
 // The thread index is recomputed here from the hardware lane counter (and the wave index the caller keeps in an SGPR): a value

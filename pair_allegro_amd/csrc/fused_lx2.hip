@@ -40,7 +40,7 @@
 #ifndef AHIP_ROW_AUX
 #define AHIP_ROW_AUX 2          // saved rows: non-temporal (fused_common.h)
 #endif
-// #define AHIP_NO_ACC_PARK 1     (V in plain VGPRs: 1557 spill stores instead of 664 -- the allocator does better with the edge tensor out of its way)
+#define AHIP_NO_ACC_PARK 1
 #include "engine.h"
 #include "fused_lx_common.h"
 #include "prims.h"
@@ -517,6 +517,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
                 for (int lm = 0; lm < D; ++lm) acc_put2(V[lm][t], h, a[lm]);
               }
               __builtin_amdgcn_sched_barrier(0);
+              asm volatile("" ::: "memory");      // the second table pass reads the path weights from LDS again (merged loads = 30 registers held across the first)
               if (2 * t + h + 1 < 2 * HT) request_vin(2 * t + h + 1);
               if (kk == 0) {
 #pragma unroll
@@ -535,6 +536,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
                 for (int lm = 0; lm < D; ++lm) acc_put2(V[lm][t], h, a[lm]);
               }
               __builtin_amdgcn_sched_barrier(0);
+              asm volatile("" ::: "memory");      // the second table pass reads the path weights from LDS again (merged loads = 30 registers held across the first)
               if (2 * t + h + 1 < 2 * HT) request_vin(2 * t + h + 1);
               if (kk == 0) {
 #pragma unroll

@@ -205,7 +205,7 @@ __device__ __forceinline__ void tp_bwd_half(const f32x2 (&o)[(L + 1) * (L + 1)],
 #ifdef AHIP_NO_ACC_PARK
 // two waves per SIMD (fused_lx2.hip): 256 registers per wave either way, and a kernel that names no AGPR gets all of them as
 // ordinary VGPRs (with AGPRs in use the compiler splits the file 128 / 128, whatever the kernel needs)
-__device__ __forceinline__ float acc_park(float x) { return x; }
+__device__ __forceinline__ float acc_park(float x) { asm volatile("" : "+v"(x)); return x; }      // pinned: the value is computed HERE (see pin())
 #else
 __device__ __forceinline__ float acc_park(float x) {
   float a;

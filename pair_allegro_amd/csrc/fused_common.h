@@ -32,12 +32,17 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 #ifndef AHIP_ROW_AUX
 #define AHIP_ROW_AUX 0
 #endif
+#ifdef ABL_NOROWS   // timing experiment only (results are wrong): no saved-row traffic
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t, int voff, int soff) { const float q = __builtin_bit_cast(float, (voff + soff) | 0x3f000000); return f32x4{q, q, q, q}; }
+__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t, int, int, f32x4 v) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); }
+#else
 __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AHIP_ROW_AUX));
 }
 __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, int voff, int soff, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, AHIP_ROW_AUX);
 }
+#endif
 __device__ __forceinline__ f32x4 bload_w(__amdgpu_buffer_rsrc_t r, int voff, int soff) {        // weight fragments: default policy
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }

@@ -120,6 +120,8 @@ __device__ __forceinline__ void reduce_stage_p(const float *stg, const int *aoff
 // send: own register images into this wave's buffer xb; after a workgroup barrier the partner's images are read from its buffer.
 // The buffers alternate (xb ^= 1 per hand-over): a buffer is rewritten two hand-overs later, i.e. after a barrier that the partner
 // passes only with its reads of the older contents complete (s_waitcnt lgkmcnt(0) precedes every s_barrier).
+// (A pair-only synchronisation -- per-wave counters in LDS, spin on the partner's -- was measured instead of the workgroup barrier:
+// 29.8 vs 29.3 ms on the 41k-atom water box, i.e. the eight waves arrive together anyway; dropped.)
 struct Xch {
   float *mine;            // lds.xch[wave]
   const float *theirs;    // lds.xch[partner wave]
@@ -130,6 +132,11 @@ template <int NT> __device__ __forceinline__ void x_send(const Xch &X, int xb, c
 #pragma unroll
   for (int t = 0; t < NT; ++t) *(f32x4 *)(X.mine + (xb * 2 + t) * ROW + lane4) = v[t];
 }
+__device__ __forceinline__ void x_wait(const Xch &) {
+#ifndef ABL_NOSYNC
+  __syncthreads();
+#endif
+}
 template <int NT> __device__ __forceinline__ void x_recv(const Xch &X, int xb, f32x4 (&v)[NT]) {
   const int lane4 = fresh_lane() * 4;
 #pragma unroll
@@ -137,7 +144,7 @@ template <int NT> __device__ __forceinline__ void x_recv(const Xch &X, int xb, f
 }
 template <int NT> __device__ __forceinline__ void x_swap(const Xch &X, int &xb, const f32x4 (&out)[NT], f32x4 (&in)[NT]) {
   x_send<NT>(X, xb, out);
-  __syncthreads();
+  x_wait(X);
   x_recv<NT>(X, xb, in);
   xb ^= 1;
 }
@@ -156,7 +163,7 @@ __device__ __forceinline__ void mix_rows_p(float (&V)[9][2][4], __amdgpu_buffer_
       f32x4 me[2] = {in[0], in[1]};
       x_send<2>(X, xb, me);
     }
-    __syncthreads();
+    x_wait(X);
     {
       f32x4 pr[2];
       x_recv<2>(X, xb, pr);
@@ -334,7 +341,9 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
 #pragma unroll
           for (int lm = 0; lm < D; ++lm) *(f32x4 *)(stw + lm * 16) = lm == 0 ? om[t] : om[l_of_lm(lm) * HT + t] * Y[lm];
           __syncthreads();
+          #ifndef ABL_NOREDUCE
           reduce_stage_p(lds.stage[0], aoffp, envk, na, A.cenv, t, uwave);
+#endif
           __builtin_amdgcn_sched_barrier(0);
           __syncthreads();
         }
@@ -354,7 +363,10 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
 #pragma unroll
               for (int lm = 0; lm < D; ++lm) vin[lm] = acc_get2(V[lm][t], h);
               if (t == HT - 1 && h == 1) ring_prime(WB, wp, V16(), ring);
-              tp_fwd_x<L, false, U>(vin, en + 16 * t + 2 * h, tp + 16 * t + 2 * h, out);
+              f32x2 ee[D];
+#pragma unroll
+              for (int lm = 0; lm < D; ++lm) ee[lm] = *(const f32x2 *)(en + 16 * t + 2 * h + lm * U);
+              tp_g<L, 0, false, U>(vin, ee, tp + 16 * t + 2 * h, out);
 #pragma unroll
               for (int lm = 0; lm < D; ++lm) acc_put2(V[lm][t], h, out[lm]);
               __builtin_amdgcn_sched_barrier(0);
@@ -370,7 +382,10 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
 #pragma unroll
               for (int lm = 0; lm < D; ++lm) vin[lm] = acc_get2(V[lm][t], h);
               if (t == HT - 1 && h == 1) ring_prime(WB, wp, V16(), ring);
-              tp_fwd_x<L, true, U>(vin, en + 16 * t + 2 * h, tp + 16 * t + 2 * h, out);
+              f32x2 ee[D];
+#pragma unroll
+              for (int lm = 0; lm < D; ++lm) ee[lm] = *(const f32x2 *)(en + 16 * t + 2 * h + lm * U);
+              tp_g<L, 0, true, U>(vin, ee, tp + 16 * t + 2 * h, out);
               set_half(sc[t], h, out[0]);
               __builtin_amdgcn_sched_barrier(0);
             }
@@ -512,7 +527,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
                 f32x2 a[D], ee[D];
 #pragma unroll
                 for (int lm = 0; lm < D; ++lm) ee[lm] = *(const f32x2 *)(en + 16 * t + 2 * h + lm * U);
-                tp_bwd_half<L, false, U, 0>(ee, tph, gg, a);
+                tp_g<L, 1, false, U>(gg, ee, tph, a);
 #pragma unroll
                 for (int lm = 0; lm < D; ++lm) acc_put2(V[lm][t], h, a[lm]);
               }
@@ -523,7 +538,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
 #pragma unroll
                 for (int lm = D - 1; lm >= 1; --lm) vin[lm] = vin[l_of_lm(lm)] * Y[lm];
               }
-              tp_bwd_half<L, false, U, 1>(vin, tph, gg, b);
+              tp_g<L, 2, false, U>(gg, vin, tph, b);
             } else {
               f32x2 gg[1];
               gg[0] = half_of(ds[t], h);
@@ -531,7 +546,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
                 f32x2 a[D], ee[D];
 #pragma unroll
                 for (int lm = 0; lm < D; ++lm) ee[lm] = *(const f32x2 *)(en + 16 * t + 2 * h + lm * U);
-                tp_bwd_half<L, true, U, 0>(ee, tph, gg, a);
+                tp_g<L, 1, true, U>(gg, ee, tph, a);
 #pragma unroll
                 for (int lm = 0; lm < D; ++lm) acc_put2(V[lm][t], h, a[lm]);
               }
@@ -542,7 +557,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
 #pragma unroll
                 for (int lm = D - 1; lm >= 1; --lm) vin[lm] = vin[l_of_lm(lm)] * Y[lm];
               }
-              tp_bwd_half<L, true, U, 1>(vin, tph, gg, b);
+              tp_g<L, 2, true, U>(gg, vin, tph, b);
             }
             {
               float *const stw = STW();
@@ -553,7 +568,9 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
           }
           if (t == HT - 1) load_rows<L * HT>(SB, RL + S::O_OM + HT, omall, V16());
           __syncthreads();
+          #ifndef ABL_NOREDUCE
           reduce_stage_p(lds.stage[0], aoffp, lds.denv, na, A.cenv, t, uwave);
+#endif
           __builtin_amdgcn_sched_barrier(0);
           __syncthreads();
         }
@@ -813,7 +830,7 @@ static void fusedlx2_prepare(Model &m) {
   for (int k = 0; k < NL; ++k) {
     const HostTensor &tp = h.get("l" + std::to_string(k + 1) + ".tp");
     for (int p = 0; p < S::NP; ++p)
-      for (int u = 0; u < U; ++u) w.push_back(p < tp.shape[0] ? (float)tp.data[(size_t)p * U + u] : 0.f);
+      for (int u = 0; u < U; ++u) w.push_back(p < tp.shape[0] ? (float)(tp.data[(size_t)p * U + u] * ahip_cg_l2_cbase[p]) : 0.f);   // x the path's base |c| (tp_g)
   }
   for (int k = 0; k < NL; ++k) {
     const HostTensor &res = h.get("l" + std::to_string(k + 1) + ".res");

@@ -198,6 +198,50 @@ __device__ __forceinline__ void tp_bwd_half(const f32x2 (&o)[(L + 1) * (L + 1)],
   }
 }
 
+// ---------------------------------------------------------------------------- tensor product, grouped tables (cg_tables.h: AhipCgG)
+// O[out] = sum over the table of  pw'[path] * sign * scale * A[a] * B[b],  pw' = path weight x the path's most frequent |c| (folded by the
+// host, ahip_cg_l?_cbase).  The A rows of a path are scaled by pw' once; an entry with that |c| is then ONE fma into O[out], the other
+// entries are summed per (path, out, |c|) group and enter with one more fma: 47 + 137 + 27 packed operations per table pass for l_max = 2
+// instead of 2 x 137 + 47.  VAR 0: forward (A = edge tensor rows i1, B = environment rows i2, O = output rows i3);
+// VAR 1: gradient w.r.t. the edge tensor (A = output gradient i3, B = environment i2, O over i1); VAR 2: per-edge environment gradient
+// (A = output gradient i3, B = edge tensor i1, O over i2).  SCALAR: only the paths with l3 = 0 (last layer).
+template <int L, int VAR> struct CgG;
+template <> struct CgG<1, 0> { static constexpr const AhipCgG *tab = ahip_cg_l1_f; };
+template <> struct CgG<1, 1> { static constexpr const AhipCgG *tab = ahip_cg_l1_b0; };
+template <> struct CgG<1, 2> { static constexpr const AhipCgG *tab = ahip_cg_l1_b1; };
+template <> struct CgG<2, 0> { static constexpr const AhipCgG *tab = ahip_cg_l2_f; };
+template <> struct CgG<2, 1> { static constexpr const AhipCgG *tab = ahip_cg_l2_b0; };
+template <> struct CgG<2, 2> { static constexpr const AhipCgG *tab = ahip_cg_l2_b1; };
+template <int L, int VAR, bool SCALAR, int U, int NA, int NB, int NO>
+__device__ __forceinline__ void tp_g(const f32x2 (&A)[NA], const f32x2 (&B)[NB], const float *tp, f32x2 (&O)[NO]) {
+  constexpr int N = CgX<L>::N;
+#pragma unroll
+  for (int k = 0; k < NO; ++k) O[k] = f32x2{0.f, 0.f};
+  f32x2 sa[2 * L + 1];
+  f32x2 s = f32x2{0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    constexpr const AhipCgG *tab = CgG<L, VAR>::tab;
+    const int l3 = VAR == 0 ? l_of_lm(tab[q].out) : l_of_lm(tab[q].a);
+    if (!(SCALAR && l3 != 0)) {
+      const int la = l_of_lm(tab[q].a), ba = la * la;
+      if (q == 0 || tab[q - 1].path != tab[q].path) {
+        const f32x2 pwp = *(const f32x2 *)(tp + tab[q].path * U);
+#pragma unroll
+        for (int k = 0; k < 2 * L + 1; ++k)
+          if (k < 2 * la + 1) sa[k] = pwp * A[ba + k];
+      }
+      const f32x2 av = tab[q].sign > 0 ? sa[tab[q].a - ba] : -sa[tab[q].a - ba];
+      if (tab[q].kind == 0) O[tab[q].out] = O[tab[q].out] + av * B[tab[q].b];
+      else {
+        if (tab[q].kind & 2) s = av * B[tab[q].b]; else s = s + av * B[tab[q].b];
+        if (tab[q].kind & 4) O[tab[q].out] = O[tab[q].out] + (float)tab[q].scale * s;
+      }
+      if (q == N - 1 || tab[q + 1].path != tab[q].path) __builtin_amdgcn_sched_barrier(0);       // one path at a time: bounds the live products
+    }
+  }
+}
+
 // The edge tensor lives in the ACCUMULATOR half of the unified register file (AGPRs): its 144 registers then do not compete
 // with the arithmetic VGPRs in the register allocator.  A value is parked with v_accvgpr_write (inline asm: there is no
 // builtin); reads are plain uses, the compiler inserts v_accvgpr_read.  No MFMA reads a parked value within the next
@@ -226,8 +270,13 @@ __device__ __forceinline__ f32x2 half_of(const f32x4 &v, int h) { return h == 0 
 __device__ __forceinline__ void set_half(f32x4 &v, int h, const f32x2 &x) { if (h == 0) { v[0] = x[0]; v[1] = x[1]; } else { v[2] = x[0]; v[3] = x[1]; } }
 // 8-byte half of a saved row image (row = [lane][4 floats])
 __device__ __forceinline__ f32x2 bload_half(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+#ifdef ABL_NOROWS
+  const float q = __builtin_bit_cast(float, (voff + soff) | 0x3f000000);
+  return f32x2{q, q};
+#else
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
   return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AHIP_ROW_AUX));
+#endif
 }
 
 // Pins a running per-edge sum where it is computed.  The sums over channels (dE/dY, the cutoff and distance derivatives, the edge energy) are

@@ -171,6 +171,7 @@ __device__ __forceinline__ void linear_b(__amdgpu_buffer_rsrc_t W, int &wp, cons
       a[i] = ring[(RP + 6 * s + i) % RINGB];
       ring[(RP + 6 * s + i) % RINGB] = __builtin_bit_cast(u32x4, bload(W, v16, (wp + (6 * s + i + RINGB) * 256) * 4));
     }
+    if (ks == 0 && p > 0 && Epi::STORES) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // the previous pair's accumulator stores have completed (see linear_s)
     // 12 MFMAs, the two accumulators alternate; smallest terms first
 #pragma unroll
     for (int m = 0; m < 6; ++m) {
@@ -244,9 +245,14 @@ enum { PH_GEOM = 0, PH_TB, PH_EMB, PH_ENV, PH_TP, PH_MIX, PH_LAT, PH_OUT, PH_BLA
 template <bool B3> struct RingT {
   f32x4 f[B3 ? 1 : RING];
   u32x4 b[B3 ? RINGB : 1];
+  bool pend = false;           // the last linear ended with stores of its accumulators that have not been waited for (see linear_s)
 };
 template <bool B3, int KT, int NT, bool ACC, int RPI, class Epi>
 __device__ __forceinline__ void lin(__amdgpu_buffer_rsrc_t W, int &wp, const f32x4 (&in)[KT], f32x4 (&out)[NT], int v16, RingT<B3> &ring, Epi epi) {
+  // accumulator stores of the previous linear's last tile pair complete before this linear's MFMAs are issued (linear_s); nothing younger
+  // than those stores is in flight here, hence vmcnt(0)
+  if (AHIP_LIN_WAIT_MODE != 0 && ring.pend) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ring.pend = Epi::STORES;
   if constexpr (B3) {
     static_assert(KT % 2 == 0, "K-steps are pairs of 16-feature tiles");
     Bop b[KT / 2], unused[NT / 2];
@@ -254,7 +260,7 @@ __device__ __forceinline__ void lin(__amdgpu_buffer_rsrc_t W, int &wp, const f32
     for (int ks = 0; ks < KT / 2; ++ks) b[ks] = split_pair(in[2 * ks], in[2 * ks + 1]);
     linear_b<KT / 2, NT, ACC, false, 6 * RPI>(W, wp, b, out, unused, v16, ring.b, epi);
   } else {
-    linear_s<KT, NT, ACC, 4 * RPI>(W, wp, in, out, v16, ring.f, epi);
+    linear_s<KT, NT, ACC, 4 * RPI, Epi, false>(W, wp, in, out, v16, ring.f, epi);
   }
 }
 

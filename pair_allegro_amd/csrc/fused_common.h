@@ -32,6 +32,8 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 #ifndef AHIP_ROW_AUX
 #define AHIP_ROW_AUX 0
 #endif
+// keeps a wave-uniform value in a scalar register and opaque to the optimiser at this point (no code motion / constant folding through it)
+__device__ __forceinline__ void pin_s(int &v) { asm volatile("" : "+s"(v)); }
 #ifdef ABL_NOROWS   // timing experiment only (results are wrong): no saved-row traffic
 __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t, int voff, int soff) { const float q = __builtin_bit_cast(float, (voff + soff) | 0x3f000000); return f32x4{q, q, q, q}; }
 __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t, int, int, f32x4 v) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); }
@@ -73,6 +75,7 @@ __device__ __forceinline__ void cutoff_poly(int p, float x, float &f, float &df)
   df = -a * p * xp1 + b * (p + 1) * xp - c * (p + 2) * xp * x;
 }
 
+
 // ---- streamed linear: running weight-fragment ring + epilogue under the next tile pair's MFMAs ----
 // The sequence of linears of a tile is static and the host lays the fragments out in consumption order, so
 // fragment n of the stream always sits at wp + n*256 floats and the 8-deep ring never drains: each step
@@ -82,11 +85,13 @@ __device__ __forceinline__ void cutoff_poly(int p, float x, float &f, float &df)
 // (4 each), which alternate ring phase RP = 0, 4.  The element-wise epilogue of pair p-1 (SiLU, save,
 // scaling, SiLU') is executed one register at a time between the MFMAs of pair p.
 struct EpiNone {
+  static constexpr bool STORES = false;      // tile_done() stores MFMA result registers (see linear_s)
   __device__ __forceinline__ void tile_done(int, const f32x4 &) const {}
   __device__ __forceinline__ float apply(int, int, float v) const { return v; }
   __device__ __forceinline__ void flush(int) const {}
 };
 struct EpiSave {             // raw rows to scratch, value unchanged
+  static constexpr bool STORES = true;
   __amdgpu_buffer_rsrc_t S; int row0, v16;
   __device__ __forceinline__ void tile_done(int ot, const f32x4 &acc) const { bstore(S, v16, (row0 + ot) * ROW * 4, acc); }
   __device__ __forceinline__ float apply(int, int, float v) const { return v; }
@@ -102,6 +107,7 @@ struct EpiSavePark : EpiSave {  // raw rows to scratch (for the backward pass) a
 // out = silu(z); the rows saved for the backward pass hold silu'(z) = s + silu (1 - s) (two extra VALU ops here, no
 // exp/rcp and no z there): they are written when all 8 registers of a tile pair have gone through apply()
 struct EpiSiluSaveD {
+  static constexpr bool STORES = false;      // its rows are VALU results, stored from flush()
   __amdgpu_buffer_rsrc_t S; int row0, v16;
   f32x4 d[2];
   __device__ __forceinline__ void tile_done(int, const f32x4 &) const {}
@@ -120,6 +126,7 @@ struct EpiSaveScale : EpiSave {  // raw rows to scratch, out = c * v
   __device__ __forceinline__ float apply(int, int, float v) const { return c * v; }
 };
 template <int NT> struct EpiMulRows {        // out = v * d (d = the saved silu' rows)
+  static constexpr bool STORES = false;
   const f32x4 (&d)[NT];
   __device__ __forceinline__ void tile_done(int, const f32x4 &) const {}
   __device__ __forceinline__ float apply(int ot, int r, float v) const { return v * d[ot][r]; }
@@ -130,12 +137,17 @@ template <int NT> struct EpiResidual : EpiSave {   // raw u rows to scratch, out
   __device__ __forceinline__ float apply(int ot, int r, float v) const { return ra * xold[ot][r] + rbf * v; }
 };
 
-template <int KT, int NT, bool ACC, int RP, class Epi>
+template <int KT, int NT, bool ACC, int RP, class Epi, bool FIRSTWAIT = true>
 __device__ __forceinline__ void linear_s(__amdgpu_buffer_rsrc_t W, int &wp, const f32x4 (&in)[KT], f32x4 (&out)[NT], int v16,
                                          f32x4 (&ring)[RING], Epi epi) {
   static_assert(NT % 2 == 0, "output tiles are processed in pairs");
   constexpr int NP = NT / 2, NSTEP = NP * KT, NS = 2 * NSTEP;
   f32x4 acc0, acc1, prev0, prev1;
+  // byte offset of the next fragment pair to request: ONE running scalar, advanced step by step.  Written as wp + constant, the
+  // optimiser forms every offset of the whole tile (~700 of them) at the top of the tile loop, spills them to VGPR lanes and reads
+  // each one back with v_readlane + hazard nops where it is used (1 450 lane operations per wave-tile in fused_lx2.hip).
+  int wo = (wp + RING * 256) * 4;
+  pin_s(wo);
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
     const int p = s / KT, kt = s % KT;
@@ -144,8 +156,25 @@ __device__ __forceinline__ void linear_s(__amdgpu_buffer_rsrc_t W, int &wp, cons
       else { acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
     const f32x4 a0 = ring[(RP + 2 * s) % RING], a1 = ring[(RP + 2 * s + 1) % RING];
-    ring[(RP + 2 * s) % RING] = bload_w(W, v16, (wp + (2 * s + RING) * 256) * 4);
-    ring[(RP + 2 * s + 1) % RING] = bload_w(W, v16, (wp + (2 * s + RING + 1) * 256) * 4);
+    ring[(RP + 2 * s) % RING] = bload_w(W, v16, wo);
+    ring[(RP + 2 * s + 1) % RING] = bload_w(W, v16 + 1024, wo);           // + 1 KiB: the instruction's immediate offset
+    wo += 2048;
+    pin_s(wo);
+    // Where an output-tile pair begins, everything older than the two requests above must have completed -- in particular the stores
+    // of the PREVIOUS pair's accumulators (Epi::tile_done: saved rows), issued straight from the MFMA result registers.  Without this
+    // wait the one-layer instance of fused_lx2 produced wrong forces in ~1 % of its tiles, different tiles on every launch, mostly in
+    // the first tiles of a launch (cold L2: the vector-memory queue backs up): the rows read back in the backward pass did not hold
+    // what the forward pass had in its registers.  Holding the stores' scalar offsets live, more wait states before or after them, and a
+    // vmcnt(0) at the forward/backward boundary did NOT cure it; completing the stores before the next pair's MFMAs are issued does
+    // (44 / 44 launches).  The wait also bounds the ring: the fragments requested up to three steps ago must have arrived here, which
+    // they have at L2 latency (41k-atom water box: 26.4 -> 26.7 ms).
+#ifndef AHIP_LIN_WAIT_MODE
+#define AHIP_LIN_WAIT_MODE 2
+#endif
+    // mode 2: at the first step of every linear (the previous linear may have ended with such stores; FIRSTWAIT = false: the caller keeps
+    // track of that itself, fused.hip) and, inside a linear, only where its epilogue stores accumulators (Epi::STORES); mode 1: at every
+    // pair; mode 0: never (A/B timing only -- unsafe)
+    if (kt == 0 && (AHIP_LIN_WAIT_MODE == 1 || (AHIP_LIN_WAIT_MODE == 2 && ((p == 0 && FIRSTWAIT) || (p > 0 && Epi::STORES))))) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -176,11 +205,14 @@ __device__ __forceinline__ void linear_s(__amdgpu_buffer_rsrc_t W, int &wp, cons
     __builtin_amdgcn_sched_barrier(0);
   }
   wp += NS * 256;
+  pin_s(wp);
 }
 // first RING fragments of the stream at wp into the ring
 __device__ __forceinline__ void ring_prime(__amdgpu_buffer_rsrc_t W, int wp, int v16, f32x4 (&ring)[RING]) {
+  int wo = wp * 4;
+  pin_s(wo);
 #pragma unroll
-  for (int j = 0; j < RING; ++j) ring[j] = bload_w(W, v16, (wp + j * 256) * 4);
+  for (int j = 0; j < RING; ++j) ring[j] = bload_w(W, v16 + (j & 3) * 1024, wo + (j >> 2) * 4096);
 }
 
 __device__ __forceinline__ float gsum(float v) {       // sum over the 4 lanes (groups) that share one edge

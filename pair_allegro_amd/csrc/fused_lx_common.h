@@ -298,6 +298,7 @@ __device__ __forceinline__ int fresh_lane() {
 
 // Saves only the first NMAX output tiles of a linear (the rest is zero padding of a ring-aligned fragment block)
 template <int NMAX> struct EpiSaveN {
+  static constexpr bool STORES = true;
   __amdgpu_buffer_rsrc_t S; int row0, v16;
   __device__ __forceinline__ void tile_done(int ot, const f32x4 &acc) const { if (ot < NMAX) bstore(S, v16, (row0 + ot) * ROW * 4, acc); }
   __device__ __forceinline__ float apply(int, int, float v) const { return v; }

@@ -87,6 +87,16 @@ def workload(config: int, ncell: int = 0):
     raise SystemExit(f"bench.py: unknown --config {config} (2, 3, 4 or 5)")
 
 
+def kernel_source_hash() -> str:
+    """sha256[:16] over the kernel sources: stored with every profiles/traffic.json entry, compared here."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "pair_allegro_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "pair_allegro_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` typed as is (no launcher): start N fresh rank processes BEFORE anything touches the GPU
     (never re-exec a process that has initialised HIP) and relay their exit status; rank 0 prints the JSON line."""
@@ -173,6 +183,7 @@ def main():
         torch.cuda.synchronize()
 
     stage_ms = {}
+    nrebuild0 = sim.nrebuild
     barrier()
     t0 = time.perf_counter()
     edges_step = []
@@ -191,6 +202,14 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     th = sim.thermo(wl["masses"])
+    rebuilds_timed = sim.nrebuild - nrebuild0
+    # cost of one re-neighboring (migration, borders, cell list + neighbor table), measured outside the timed region: the metric counts
+    # amortised rebuilds; a short timed window may contain none
+    barrier()
+    tr0 = time.perf_counter()
+    sim.rebuild()
+    barrier()
+    rebuild_ms = 1e3 * (time.perf_counter() - tr0)
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
@@ -206,12 +225,13 @@ def main():
         stage_avg = {k: float(np.mean(v)) for k, v in stage_ms.items()}
         dom = max((k for k in stage_avg if k.startswith("model")), key=lambda k: stage_avg[k], default=None)
         roof = None
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_hash = None, None, None
         tj = os.path.join(ROOT, "profiles", "traffic.json")          # measured in separate --pmc passes (cannot be collected live)
         if os.path.exists(tj) and world == 1:
             ent = json.load(open(tj)).get(f"config{args.config}:{used_path}:{natoms}")
             if ent:
                 traffic, traffic_src = ent["traffic_bytes_per_launch"], ent["source"]
+                traffic_hash = ent.get("kernel_hash")
         if dom is not None:
             ach = flops_per_edge * edges_rank0 / (stage_avg[dom] * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": 157.3, "unit": "TFLOP/s",
@@ -221,6 +241,9 @@ def main():
                     "frac_executed": round(ach / 157.3 * executed_flops_per_edge / flops_per_edge, 4),
                     "two_body": "table" if tb_tab else "mlp"}
             if traffic:
+                # the byte counts come from committed --pmc passes: flag them when the kernel sources changed since
+                roof["traffic_kernel_hash"] = traffic_hash
+                roof["traffic_stale"] = traffic_hash != kernel_source_hash()
                 # north-star wording: ">= 40 % of the HBM roofline on the neighbor-gather + tensor-product kernels": the model kernel's
                 # measured HBM bytes (committed --pmc passes) over its HIP-event time of this run, next to the MFMA figure above
                 hb = traffic / (stage_avg[dom] * 1e-3) / 1e9
@@ -251,6 +274,9 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE config {args.config}: {wl['name']}, r_max {cfg['r_max']} A + skin 1.0 A, NVE dt=1 fs",
                        "grid": "x".join(map(str, grid)), "kernel_path": used_path, "rebuilds": sim.nrebuild,
+                       "rebuilds_in_timed_steps": rebuilds_timed, "rebuild_ms": round(rebuild_ms, 3),
+                       "steps_per_rebuild": (round(args.steps / rebuilds_timed, 1) if rebuilds_timed else None),
+                       "rebuild_share_of_step_at_1_per_50": round(rebuild_ms / 50.0 / ms_per_step, 5),
                        "comm": "overlapped" if sim.overlap else "serial",
                        "stage_ms_rank0": {k: round(v, 3) for k, v in stage_avg.items()},
                        "pe_per_atom": th["pe"] / natoms},
@@ -306,37 +332,80 @@ def cpu_baseline_and_parity(lib, config, device_index, ncell, path):
         # sequence (oracle/cpu_baseline.cpp: jit::load + freeze + preprocess -> forward(Dict) -> scatter), 3 warm-up + >= 10 timed
         pth = os.path.join(tmpdir, "model.nequip.pth")
         allegro_torch.export_nequip_pth(pth, cfg, weights)
+        import subprocess
+
+        def write_sys(r):
+            sysf = os.path.join(tmpdir, f"sys_{r.nlocal}.bin")
+            with open(sysf, "wb") as fh:
+                np.array([r.nlocal, r.nghost, len(names), int(r.offsets[-1])], dtype=np.int32).tofile(fh)
+                r.x.astype(np.float64).tofile(fh); r.type.astype(np.int32).tofile(fh); r.tag.astype(np.int32).tofile(fh)
+                r.numneigh.astype(np.int32).tofile(fh); r.flat.astype(np.int32).tofile(fh)
+            return sysf
+
+        def run(sysf, threads, warm, reps, budget, bind=None):
+            env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+            if bind:
+                env["OMP_PROC_BIND"] = bind
+            pr = subprocess.run([harness, sysf, pth, "--warmup", str(warm), "--reps", str(reps), "--budget", str(budget), "--threads", str(threads)]
+                                + list(names), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            if pr.returncode != 0:
+                return None
+            d = json.loads(pr.stdout.decode().strip().splitlines()[-1])
+            d["bind"] = bind or "unset"
+            return d
+
+        # Thread count: all host cores oversubscribe this model (r02: 128 threads = 500 ms for 64 atoms, 8 threads = 30 ms), so the count is
+        # swept {8, 16, 32, 64, 128} (capped at the host's cores) on a small sample of the same workload, then OMP_PROC_BIND close / spread
+        # at the best count; the benchmarked sample is then timed with the winner: 3 warm-up + 10 timed evaluations when one takes
+        # under 2 s, else 1 + 3 inside a ~25 s budget.
+        ncores = os.cpu_count() or 8
+        counts = [t for t in (8, 16, 32, 64, 128) if t <= ncores] or [ncores]
+        if config in (2, 4):
+            c_s, p_s, t_s = lmp_like.diamond_si(5)                       # 1 000-atom Si for the sweep
+            sweep_rs, sweep_label = lmp_like.build_rank_system(c_s, p_s, t_s, cfg["r_max"] + 1.0), "1000-atom bulk Si"
+        else:
+            sweep_rs, sweep_label = rs, wl["name"]
+        sweep_sys = write_sys(sweep_rs)
+        sweep = []
+        heavy_sweep = cfg["l_max"] >= 2
+        for t in counts:
+            d = run(sweep_sys, t, 1, 1 if heavy_sweep else 3, 8)
+            if d:
+                sweep.append({"threads": t, "bind": "unset", "ms_model": d["ms_model"]})
+        best_t, best_bind = (min(sweep, key=lambda r: r["ms_model"])["threads"], None) if sweep else (min(8, ncores), None)
+        if sweep and not heavy_sweep:
+            for bind in ("close", "spread"):
+                d = run(sweep_sys, best_t, 1, 3, 8, bind)
+                if d:
+                    sweep.append({"threads": best_t, "bind": bind, "ms_model": d["ms_model"]})
+            w = min(sweep, key=lambda r: r["ms_model"])
+            best_t, best_bind = w["threads"], (None if w["bind"] == "unset" else w["bind"])
         runs = []
         samples = [(wl["name"], rs)]
         if config in (2, 4):                                          # SURVEY 8d sizes: 64 and 10 648 atoms
             c64, p64, t64 = lmp_like.diamond_si(2)
             samples.insert(0, ("64-atom bulk Si (config 1)", lmp_like.build_rank_system(c64, p64, t64, cfg["r_max"] + 1.0)))
         for label, r in samples:
-            sysf = os.path.join(tmpdir, f"sys_{r.nlocal}.bin")
-            with open(sysf, "wb") as fh:
-                np.array([r.nlocal, r.nghost, len(names), int(r.offsets[-1])], dtype=np.int32).tofile(fh)
-                r.x.astype(np.float64).tofile(fh); r.type.astype(np.int32).tofile(fh); r.tag.astype(np.int32).tofile(fh)
-                r.numneigh.astype(np.int32).tofile(fh); r.flat.astype(np.int32).tofile(fh)
-            import subprocess
-            # 3 warm-up + >= 10 timed where that fits ~25 s; a sample whose single evaluation takes tens of seconds
-            # (model L on CPU: ~20 ms per atom) gets 1 warm-up + 3 timed
-            heavy = cfg["l_max"] >= 2 or r.nlocal > 4000
-            pr = subprocess.run([harness, sysf, pth, "--warmup", "1" if heavy else "3", "--reps", "3" if heavy else "10", "--budget", "25"] + list(names),
-                                stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-            if pr.returncode == 0:
-                d = json.loads(pr.stdout.decode().strip().splitlines()[-1])
+            sysf = write_sys(r)
+            probe = run(sysf, best_t, 1, 1, 1, best_bind)             # one evaluation to choose the protocol
+            fast = probe is not None and probe["ms_model"] < 2000.0
+            d = run(sysf, best_t, 3 if fast else 1, 10 if fast else 3, 25, best_bind)
+            if d:
                 d["sample"] = label
                 runs.append(d)
         if runs:
             main_run = runs[-1]
             cpu = {"value": round(main_run["nlocal"] / (main_run["ms_model"] * 1e-3), 1), "unit": "atom-steps/s", "cores": main_run["threads"],
-                   "kind": "port",
+                   "kind": "port", "host_cores": ncores, "omp_proc_bind": main_run["bind"],
                    "sample": f"{main_run['sample']}: libtorch C++ harness (oracle/cpu_baseline.cpp, the reference's load / freeze / "
                              f"preprocess / forward(Dict) / scatter sequence) on the oracle's TorchScript export, float32 model, "
+                             f"{main_run['threads']} intra-op threads (best of the sweep), "
                              f"{main_run['warmup']} warm-up + {main_run['reps']} timed evaluations, {main_run['ms_model']:.0f} ms each (model only), "
-                             f"{main_run['ms_total']:.0f} ms with preprocess + scatter",
+                             f"{main_run['ms_total']:.0f} ms with preprocess + scatter; "
+                             f"{1e3 * main_run['ms_model'] / max(main_run['nedges'], 1):.1f} us per edge",
                    "value_glue_inclusive": round(main_run["nlocal"] / (main_run["ms_total"] * 1e-3), 1),
-                   "runs": [{k: r[k] for k in ("sample", "nlocal", "nedges", "threads", "reps", "ms_model", "ms_total")} for r in runs]}
+                   "thread_sweep": {"sample": sweep_label, "runs": sweep},
+                   "runs": [{k: r[k] for k in ("sample", "nlocal", "nedges", "threads", "bind", "warmup", "reps", "ms_model", "ms_total")} for r in runs]}
     if cpu is None:
         inp = glue.preprocess(rs.x, rs.type, rs.nlocal, rs.ilist, rs.numneigh, rs.firstneigh, mapper, cm)
         tin = {k: torch.from_numpy(v) for k, v in inp.items()}

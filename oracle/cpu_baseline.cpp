@@ -46,9 +46,9 @@ template <typename T> static std::vector<T> rd(FILE *f, size_t n) {
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main(int argc, char **argv) {
-  if (argc < 4) { fprintf(stderr, "usage: cpu_baseline system.bin model.nequip.pth [--out f.bin] [--warmup 3] [--reps 10] [--budget 20] names...\n"); return 2; }
+  if (argc < 4) { fprintf(stderr, "usage: cpu_baseline system.bin model.nequip.pth [--out f.bin] [--warmup 3] [--reps 10] [--budget 20] [--threads N] names...\n"); return 2; }
   std::string sysf = argv[1], model_path = argv[2], outf;
-  int warmup = 3, min_reps = 10;
+  int warmup = 3, min_reps = 10, threads = 0;
   double budget = 20.0;
   std::vector<std::string> names;
   for (int k = 3; k < argc; ++k) {
@@ -57,8 +57,12 @@ int main(int argc, char **argv) {
     else if (a == "--warmup" && k + 1 < argc) warmup = atoi(argv[++k]);
     else if (a == "--reps" && k + 1 < argc) min_reps = atoi(argv[++k]);
     else if (a == "--budget" && k + 1 < argc) budget = atof(argv[++k]);
+    else if (a == "--threads" && k + 1 < argc) threads = atoi(argv[++k]);
     else names.push_back(a);
   }
+  // intra-op threads: the host's full core count oversubscribes this model badly (128 threads: 500 ms for 64 atoms, 8 threads: 30 ms),
+  // so bench.py sweeps the count and reports the best (the reference leaves it to OMP_NUM_THREADS, README.md:142-146)
+  if (threads > 0) at::set_num_threads(threads);
   FILE *f = fopen(sysf.c_str(), "rb");
   int hdr[4];
   if (!f || fread(hdr, sizeof(int), 4, f) != 4) { fprintf(stderr, "cannot read %s\n", sysf.c_str()); return 3; }

@@ -513,6 +513,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) eps += silu1(zr[t][r]) * wo1[t][r];
     eps = gsum(eps);
+    asm volatile("" : "+v"(eps));            // computed here, not sunk to its use at the end of the tile (keeps the read-out rows alive until then)
 
     // =========================== backward ===========================
     const float deps = valid ? lds.scale[ti] * A.cenv : 0.f;

@@ -203,6 +203,47 @@ int ahip_reneighbor_flag_dev(ahip_model *m, int n, const double *x_dev, const do
 int ahip_nve_dev(ahip_model *m, int mode, int n, double *x_dev, double *v_dev, const double *f_dev,
                  const int *mtype_dev, const double *mass_by_mtype, double dt, double ftm2v, void *stream);
 
+/* ---- ghost exchange of a spatially decomposed system (csrc/comm.hip) ---------------------------
+ * Replaces what the reference gets from LAMMPS: ghost positions through Comm::forward_comm before compute(), and the forces the
+ * model puts on ghost atoms (pair_nequip_allegro.cpp:370-377 adds to all nlocal + nghost rows) returned to their owners by the
+ * reverse communication of `newton_pair on` (pair_nequip_allegro.cpp:149 requests it, :366-368 relies on it).
+ * HIP pack / unpack kernels + RCCL ncclSend / ncclRecv groups on the caller's stream (one group per dimension, both directions);
+ * librccl.so is opened at the first RCCL call.  The hosted transport moves the same packed buffers through a host callback
+ * (CPU tests through the emulation build; several ranks sharing one GPU). */
+typedef struct ahip_comm ahip_comm;
+typedef struct ahip_xfer_op {
+  int kind;          /* 0 = send, 1 = receive, 2 = in-place all-reduce float64 sum, 3 = in-place all-reduce int32 max */
+  int peer;          /* rank (send / receive) */
+  void *ptr;         /* the buffer as the library sees it (a device pointer on the GPU) */
+  long long bytes;
+} ahip_xfer_op;
+/* performs all ops of one group (they may only complete together: post the receives before waiting for the sends); 0 = success */
+typedef int (*ahip_xfer_fn)(void *user, int nops, const ahip_xfer_op *ops);
+
+/* 128-byte RCCL unique id (ncclGetUniqueId): rank 0 creates it, the host program hands it to every rank */
+int ahip_comm_unique_id(unsigned char id[128]);
+int ahip_comm_create_rccl(int rank, int nranks, const unsigned char id[128], int device, ahip_comm **out);
+int ahip_comm_create_hosted(int rank, int nranks, ahip_xfer_fn fn, void *user, ahip_comm **out);
+void ahip_comm_free(ahip_comm *c);
+
+/* Exchange plan, set after every re-neighboring (LAMMPS Comm::borders): nswaps directed swaps, two per dimension in the order
+ * (dim 0: -,+), (dim 1: -,+), (dim 2: -,+).  Swap s sends rows send_idx_dev[s][0..nsend[s]) of x, shifted by shift[s] along dim[s],
+ * to sendrank[s] and receives nrecv[s] rows from recvrank[s] into rows [first_recv[s], first_recv[s] + nrecv[s]) of x.  Later swaps
+ * may send rows received by earlier dimensions.  The index arrays stay owned by the caller and must live until the next plan. */
+int ahip_comm_set_plan(ahip_comm *c, int nswaps, const int *dim, const int *sendrank, const int *recvrank, const double *shift,
+                       const int *nsend, const int *nrecv, const int *first_recv, const long long *const *send_idx_dev);
+/* One rank: ghost g (row nlocal + g) is the image of local row src_dev[g] displaced by shift_dev[g][3]. */
+int ahip_comm_set_plan_local(ahip_comm *c, int nlocal, int nghost, const long long *src_dev, const double *shift_dev);
+/* x_dev [nall][3]: ghost rows refreshed from their owners (forward);  f_dev [nall][3]: ghost rows added to their owners (reverse). */
+int ahip_comm_forward(ahip_comm *c, double *x_dev, void *stream);
+int ahip_comm_reverse(ahip_comm *c, double *f_dev, void *stream);
+/* in-place all-reduce over the ranks: kind 0 = float64 sum, 1 = int32 max (thermo sums, the re-neighboring flag) */
+int ahip_comm_allreduce(ahip_comm *c, void *buf_dev, int count, int kind, void *stream);
+/* ring send / receive + both all-reduces with known values through every transport entry point; AHIP_ERR_STATE on a wrong value */
+int ahip_comm_selftest(ahip_comm *c, int n, void *stream);
+/* hipMemsetAsync(ptr, 0, bytes) on the stream (the driver zeroes its force array with it) */
+int ahip_fill_zero_dev(void *ptr_dev, long long bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,7 +24,16 @@ SYMBOLS = [
     "ahip_compute", "ahip_compute_dev", "ahip_output_register", "ahip_output_get", "ahip_get_edges", "ahip_debug_dump_edges", "ahip_get_timings",
     "ahip_compute_dev_range", "ahip_last_list_size", "ahip_neigh_update_dev_table", "ahip_map_types_dev", "ahip_reneighbor_flag_dev",
     "ahip_last_path", "ahip_last_max_degree", "ahip_debug_fused_linear", "ahip_debug_fused_edges", "ahip_build_neighbors_dev", "ahip_nve_dev",
+    "ahip_comm_unique_id", "ahip_comm_create_rccl", "ahip_comm_create_hosted", "ahip_comm_free", "ahip_comm_set_plan", "ahip_comm_set_plan_local",
+    "ahip_comm_forward", "ahip_comm_reverse", "ahip_comm_allreduce", "ahip_comm_selftest", "ahip_fill_zero_dev",
 ]
+
+
+class XferOp(C.Structure):
+    _fields_ = [("kind", C.c_int), ("peer", C.c_int), ("ptr", C.c_void_p), ("bytes", C.c_longlong)]
+
+
+XFER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(XferOp))
 
 
 class AhipError(RuntimeError):
@@ -89,6 +98,19 @@ class Library:
                                    C.POINTER(C.c_double), C.c_double, C.c_double, C.c_void_p]
 
         L.ahip_debug_fused_linear.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.ahip_comm_unique_id.argtypes = [C.c_char_p]
+        L.ahip_comm_create_rccl.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.ahip_comm_create_hosted.argtypes = [C.c_int, C.c_int, XFER_FN, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.ahip_comm_free.argtypes = [C.c_void_p]
+        L.ahip_comm_free.restype = None
+        L.ahip_comm_set_plan.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                         C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+        L.ahip_comm_set_plan_local.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.ahip_comm_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ahip_comm_reverse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ahip_comm_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.ahip_comm_selftest.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.ahip_fill_zero_dev.argtypes = [C.c_void_p, C.c_longlong, C.c_void_p]
 
     def debug_fused_linear(self, W: np.ndarray, x: np.ndarray) -> np.ndarray:
         W = np.ascontiguousarray(W, dtype=np.float64)
@@ -281,3 +303,75 @@ class Model:
         out = np.zeros(n.value, dtype=np.float64)
         self.L.check(self.L.lib.ahip_output_get(self.h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_double)), n.value, C.byref(n)))
         return out
+
+
+class Comm:
+    """Owning handle of an ahip_comm: the ghost exchange of a decomposed system (csrc/comm.hip).  Transports: "rccl" (unique id from
+    rank 0, handed over by the caller) or "hosted" (a Python callable moves the packed buffers: CPU tests, ranks sharing one GPU)."""
+
+    def __init__(self, lib: Library, rank: int, nranks: int, rccl_id: Optional[bytes] = None, device: int = 0, xfer=None):
+        self.L = lib
+        self.rank, self.nranks = rank, nranks
+        self.h = C.c_void_p()
+        self._keep = []
+        self._cb = None
+        if rccl_id is not None:
+            assert len(rccl_id) == 128
+            self.L.check(self.L.lib.ahip_comm_create_rccl(rank, nranks, rccl_id, device, C.byref(self.h)))
+            self.transport = "rccl"
+        else:
+            if xfer is not None:
+                def _cb(user, nops, ops):
+                    try:
+                        xfer([(ops[k].kind, ops[k].peer, ops[k].ptr, ops[k].bytes) for k in range(nops)])
+                        return 0
+                    except Exception as e:          # never let an exception cross the C boundary
+                        import traceback
+                        traceback.print_exc()
+                        return 1
+                self._cb = XFER_FN(_cb)
+            else:
+                self._cb = C.cast(None, XFER_FN)
+            self.L.check(self.L.lib.ahip_comm_create_hosted(rank, nranks, self._cb, None, C.byref(self.h)))
+            self.transport = "hosted"
+
+    @staticmethod
+    def unique_id(lib: Library) -> bytes:
+        buf = C.create_string_buffer(128)
+        lib.check(lib.lib.ahip_comm_unique_id(buf))
+        return buf.raw
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lib.ahip_comm_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_plan(self, dims, sendranks, recvranks, shifts, nsend, nrecv, first_recv, idx_ptrs) -> None:
+        n = len(dims)
+        ai = lambda v: np.ascontiguousarray(v, dtype=np.int32)
+        a = [ai(dims), ai(sendranks), ai(recvranks), np.ascontiguousarray(shifts, dtype=np.float64), ai(nsend), ai(nrecv), ai(first_recv)]
+        ptrs = (C.c_void_p * max(n, 1))(*[int(p) for p in idx_ptrs])
+        self._keep = a + [ptrs]
+        self.L.check(self.L.lib.ahip_comm_set_plan(self.h, n, _p(a[0], C.c_int), _p(a[1], C.c_int), _p(a[2], C.c_int), _p(a[3], C.c_double),
+                                                   _p(a[4], C.c_int), _p(a[5], C.c_int), _p(a[6], C.c_int), ptrs))
+
+    def set_plan_local(self, nlocal: int, nghost: int, src_ptr: int, shift_ptr: int) -> None:
+        self.L.check(self.L.lib.ahip_comm_set_plan_local(self.h, nlocal, nghost, src_ptr or None, shift_ptr or None))
+
+    def forward(self, x_ptr: int, stream: int = 0) -> None:
+        self.L.check(self.L.lib.ahip_comm_forward(self.h, x_ptr, stream or None))
+
+    def reverse(self, f_ptr: int, stream: int = 0) -> None:
+        self.L.check(self.L.lib.ahip_comm_reverse(self.h, f_ptr, stream or None))
+
+    def allreduce(self, ptr: int, count: int, kind: int, stream: int = 0) -> None:
+        self.L.check(self.L.lib.ahip_comm_allreduce(self.h, ptr, count, kind, stream or None))
+
+    def selftest(self, n: int = 1024, stream: int = 0) -> None:
+        self.L.check(self.L.lib.ahip_comm_selftest(self.h, n, stream or None))

@@ -23,6 +23,7 @@ struct ahip_model : public ahip::Model {};
 static thread_local std::string g_err;
 
 const char *ahip_last_error(void) { return g_err.c_str(); }
+namespace ahip { void set_error(const std::string &s) { g_err = s; } }          // comm.hip
 
 template <typename F> static int guarded(F &&fn) {
   try {

@@ -1,0 +1,366 @@
+// Ghost exchange of the spatial decomposition, inside the library: HIP pack / unpack kernels + RCCL point-to-point groups over xGMI.
+//
+// What it replaces: the reference leaves the halo to LAMMPS -- ghost positions arrive through Comm::forward_comm before
+// PairNequIPAllegro::compute runs, and the forces the model puts on ghost atoms (pair_nequip_allegro.cpp:370-377 adds to ALL
+// nlocal + nghost rows) go home through the reverse communication LAMMPS performs for newton_pair on (:149, :366-368).  A stand-alone
+// driver (md.py, bench.py) has to do both itself; rounds 1-2 did it with torch.distributed P2P ops and torch indexing kernels.
+//
+// Plan (set once per re-neighboring, from the `borders` step): an ordered list of directed swaps, two per dimension
+// (LAMMPS' swap list): swap s sends the rows send_idx[s][0..nsend) of x -- shifted by the periodic image vector when the slab crosses
+// the box -- to `sendrank` and receives nrecv rows from `recvrank` into the CONTIGUOUS rows [first_recv, first_recv + nrecv) of x.
+//   forward:  per dimension  k_pack (both swaps) -> one ncclGroup {send, recv, send, recv} -> ghosts land in x directly;
+//             later dimensions forward what earlier ones received (corner / edge ghosts).
+//   reverse:  dimensions in reverse order; the ghost rows of f go back as they lie (contiguous), the received rows are added to
+//             f[send_idx] by k_unpack_add.
+//   a swap with sendrank == recvrank == me (one rank along that dimension) is a local gather / scatter-add, no transport.
+//   one rank in total: every ghost is an image of a local atom -- set_plan_local resolves the chains once, forward is one gather and
+//   reverse one scatter-add.
+// Transports: RCCL (ncclSend / ncclRecv on the caller's stream; librccl.so is opened on first use, so the library itself loads
+// without it) or a host callback (the CPU tests run the same kernels through the host-emulation build and move the bytes with gloo).
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/allegro_hip.h"
+#include "engine.h"
+
+namespace ahip {
+
+void set_error(const std::string &s);      // allegro_hip.hip
+
+// ---------------------------------------------------------------------------- kernels
+// buf[k] = x[idx[k]] (+ shift on coordinate dim)
+static __global__ void k_comm_pack(int n, const long long *idx, const double *x, int dim, double shift, double *buf) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const long long i = idx[k];
+  double v0 = x[3 * i], v1 = x[3 * i + 1], v2 = x[3 * i + 2];
+  if (dim == 0) v0 += shift; else if (dim == 1) v1 += shift; else v2 += shift;
+  buf[3 * k] = v0; buf[3 * k + 1] = v1; buf[3 * k + 2] = v2;
+}
+// f[idx[k]] += buf[k]   (several k may name the same row: atomics)
+static __global__ void k_comm_unpack_add(int n, const long long *idx, const double *buf, double *f) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const long long i = idx[k];
+  atomicAdd(&f[3 * i], buf[3 * k]);
+  atomicAdd(&f[3 * i + 1], buf[3 * k + 1]);
+  atomicAdd(&f[3 * i + 2], buf[3 * k + 2]);
+}
+// one rank: x[nlocal + g] = x[src[g]] + shift[g]
+static __global__ void k_comm_gather_local(int nghost, int nlocal, const long long *src, const double *shift, double *x) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nghost) return;
+  const long long i = src[g];
+  x[3 * (size_t)(nlocal + g)] = x[3 * i] + shift[3 * g];
+  x[3 * (size_t)(nlocal + g) + 1] = x[3 * i + 1] + shift[3 * g + 1];
+  x[3 * (size_t)(nlocal + g) + 2] = x[3 * i + 2] + shift[3 * g + 2];
+}
+static __global__ void k_comm_scatter_local(int nghost, int nlocal, const long long *src, double *f) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nghost) return;
+  const long long i = src[g];
+  atomicAdd(&f[3 * i], f[3 * (size_t)(nlocal + g)]);
+  atomicAdd(&f[3 * i + 1], f[3 * (size_t)(nlocal + g) + 1]);
+  atomicAdd(&f[3 * i + 2], f[3 * (size_t)(nlocal + g) + 2]);
+}
+
+// ---------------------------------------------------------------------------- RCCL, opened at run time
+struct NcclUniqueId { char internal[128]; };
+struct Rccl {
+  void *h = nullptr;
+  int (*GetUniqueId)(NcclUniqueId *) = nullptr;
+  int (*CommInitRank)(void **, int, NcclUniqueId, int) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  bool load(std::string *why) {
+    if (h) return true;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) { if (why) *why = std::string("cannot open librccl.so: ") + dlerror(); return false; }
+    auto sym = [&](const char *n) { void *p = dlsym(h, n); if (!p && why) *why = std::string("librccl.so lacks ") + n; return p; };
+    GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
+    CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
+    CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+    GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+    GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+    Send = (decltype(Send))sym("ncclSend");
+    Recv = (decltype(Recv))sym("ncclRecv");
+    AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
+    GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+    return GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv && AllReduce && GetErrorString;
+  }
+};
+static Rccl g_rccl;
+static constexpr int NCCL_INT32 = 2, NCCL_UINT8 = 1, NCCL_FLOAT64 = 8, NCCL_SUM = 0, NCCL_MAX = 2;
+
+struct Swap {
+  int dim, sendrank, recvrank, nsend, nrecv, first_recv;
+  double shift;
+  const long long *send_idx;      // device, owned by the caller, valid until the next set_plan
+};
+
+struct Comm {
+  int rank = 0, nranks = 1, device = 0;
+  void *nccl = nullptr;                 // ncclComm_t (RCCL transport)
+  ahip_xfer_fn host_fn = nullptr;       // hosted transport
+  void *host_user = nullptr;
+  std::vector<Swap> swaps;
+  // single-rank plan
+  int loc_nlocal = 0, loc_nghost = 0;
+  const long long *loc_src = nullptr;
+  const double *loc_shift = nullptr;
+  bool local_plan = false;
+  DevBuf sendbuf[2], recvbuf[2];        // per swap of a dimension pair
+};
+
+#define AHIP_NCCL(expr)                                                                                   \
+  do {                                                                                                    \
+    int _r = (expr);                                                                                      \
+    if (_r != 0) throw HipError(std::string(#expr) + " failed: " + g_rccl.GetErrorString(_r));            \
+  } while (0)
+
+// one group of sends / receives: RCCL on the stream, or the host callback after the stream has drained
+struct Xfer {
+  Comm &c; hipStream_t s;
+  std::vector<ahip_xfer_op> ops;
+  void send(const void *p, long long bytes, int peer) { if (bytes > 0) ops.push_back({0, peer, (void *)p, bytes}); }
+  void recv(void *p, long long bytes, int peer) { if (bytes > 0) ops.push_back({1, peer, p, bytes}); }
+  void run() {
+    if (ops.empty()) return;
+    if (c.nccl) {
+      AHIP_NCCL(g_rccl.GroupStart());
+      for (const auto &o : ops) {
+        if (o.kind == 0) AHIP_NCCL(g_rccl.Send(o.ptr, (size_t)o.bytes, NCCL_UINT8, o.peer, c.nccl, s));
+        else AHIP_NCCL(g_rccl.Recv(o.ptr, (size_t)o.bytes, NCCL_UINT8, o.peer, c.nccl, s));
+      }
+      AHIP_NCCL(g_rccl.GroupEnd());
+    } else if (c.host_fn) {
+      AHIP_CHECK(hipStreamSynchronize(s));
+      if (c.host_fn(c.host_user, (int)ops.size(), ops.data()) != 0) throw StateError("the host transfer callback failed");
+    } else throw StateError("communicator has no transport for a remote rank");
+    ops.clear();
+  }
+};
+
+static void comm_forward(Comm &c, double *x, hipStream_t s) {
+  if (c.local_plan) {
+    if (c.loc_nghost > 0)
+      hipLaunchKernelGGL(k_comm_gather_local, dim3((c.loc_nghost + 255) / 256), dim3(256), 0, s, c.loc_nghost, c.loc_nlocal, c.loc_src, c.loc_shift, x);
+    return;
+  }
+  for (size_t k = 0; k < c.swaps.size(); k += 2) {
+    Xfer X{c, s, {}};
+    const size_t kend = std::min(k + 2, c.swaps.size());
+    for (size_t q = k; q < kend; ++q) {
+      const Swap &sw = c.swaps[q];
+      const bool self = sw.sendrank == c.rank && sw.recvrank == c.rank;
+      double *dst;
+      if (self) dst = x + 3 * (size_t)sw.first_recv;                       // local image copy: straight into the ghost rows
+      else { c.sendbuf[q - k].reserve((size_t)std::max(sw.nsend, 1) * 24); dst = c.sendbuf[q - k].as<double>(); }
+      if (sw.nsend > 0)
+        hipLaunchKernelGGL(k_comm_pack, dim3((sw.nsend + 255) / 256), dim3(256), 0, s, sw.nsend, sw.send_idx, x, sw.dim, sw.shift, dst);
+      if (!self) {
+        X.send(dst, (long long)sw.nsend * 24, sw.sendrank);
+        X.recv(x + 3 * (size_t)sw.first_recv, (long long)sw.nrecv * 24, sw.recvrank);
+      }
+    }
+    X.run();
+  }
+}
+
+static void comm_reverse(Comm &c, double *f, hipStream_t s) {
+  if (c.local_plan) {
+    if (c.loc_nghost > 0)
+      hipLaunchKernelGGL(k_comm_scatter_local, dim3((c.loc_nghost + 255) / 256), dim3(256), 0, s, c.loc_nghost, c.loc_nlocal, c.loc_src, f);
+    return;
+  }
+  const int n = (int)c.swaps.size();
+  for (int k = (n - 1) & ~1; k >= 0; k -= 2) {
+    Xfer X{c, s, {}};
+    const int kend = std::min(k + 2, n);
+    for (int q = k; q < kend; ++q) {
+      const Swap &sw = c.swaps[q];
+      if (sw.sendrank == c.rank && sw.recvrank == c.rank) continue;
+      // data flows back: the ghost rows I received from recvrank return to it; the rows I sent to sendrank come back from it
+      c.recvbuf[q - k].reserve((size_t)std::max(sw.nsend, 1) * 24);
+      X.send(f + 3 * (size_t)sw.first_recv, (long long)sw.nrecv * 24, sw.recvrank);
+      X.recv(c.recvbuf[q - k].as<double>(), (long long)sw.nsend * 24, sw.sendrank);
+    }
+    X.run();
+    for (int q = k; q < kend; ++q) {
+      const Swap &sw = c.swaps[q];
+      if (sw.nsend == 0) continue;
+      const bool self = sw.sendrank == c.rank && sw.recvrank == c.rank;
+      const double *src = self ? f + 3 * (size_t)sw.first_recv : c.recvbuf[q - k].as<double>();   // self: nrecv == nsend, ghost rows are not targets
+      hipLaunchKernelGGL(k_comm_unpack_add, dim3((sw.nsend + 255) / 256), dim3(256), 0, s, sw.nsend, sw.send_idx, src, f);
+    }
+  }
+}
+
+}  // namespace ahip
+
+using namespace ahip;
+
+#define COMM_TRY try {
+#define COMM_CATCH                                                                      \
+  }                                                                                     \
+  catch (const ArgError &e) { set_error(e.what()); return AHIP_ERR_ARG; }               \
+  catch (const StateError &e) { set_error(e.what()); return AHIP_ERR_STATE; }           \
+  catch (const UnsupportedError &e) { set_error(e.what()); return AHIP_ERR_UNSUPPORTED; } \
+  catch (const std::exception &e) { set_error(e.what()); return AHIP_ERR_DEVICE; }      \
+  return AHIP_OK;
+
+extern "C" int ahip_comm_unique_id(unsigned char id[128]) {
+  COMM_TRY
+  std::string why;
+  if (!g_rccl.load(&why)) throw UnsupportedError(why);
+  NcclUniqueId u;
+  AHIP_NCCL(g_rccl.GetUniqueId(&u));
+  std::memcpy(id, u.internal, 128);
+  COMM_CATCH
+}
+
+extern "C" int ahip_comm_create_rccl(int rank, int nranks, const unsigned char id[128], int device, ahip_comm **out) {
+  COMM_TRY
+  if (!out || !id || nranks < 1 || rank < 0 || rank >= nranks) throw ArgError("ahip_comm_create_rccl: bad arguments");
+  std::string why;
+  if (!g_rccl.load(&why)) throw UnsupportedError(why);
+  AHIP_CHECK(hipSetDevice(device));
+  Comm *c = new Comm();
+  c->rank = rank; c->nranks = nranks; c->device = device;
+  NcclUniqueId u;
+  std::memcpy(u.internal, id, 128);
+  int r = g_rccl.CommInitRank(&c->nccl, nranks, u, rank);
+  if (r != 0) { delete c; throw HipError(std::string("ncclCommInitRank failed: ") + g_rccl.GetErrorString(r)); }
+  *out = (ahip_comm *)c;
+  COMM_CATCH
+}
+
+extern "C" int ahip_comm_create_hosted(int rank, int nranks, ahip_xfer_fn fn, void *user, ahip_comm **out) {
+  COMM_TRY
+  if (!out || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !fn)) throw ArgError("ahip_comm_create_hosted: bad arguments");
+  Comm *c = new Comm();
+  c->rank = rank; c->nranks = nranks; c->host_fn = fn; c->host_user = user;
+  *out = (ahip_comm *)c;
+  COMM_CATCH
+}
+
+extern "C" void ahip_comm_free(ahip_comm *h) {
+  Comm *c = (Comm *)h;
+  if (!c) return;
+  if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
+  for (DevBuf *b : {&c->sendbuf[0], &c->sendbuf[1], &c->recvbuf[0], &c->recvbuf[1]}) b->release();
+  delete c;
+}
+
+extern "C" int ahip_comm_set_plan(ahip_comm *h, int nswaps, const int *dim, const int *sendrank, const int *recvrank, const double *shift,
+                                  const int *nsend, const int *nrecv, const int *first_recv, const long long *const *send_idx_dev) {
+  COMM_TRY
+  Comm *c = (Comm *)h;
+  if (!c || nswaps < 0 || (nswaps & 1)) throw ArgError("ahip_comm_set_plan: swaps come in pairs (two directions per dimension)");
+  c->swaps.clear();
+  c->local_plan = false;
+  for (int k = 0; k < nswaps; ++k) {
+    if (dim[k] < 0 || dim[k] > 2 || sendrank[k] < 0 || sendrank[k] >= c->nranks || recvrank[k] < 0 || recvrank[k] >= c->nranks || nsend[k] < 0 || nrecv[k] < 0)
+      throw ArgError("ahip_comm_set_plan: swap " + std::to_string(k) + " is malformed");
+    if (sendrank[k] == c->rank && recvrank[k] == c->rank && nsend[k] != nrecv[k]) throw ArgError("ahip_comm_set_plan: a self-swap receives what it sends");
+    c->swaps.push_back(Swap{dim[k], sendrank[k], recvrank[k], nsend[k], nrecv[k], first_recv[k], shift[k], send_idx_dev[k]});
+  }
+  COMM_CATCH
+}
+
+extern "C" int ahip_comm_set_plan_local(ahip_comm *h, int nlocal, int nghost, const long long *src_dev, const double *shift_dev) {
+  COMM_TRY
+  Comm *c = (Comm *)h;
+  if (!c || nlocal < 0 || nghost < 0 || (nghost > 0 && (!src_dev || !shift_dev))) throw ArgError("ahip_comm_set_plan_local: bad arguments");
+  c->swaps.clear();
+  c->local_plan = true;
+  c->loc_nlocal = nlocal; c->loc_nghost = nghost; c->loc_src = src_dev; c->loc_shift = shift_dev;
+  COMM_CATCH
+}
+
+extern "C" int ahip_comm_forward(ahip_comm *h, double *x_dev, void *stream) {
+  COMM_TRY
+  if (!h || !x_dev) throw ArgError("ahip_comm_forward: null argument");
+  comm_forward(*(Comm *)h, x_dev, (hipStream_t)stream);
+  AHIP_CHECK(hipGetLastError());
+  COMM_CATCH
+}
+
+extern "C" int ahip_comm_reverse(ahip_comm *h, double *f_dev, void *stream) {
+  COMM_TRY
+  if (!h || !f_dev) throw ArgError("ahip_comm_reverse: null argument");
+  comm_reverse(*(Comm *)h, f_dev, (hipStream_t)stream);
+  AHIP_CHECK(hipGetLastError());
+  COMM_CATCH
+}
+
+extern "C" int ahip_comm_allreduce(ahip_comm *h, void *buf_dev, int count, int kind, void *stream) {
+  COMM_TRY
+  Comm *c = (Comm *)h;
+  if (!c || !buf_dev || count < 0 || (kind != 0 && kind != 1)) throw ArgError("ahip_comm_allreduce: kind 0 = float64 sum, 1 = int32 max");
+  if (c->nranks == 1 || count == 0) return AHIP_OK;
+  if (c->nccl) AHIP_NCCL(g_rccl.AllReduce(buf_dev, buf_dev, (size_t)count, kind == 0 ? NCCL_FLOAT64 : NCCL_INT32, kind == 0 ? NCCL_SUM : NCCL_MAX, c->nccl, (hipStream_t)stream));
+  else if (c->host_fn) {
+    // hosted transport: all-reduce through the callback (kind encoded as 2 + kind, peer = -1, in place)
+    AHIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    ahip_xfer_op op{2 + kind, -1, buf_dev, (long long)count * (kind == 0 ? 8 : 4)};
+    if (c->host_fn(c->host_user, 1, &op) != 0) throw StateError("the host transfer callback failed");
+  } else throw StateError("communicator has no transport");
+  COMM_CATCH
+}
+
+// Exercises every RCCL entry point the exchange uses on THIS communicator: a grouped send + receive with the next / previous rank on the
+// ring (with one rank: to itself) and the two all-reduces; returns AHIP_ERR_STATE when a value comes back wrong.
+extern "C" int ahip_comm_selftest(ahip_comm *h, int n, void *stream) {
+  COMM_TRY
+  Comm *c = (Comm *)h;
+  if (!c || n < 1) throw ArgError("ahip_comm_selftest: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<double> a(n), b(n, -1.0);
+  for (int i = 0; i < n; ++i) a[i] = 1000.0 * c->rank + i;
+  DevBuf da, db, dr;
+  da.reserve((size_t)n * 8); db.reserve((size_t)n * 8); dr.reserve(64);
+  AHIP_CHECK(hipMemcpyAsync(da.p, a.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+  AHIP_CHECK(hipMemcpyAsync(db.p, b.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+  const int next = (c->rank + 1) % c->nranks, prev = (c->rank + c->nranks - 1) % c->nranks;
+  Xfer X{*c, s, {}};
+  X.send(da.p, (long long)n * 8, next);
+  X.recv(db.p, (long long)n * 8, prev);
+  X.run();
+  double red[2] = {1.0 + c->rank, 0.5};
+  int imax = 7 + c->rank;
+  AHIP_CHECK(hipMemcpyAsync(dr.p, red, 16, hipMemcpyHostToDevice, s));
+  AHIP_CHECK(hipMemcpyAsync((char *)dr.p + 32, &imax, 4, hipMemcpyHostToDevice, s));
+  if (ahip_comm_allreduce(h, dr.p, 2, 0, s) != 0 || ahip_comm_allreduce(h, (char *)dr.p + 32, 1, 1, s) != 0) return AHIP_ERR_DEVICE;
+  AHIP_CHECK(hipMemcpyAsync(b.data(), db.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  AHIP_CHECK(hipMemcpyAsync(red, dr.p, 16, hipMemcpyDeviceToHost, s));
+  AHIP_CHECK(hipMemcpyAsync(&imax, (char *)dr.p + 32, 4, hipMemcpyDeviceToHost, s));
+  AHIP_CHECK(hipStreamSynchronize(s));
+  da.release(); db.release(); dr.release();
+  bool ok = true;
+  for (int i = 0; i < n; ++i) ok = ok && b[i] == 1000.0 * prev + i;
+  const double nr = c->nranks;
+  ok = ok && red[0] == nr * (nr + 1) / 2 && red[1] == 0.5 * nr && imax == 7 + c->nranks - 1;
+  if (!ok) throw StateError("ahip_comm_selftest: a value came back wrong");
+  COMM_CATCH
+}
+
+extern "C" int ahip_fill_zero_dev(void *ptr_dev, long long bytes, void *stream) {
+  COMM_TRY
+  if (bytes < 0 || (bytes > 0 && !ptr_dev)) throw ArgError("ahip_fill_zero_dev: bad arguments");
+  if (bytes > 0) AHIP_CHECK(hipMemsetAsync(ptr_dev, 0, (size_t)bytes, (hipStream_t)stream));
+  COMM_CATCH
+}

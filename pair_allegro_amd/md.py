@@ -82,6 +82,9 @@ class HipBackend:
     def nve(self, mode: int, n: int, x, v, f, mtype, dt: float) -> None:
         self.model.nve_dev(mode, n, x.data_ptr(), v.data_ptr(), f.data_ptr(), mtype.data_ptr(), self.mass, dt, FTM2V)
 
+    def fill_zero(self, t: torch.Tensor, stream: int = 0) -> None:
+        self.model.L.check(self.model.L.lib.ahip_fill_zero_dev(t.data_ptr(), t.numel() * t.element_size(), stream or None))
+
     def reneighbor_flag(self, n: int, x, x_hold, v, dt: float, half_skin: float, flag) -> None:
         """flag[0] = max displacement since the last build + 2 dt max|v| > half_skin (ahip_reneighbor_flag_dev)."""
         self.model.reneighbor_flag_dev(n, x.data_ptr(), x_hold.data_ptr() if n else 0, v.data_ptr(), dt, half_skin, flag.data_ptr())
@@ -164,7 +167,75 @@ class Simulation:
         self.x_hold = None
         self._ghost_src = self._ghost_shift = None
         self._flag_posted = False
+        self.comm = self._make_comm()
         self.rebuild()
+
+    # ---- the library's ghost exchange (csrc/comm.hip) -----------------------------------------------
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else 0
+
+    def _tensor_at(self, ptr: int, nbytes: int, dtype=torch.uint8) -> torch.Tensor:
+        """A tensor over raw memory the library handed to the hosted transfer callback (host memory in the CPU emulation, device
+        memory on the GPU)."""
+        esz = torch.empty((), dtype=dtype).element_size()
+        if self.dev.type == "cuda":
+            class _Mem:
+                pass
+            m = _Mem()
+            m.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+            t = torch.as_tensor(m, device=self.dev)
+        else:
+            import ctypes
+            t = torch.frombuffer((ctypes.c_char * nbytes).from_address(int(ptr)), dtype=torch.uint8)
+        return t.view(dtype) if esz != 1 else t
+
+    def _hosted_xfer(self, ops) -> None:
+        """Moves one group of packed buffers with the process group handed to the constructor (gloo on CPU tensors; HostStagedDist
+        for ranks that share one GPU)."""
+        d = self.dist
+        p2p = []
+        for kind, peer, ptr, nbytes in ops:
+            if kind == 0:
+                p2p.append(d.P2POp(d.isend, self._tensor_at(ptr, nbytes), peer))
+            elif kind == 1:
+                p2p.append(d.P2POp(d.irecv, self._tensor_at(ptr, nbytes), peer))
+            elif kind == 2:
+                d.all_reduce(self._tensor_at(ptr, nbytes, torch.float64))
+            else:
+                d.all_reduce(self._tensor_at(ptr, nbytes, torch.int32), op=d.ReduceOp.MAX)
+        if p2p:
+            for w in d.batch_isend_irecv(p2p):
+                w.wait()
+
+    def _make_comm(self):
+        """The exchange runs inside the library when the backend is the library (HipBackend): RCCL when the process group is RCCL
+        ("nccl"), the hosted transport otherwise.  Other backends (none today) keep the torch implementation below."""
+        model = getattr(self.backend, "model", None)
+        if model is None or not hasattr(model.L.lib, "ahip_comm_forward"):
+            return None
+        from . import capi
+        if self.nranks == 1:
+            return capi.Comm(model.L, 0, 1)
+        is_rccl = self.dev.type == "cuda" and hasattr(self.dist, "get_backend") and self.dist.get_backend() == "nccl"
+        if is_rccl:
+            idt = torch.zeros(128, dtype=torch.uint8, device=self.dev)
+            if self.rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(capi.Comm.unique_id(model.L)), dtype=torch.uint8))
+            self.dist.broadcast(idt, src=0)
+            return capi.Comm(model.L, self.rank, self.nranks, rccl_id=bytes(idt.cpu().numpy().tobytes()), device=self.dev.index or 0)
+        return capi.Comm(model.L, self.rank, self.nranks, xfer=self._hosted_xfer)
+
+    def _set_comm_plan(self) -> None:
+        if self.comm is None:
+            return
+        if self._ghost_src is not None or self.nall == self.nlocal:
+            ng = self.nall - self.nlocal
+            self.comm.set_plan_local(self.nlocal, ng, self._ghost_src.data_ptr() if ng else 0, self._ghost_shift.data_ptr() if ng else 0)
+            return
+        sw = self.swaps
+        self.comm.set_plan([s.dim for s in sw], [s.sendrank for s in sw], [s.recvrank for s in sw], [s.shift for s in sw],
+                           [s.nsend for s in sw], [s.nrecv for s in sw], [s.first_recv for s in sw],
+                           [s.send_idx.data_ptr() if s.nsend else 0 for s in sw])
 
     # ---- rank helpers ---------------------------------------------------------------------------
     def _rank_of(self, c) -> int:
@@ -317,6 +388,7 @@ class Simulation:
         if self.overlap:
             self._order_interior_first()
         self._borders()
+        self._set_comm_plan()
         self.f = torch.zeros((self.nall, 3), dtype=torch.float64, device=self.dev)
         lo = self.lo - self.rc - 1e-6
         hi = self.hi + self.rc + 1e-6
@@ -327,6 +399,9 @@ class Simulation:
 
     # ---- per-step communication -------------------------------------------------------------------
     def forward_comm(self) -> None:
+        if self.comm is not None:                                  # HIP pack kernels + RCCL groups inside the library
+            self.comm.forward(self.x.data_ptr(), self._stream())
+            return
         if self._ghost_src is not None:                            # one rank: all ghosts are images of local atoms
             self.x[self.nlocal:] = self.x[self._ghost_src] + self._ghost_shift
             return
@@ -342,6 +417,9 @@ class Simulation:
                 self.x[sw.first_recv: sw.first_recv + sw.nrecv] = rx
 
     def reverse_comm(self) -> None:
+        if self.comm is not None:
+            self.comm.reverse(self.f.data_ptr(), self._stream())
+            return
         if self._ghost_src is not None:
             self.f[: self.nlocal].index_add_(0, self._ghost_src, self.f[self.nlocal:])      # sources are local rows: disjoint from the ghost rows read
             return
@@ -374,7 +452,10 @@ class Simulation:
                 reach = torch.zeros((), dtype=torch.float64, device=self.dev)
             flag = (reach > 0.5 * self.skin).to(torch.int32).reshape(1)
         if self.nranks > 1:
-            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+            if self.comm is not None:
+                self.comm.allreduce(flag.data_ptr(), 1, 1, self._stream())
+            else:
+                self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
         if self.dev.type == "cuda":
             if self._flag_host is None:
                 self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
@@ -400,7 +481,10 @@ class Simulation:
     # ---- force evaluation and time step -----------------------------------------------------------
     def compute_forces(self, comm_first: bool = True) -> None:
         """forward comm -> forces of all centres -> reverse comm.  Overlapped schedule: see __init__."""
-        self.f.zero_()
+        if hasattr(self.backend, "fill_zero"):
+            self.backend.fill_zero(self.f, self._stream())
+        else:
+            self.f.zero_()
         if not self.overlap:
             if comm_first:
                 self.forward_comm()

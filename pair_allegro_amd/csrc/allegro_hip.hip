@@ -23,7 +23,10 @@ struct ahip_model : public ahip::Model {};
 static thread_local std::string g_err;
 
 const char *ahip_last_error(void) { return g_err.c_str(); }
-namespace ahip { void set_error(const std::string &s) { g_err = s; } }          // comm.hip
+namespace ahip {
+void set_error(const std::string &s) { g_err = s; }          // comm.hip
+std::atomic<int> g_models_alive{0};                          // edges.hip: unit schedule of the edge build
+}
 
 template <typename F> static int guarded(F &&fn) {
   try {
@@ -120,6 +123,8 @@ int ahip_model_load(const char *path, int device, ahip_model **out) {
       AHIP_CHECK(hipMemcpy(m->cg_dev, tab, (size_t)m->ncg_full * sizeof(AhipCgEntry), hipMemcpyHostToDevice));
     } catch (...) { ahip_model_free(m); throw; }
     *out = m;
+    m->counted = true;
+    g_models_alive.fetch_add(1);
   });
 }
 
@@ -142,6 +147,7 @@ void ahip_model_free(ahip_model *m) {
                     &m->b_ws, &m->b_misc, &m->hv_eoff, &m->hv_eii, &m->hv_ej, &m->hv_rvec, &m->hv_ilist, &m->hv_engvir})
     b->release();
   for (auto &t : m->slots) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
+  if (m->counted) g_models_alive.fetch_sub(1);
   delete m;
 }
 
@@ -191,6 +197,9 @@ int ahip_set_option(ahip_model *m, const char *key, const char *value) {
       if (v != "le" && v != "lt") throw ArgError("option cutoff_compare: expected le|lt");
       m->cutoff_strict = v == "lt";
       m->h_cutsq_dev.clear();
+    } else if (k == "edge_schedule") {
+      if (v != "auto" && v != "static" && v != "dynamic") throw ArgError("option edge_schedule: expected auto|static|dynamic");
+      m->opt_edge_schedule = v;
     } else if (k == "timing") {
       m->timing = (v == "1" || v == "on" || v == "true");
     } else throw ArgError("unknown option '" + k + "'");

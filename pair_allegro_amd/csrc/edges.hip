@@ -14,6 +14,8 @@
 // Rows longer than 128 entries raise the overflow flag and the caller re-runs the two-pass kernels.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "engine.h"
 
 namespace ahip {
@@ -21,12 +23,10 @@ namespace ahip {
 static constexpr int EB_ATOMS = 64;      // centres per scan unit (one status word each): 8 waves x 8 centres
 static constexpr int EB_THREADS = EB_ATOMS / 8 * 64;
 static constexpr int LB_PER_LANE = 1;   // look-back window = 64 * LB_PER_LANE predecessors per poll (8: 0.93 ms instead of 0.70 -- the polls themselves load the L2)
-// The kernel is PERSISTENT: a grid of resident 8-wave workgroups (2 per CU = the 4 waves per SIMD its registers admit; 1 per CU
-// for the two-chunk instance) each takes one ticket and then handles the scan units ticket, ticket + G, ticket + 2 G, ...  One
-// ticket per unit cost 0.35 ms at 1 M atoms (a single device-scope word takes ~88 atomics per microsecond).  The look-back
-// costs (units) x (half the resident grid / 64) dependent polls in total, i.e. it shrinks with the unit size: 64 centres.  The look-back of unit u
-// waits for unit u - 1 = the previous ticket in the same round (or the last ticket of the previous round): all G workgroups are
-// resident, so every predecessor is running -- a grid larger than the residency would deadlock here.
+// The kernel is PERSISTENT: a grid of 8-wave workgroups the size of the residency (2 per CU = the 4 waves per SIMD its registers
+// admit; 1 per CU for the two-chunk instance; queried with hipOccupancyMaxActiveBlocksPerMultiprocessor) walks the 64-centre scan
+// units.  The look-back costs (units) x (half the grid / 64) dependent polls in total, i.e. it shrinks with the unit size: 64 centres.
+// Unit order: a fixed stride per workgroup, or one atomic ticket per unit where co-residency of the grid is not a given (see the kernel).
 static constexpr int EB_PER_WAVE = 8;    // centres per wave
 // EB_CHUNKS (template parameter): 64-entry chunks of a list row held in registers: 1 when no row of the installed list is longer
 // than 64 entries (half the registers: 5 instead of 3 waves per SIMD in flight for this latency-bound gather), else 2
@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256) k_pack_xt(int nall, const double *__restr
 
 __device__ __forceinline__ unsigned long long pack_state(unsigned long long state, unsigned long long v) { return (state << 62) | v; }
 
-template <int EB_CHUNKS>
+template <int EB_CHUNKS, bool DYN>
 __global__ void __launch_bounds__(EB_THREADS) k_build_edges(int inum, const int *__restrict__ ilist, const int *__restrict__ nl_off,
                                                        const int *__restrict__ nl_j, const AtomXT *__restrict__ xt,
                                                        const double *__restrict__ cutsq, int nft, int nunits,
@@ -57,12 +57,21 @@ __global__ void __launch_bounds__(EB_THREADS) k_build_edges(int inum, const int 
                                                        int *heavy_cnt, int *heavy_list) {
   __shared__ int s_cnt2[2][EB_ATOMS];          // counters of two consecutive units (no barrier between the stores of one and the
   __shared__ int s_base2[2][EB_ATOMS + 1];     // counting of the next)
-  __shared__ int s_blk;
+  __shared__ int s_blk, s_claim;
   __shared__ long long s_prefix2[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) s_blk = (int)atomicAdd(ticket, 1u);
+  // Two unit schedules.  DYN = false: the workgroup takes ONE ticket t and walks the units t, t + G, t + 2 G ... (G = grid size).  The
+  // look-back of a unit waits for the unit before it, i.e. for the previous ticket of the same round: safe only while all G workgroups
+  // are resident (the host sizes the grid from the occupancy query and serialises the launches of this kernel inside the process).
+  // DYN = true: units are claimed ONE AT A TIME from the ticket counter, two units ahead of their use (the claim's round trip runs
+  // under a whole unit): every unit below a claimed one has then been claimed by a workgroup that is running, so the look-back cannot
+  // wait for a workgroup that has not started -- whatever the grid size and whatever else occupies the chip (a second model on another
+  // stream, ranks sharing the GPU, exchange kernels).  It costs one device-scope atomic per unit on one address: +0.19 ms at 1 M atoms
+  // (0.55 -> 0.74 ms), so the host picks it only where co-residency is not a given (edges_build_f32).
+  if (tid == 0) { s_blk = (int)atomicAdd(ticket, 1u); if (DYN) s_claim = (int)atomicAdd(ticket, 1u); }
   __syncthreads();
   const int b0 = s_blk;
+  int bn = DYN ? s_claim : b0 + (int)gridDim.x;       // the unit after the current one
   const int uwave = __builtin_amdgcn_readfirstlane(wave);
   int run_max = 0;                       // largest edge count seen by this workgroup (thread 0), published once at the end
   constexpr int NB = EB_CHUNKS == 1 ? EB_PER_WAVE : 2;
@@ -93,9 +102,10 @@ __global__ void __launch_bounds__(EB_THREADS) k_build_edges(int inum, const int 
   };
   request_rows(b0);
   take_rows();
-  int par = 0;
-  for (int b = b0; b < nunits; b += (int)gridDim.x, par ^= 1) {
+  int par = 0, bnn = 0;
+  for (int b = b0; b < nunits; b = bn, bn = bnn, par ^= 1) {
   const int a_begin = b * EB_ATOMS;
+  if (DYN && tid == 0) s_claim = (int)atomicAdd(ticket, 1u);        // the unit after next; read behind this unit's second barrier
   int *s_cnt = s_cnt2[par], *s_base = s_base2[par];
   long long &s_prefix = s_prefix2[par];
 
@@ -168,7 +178,7 @@ __global__ void __launch_bounds__(EB_THREADS) k_build_edges(int inum, const int 
       }
     }
   }
-  request_rows(b + (int)gridDim.x);      // answered during the scan and the look-back
+  request_rows(bn);                      // answered during the scan and the look-back
   __syncthreads();
 
   // ---- block scan of the 64 counts, then decoupled look-back for the block's global offset ----------
@@ -232,6 +242,7 @@ __global__ void __launch_bounds__(EB_THREADS) k_build_edges(int inum, const int 
   }
   __syncthreads();
   const long long gbase = s_prefix;
+  bnn = DYN ? s_claim : bn + (int)gridDim.x;
 
   // ---- offsets + edges -------------------------------------------------------------------------------
   take_rows();                           // next unit's rows have arrived; its neighbour indices travel during the stores
@@ -258,7 +269,7 @@ __global__ void __launch_bounds__(EB_THREADS) k_build_edges(int inum, const int 
   if (tid == 0 && run_max > 0) atomicMax(maxdeg, run_max);
 }
 
-struct EdgeState { DevBuf flags, heavy, hoff, xt; };
+struct EdgeState { DevBuf flags, heavy, hoff, xt; int ncu = 0, occ[2] = {1, 1}; int *h_back = nullptr; };     // h_back: pinned read-back words
 
 // ---- compact copy of the edges of the listed ("heavy") centres: the edge list the layer-at-a-time kernels run on ----
 static __global__ void k_heavy_offsets(int nh, const int *heavy, const int *eoff, int *hoff) {
@@ -306,12 +317,31 @@ bool edges_build_f32(Model &m, const ComputeArgs &a) {
   StageTimer tm(m, "edge_build", a.stream);
   const int inum = m.inum;
   const int nunits = (inum + EB_ATOMS - 1) / EB_ATOMS;
-  int ncu = 256;
-  { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, m.device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
-  const bool one_chunk = m.max_list_row >= 0 && m.max_list_row <= 64;
-  const int nblocks = std::min(nunits, ncu * (one_chunk ? 2 : 1));          // resident grid, see k_build_edges
   if (!m.edge_state) m.edge_state = new EdgeState();
   EdgeState &st = *(EdgeState *)m.edge_state;
+  if (st.ncu == 0) {                      // once per model: CU count and the residency of both instances
+    hipDeviceProp_t prop;
+    st.ncu = (hipGetDeviceProperties(&prop, m.device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&st.occ[0], k_build_edges<1, false>, EB_THREADS, 0) != hipSuccess || st.occ[0] < 1) st.occ[0] = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&st.occ[1], k_build_edges<2, false>, EB_THREADS, 0) != hipSuccess || st.occ[1] < 1) st.occ[1] = 1;
+    AHIP_CHECK(hipHostMalloc((void **)&st.h_back, 8 * sizeof(int), hipHostMallocDefault));
+  }
+  const bool one_chunk = m.max_list_row >= 0 && m.max_list_row <= 64;
+  // a grid the size of the residency (more workgroups would only queue)
+  const int nblocks = std::max(1, std::min(nunits, st.ncu * st.occ[one_chunk ? 0 : 1] - m.reserve_wgs));
+  // Unit schedule (see k_build_edges): the fixed stride needs the whole grid resident.  That holds for one model evaluating alone;
+  // it is not a given when other kernels share the chip -- the overlapped multi-rank schedule (reserve_wgs > 0: exchange kernels and
+  // the persistent model kernel of the other range run beside this one), a second model in the process, other processes on the
+  // device (option edge_schedule=dynamic) -- and then units are claimed one at a time, which cannot wait on a workgroup that has not
+  // started.  Launches with the fixed stride are additionally chained by an event, so that two of them never overlap in one process.
+  const bool dyn = m.opt_edge_schedule == "dynamic" || (m.opt_edge_schedule == "auto" && (m.reserve_wgs > 0 || g_models_alive.load() > 1));
+  static hipEvent_t chain = nullptr;
+  static std::mutex chain_mu;
+  if (!dyn) {
+    std::lock_guard<std::mutex> lk(chain_mu);
+    if (!chain) AHIP_CHECK(hipEventCreateWithFlags(&chain, hipEventDisableTiming));
+    else AHIP_CHECK(hipStreamWaitEvent(a.stream, chain, 0));
+  }
   // header: [0] ticket (u32), [1] maxdeg, [2] overflow, [3] number of heavy centres; status array starts at byte 64
   const size_t bytes = 64 + (size_t)nunits * sizeof(unsigned long long);
   st.flags.reserve(bytes);
@@ -328,18 +358,24 @@ bool edges_build_f32(Model &m, const ComputeArgs &a) {
   const int nall = std::max(m.nall, 1);
   st.xt.reserve((size_t)nall * sizeof(AtomXT));
   hipLaunchKernelGGL(k_pack_xt, dim3((nall + 255) / 256), dim3(256), 0, a.stream, m.nall, a.x, a.ftype, a.mtype, (AtomXT *)st.xt.p);
-#define EB_LAUNCH(CH) hipLaunchKernelGGL(k_build_edges<CH>, dim3(nblocks), dim3(EB_THREADS), 0, a.stream, inum, m.d_ilist, m.d_nloff, m.d_nlj,       \
+#define EB_LAUNCH(CH, DY) hipLaunchKernelGGL((k_build_edges<CH, DY>), dim3(nblocks), dim3(EB_THREADS), 0, a.stream, inum, m.d_ilist, m.d_nloff, m.d_nlj,       \
                      (const AtomXT *)st.xt.p, a.cutsq, a.nft, nunits, (unsigned int *)hdr, (unsigned long long *)((char *)st.flags.p + 64),   \
                      m.b_eoff.as<int>(), m.b_eii.as<int>(), m.b_ej.as<int>(), m.b_rvec.as<float>(), hdr + 1, hdr + 2,                \
                      m.b_ett.as<unsigned char>(), m.heavy_thresh, hdr + 3, st.heavy.as<int>())
-  if (one_chunk) EB_LAUNCH(1); else EB_LAUNCH(2);
+  if (dyn) { if (one_chunk) EB_LAUNCH(1, true); else EB_LAUNCH(2, true); }
+  else {
+    if (one_chunk) EB_LAUNCH(1, false); else EB_LAUNCH(2, false);
+    std::lock_guard<std::mutex> lk(chain_mu);
+    AHIP_CHECK(hipEventRecord(chain, a.stream));
+  }
 #undef EB_LAUNCH
   AHIP_CHECK(hipGetLastError());
-  int h3[4] = {0, 0, 0, 0}, tot = 0;
-  // the scalar read-back per step (the Kokkos path has the same one: pair_nequip_allegro_kokkos.cpp:203-206)
+  // the scalar read-back per step (the Kokkos path has the same one: pair_nequip_allegro_kokkos.cpp:203-206), into pinned memory
+  int *h3 = st.h_back;
   AHIP_CHECK(hipMemcpyAsync(h3, hdr, 4 * sizeof(int), hipMemcpyDeviceToHost, a.stream));
-  AHIP_CHECK(hipMemcpyAsync(&tot, m.b_eoff.as<int>() + inum, sizeof(int), hipMemcpyDeviceToHost, a.stream));
+  AHIP_CHECK(hipMemcpyAsync(h3 + 4, m.b_eoff.as<int>() + inum, sizeof(int), hipMemcpyDeviceToHost, a.stream));
   AHIP_CHECK(hipStreamSynchronize(a.stream));
+  const int tot = h3[4];
   if (h3[2] != 0) return false;                     // a row longer than 128 entries: caller uses the two-pass kernels
   m.nedges = tot;
   m.last_max_deg = h3[1];
@@ -355,6 +391,7 @@ void edges_free(Model &m) {
   st->xt.release();
   st->heavy.release();
   st->hoff.release();
+  if (st->h_back) (void)hipHostFree(st->h_back);
   delete st;
   m.edge_state = nullptr;
 }

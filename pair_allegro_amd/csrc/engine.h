@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -74,11 +75,14 @@ template <typename T> struct DeviceWeights {
   }
 };
 
+extern std::atomic<int> g_models_alive;     // models of this process (allegro_hip.hip)
+
 struct TimingSlot { std::string name; hipEvent_t a = nullptr, b = nullptr; bool used = false; };
 
 struct Model {
   HostModel hm;
   int device = 0;
+  bool counted = false;                     // included in g_models_alive
   int D = 1, Ka = 0;
   std::vector<double> rcut_model_host;      // [T*T]
 
@@ -90,6 +94,7 @@ struct Model {
   long long chunk_edges = 2000000;
   int reserve_wgs = 0;                      // workgroup slots the persistent fused kernels leave free (for kernels of other streams)
   bool timing = false;
+  std::string opt_edge_schedule = "auto";   // auto | static | dynamic: unit schedule of the single-pass edge build (edges.hip)
   bool cutoff_strict = false;               // edge kept iff rsq < cut^2 (the KOKKOS reference path) instead of rsq <= cut^2 (the host path)
 
   // weights

@@ -96,6 +96,19 @@ __global__ void k_iota(int n, int *p) {
   if (i < n) p[i] = (int)i;
 }
 
+// The 32-bit row offsets (like the reference's int edge counters) hold at most 2^31 - 1 list entries.  A wrapped scan total need not be
+// negative, so the bound is checked in 64 bits: cheaply through n x longest row, exactly (counts summed on the host) only when that
+// bound does not settle it.
+static void check_list_total(const int *cnt_dev, int n, int maxrow, hipStream_t s) {
+  if ((long long)n * (long long)maxrow <= 2147483647LL) return;
+  std::vector<int> h((size_t)n);
+  AHIP_CHECK(hipMemcpyAsync(h.data(), cnt_dev, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+  AHIP_CHECK(hipStreamSynchronize(s));
+  long long tot = 0;
+  for (int v : h) tot += v;
+  if (tot > 2147483647LL) throw ArgError("neighbor list: more than 2^31 - 1 entries (row offsets are 32-bit, like the reference's)");
+}
+
 void neigh_build(Model &m, int nlocal, int nall, const double *x_dev, const double *lo, const double *hi,
                  double rc_list, hipStream_t s) {
   if (!m.nb_state) m.nb_state = new NbState();
@@ -139,6 +152,7 @@ void neigh_build(Model &m, int nlocal, int nall, const double *x_dev, const doub
   AHIP_CHECK(hipMemcpyAsync(&tot, st.off.as<int>() + nlocal, sizeof(int), hipMemcpyDeviceToHost, s));
   AHIP_CHECK(hipMemcpyAsync(&maxrow, st.box.as<int>(), sizeof(int), hipMemcpyDeviceToHost, s));
   AHIP_CHECK(hipStreamSynchronize(s));
+  check_list_total(st.cnt.as<int>(), nlocal, maxrow, s);
   st.nlj.reserve((size_t)std::max(tot, 1) * sizeof(int));
   if (nlocal > 0)
     hipLaunchKernelGGL(k_neigh_pass<true>, grid(nlocal), dim3(B), 0, s, nlocal, x_dev, g, st.bin_start.as<int>(), st.sorted.as<int>(), rcsq, (int *)nullptr, st.off.as<int>(), st.nlj.as<int>());
@@ -202,7 +216,7 @@ void neigh_from_table(Model &m, int inum, int nall, const int *ilist_dev, const 
   AHIP_CHECK(hipStreamSynchronize(s));
   if (hb[1] == 1) throw ArgError("neighbor list: ilist entry out of range");
   if (hb[1] == 2) throw ArgError("neighbor list: negative numneigh");
-  if (tot < 0) throw ArgError("neighbor list: more than 2^31 - 1 entries (row offsets are 32-bit, like the reference's)");
+  check_list_total(st.cnt.as<int>(), inum, hb[0], s);
   st.nlj.reserve((size_t)std::max(tot, 1) * sizeof(int));
   if (inum > 0)
     hipLaunchKernelGGL(k_table_rows, grid(inum), dim3(B), 0, s, inum, nall, st.ilist.as<int>(), st.cnt.as<int>(), st.off.as<int>(), table_dev, stride_atom,

@@ -10,6 +10,8 @@
 
 #include "pair_allegro_hip_kokkos.h"
 
+#include <type_traits>
+
 #include "allegro_hip.h"
 
 #include "atom_kokkos.h"
@@ -104,6 +106,11 @@ void PairAllegroHIPKokkos::compute(int eflag_in, int vflag_in)
     last_list_build = 1;
   }
 
+  // the C-ABI takes float64 positions and forces (the reference's inputtype / outputtype, pair_nequip_allegro.h:73-78): a KOKKOS build
+  // with single or mixed precision views must not be reinterpreted silently
+  static_assert(sizeof(typename std::remove_reference<decltype(x(0, 0))>::type) == sizeof(double) &&
+                sizeof(typename std::remove_reference<decltype(f(0, 0))>::type) == sizeof(double),
+                "pair_style allegro/kk needs KOKKOS built with double-precision X_FLOAT and F_FLOAT");
   // forces are accumulated in place into the KOKKOS force view, E_i written for the inum centre atoms (:305-319)
   if (ahip_compute_dev(model, nlocal, nghost, x.data(), d_mtype.data(), cutoff_model, f.data(), eflag_atom ? d_eatom.data() : nullptr,
                        d_engvir.data(), stream) != AHIP_OK)

@@ -49,12 +49,13 @@ DEFAULT_RULES: List[Tuple[str, str, str]] = [
     (r".*allegro\.latents\.(\d+)\._weight_(\d+)$", "l{k}.lat.w{j}", "io"),
     (r".*allegro\.linears\.(\d+)\.(?:weight|weights)$", "l{k}.mix", "mix"),
     (r".*allegro\._latent_resnet_update_params$", "__resnet__", "vec"),
+    (r".*avg_num_neighbors$", "__avg_num_neighbors__", "vec"),        # the archive's own normalisation constant (a buffer)
     (r".*(?:edge_readout|readout|edge_eng).*\._weight_(\d+)$", "out.w{j0}", "io"),
     (r".*per_type_energy_scale_shift\.scales$", "scale", "vec"),
     (r".*per_type_energy_scale_shift\.shifts$", "shift", "vec"),
 ]
 # tensors that carry no learned arithmetic of this model spec (constants the kernels regenerate, bookkeeping buffers)
-DEFAULT_IGNORE = [r".*bessel\.bessel_weights$", r".*_zero$", r".*\.cg$", r".*w3j.*", r".*_dummy.*", r".*avg_num_neighbors$", r".*\.num_batches_tracked$"]
+DEFAULT_IGNORE = [r".*bessel\.bessel_weights$", r".*_zero$", r".*\.cg$", r".*w3j.*", r".*_dummy.*", r".*\.num_batches_tracked$"]
 
 
 class ConversionError(RuntimeError):
@@ -148,17 +149,31 @@ def infer_cfg(meta: Dict[str, str], w: Dict[str, np.ndarray], avg_num_neighbors:
                per_edge_type_cutoff=(np.array([float(v) for v in pc]).reshape(T, T).tolist() if pc else None),
                num_bessels=int(B), l_max=int(L), num_layers=NL, num_scalar_features=int(S), num_tensor_features=int(U),
                mlp_depth=depth, mlp_width=int(tb0.shape[1]), readout_depth=rd, readout_width=int(w["out.w0"].shape[1]) if rd else 1,
-               avg_num_neighbors=float(avg_num_neighbors) if avg_num_neighbors else 1.0, model_dtype="float32")
+               avg_num_neighbors=float(avg_num_neighbors), model_dtype="float32")
     return cfg
 
 
 def convert(path: str, rules=None, ignore=None, avg_num_neighbors: Optional[float] = None):
     meta, sd = read_archive(path)
     w = map_state_dict(sd, rules, ignore)
-    if "__resnet__" in w:                                       # one learned coefficient per layer -> (alpha, beta) pairs, see MODEL_SPEC
-        c = 1.0 / (1.0 + np.exp(-w.pop("__resnet__")))
-        for k in range(len(c)):
-            w[f"l{k + 1}.res"] = np.array([np.sqrt(1.0 - c[k]), np.sqrt(c[k])])
+    if "__resnet__" in w:
+        # one learned parameter p per layer -> (alpha, beta) of x <- alpha x + beta u, the upstream allegro form (as recalled):
+        # s = sigmoid(p), coefficient_old = rsqrt(s^2 + 1), coefficient_new = s * coefficient_old
+        sg = 1.0 / (1.0 + np.exp(-np.atleast_1d(w.pop("__resnet__"))))
+        for k in range(len(sg)):
+            a_old = 1.0 / np.sqrt(sg[k] * sg[k] + 1.0)
+            w[f"l{k + 1}.res"] = np.array([a_old, sg[k] * a_old])
+    # environment normalisation 1/sqrt(avg_num_neighbors): the archive's own buffer, else the command line; never a silent default
+    # (a wrong constant gives wrong energies and forces with no error)
+    file_avg = w.pop("__avg_num_neighbors__", None)
+    if avg_num_neighbors is None:
+        if file_avg is None:
+            raise ConversionError("the archive carries no avg_num_neighbors buffer: pass --avg-num-neighbors (the value the model was trained with)")
+        avg_num_neighbors = float(np.ravel(file_avg)[0])
+    elif file_avg is not None and abs(float(np.ravel(file_avg)[0]) - avg_num_neighbors) > 1e-6 * abs(avg_num_neighbors):
+        raise ConversionError(f"--avg-num-neighbors {avg_num_neighbors} contradicts the archive's buffer {float(np.ravel(file_avg)[0])}")
+    if not avg_num_neighbors > 0:
+        raise ConversionError("avg_num_neighbors must be positive")
     cfg = infer_cfg(meta, w, avg_num_neighbors)
     want = dict(model_file.tensor_shapes(cfg))
     for name, shape in want.items():
@@ -201,6 +216,8 @@ def main(argv=None) -> int:
     except ConversionError as e:
         print(f"convert_nequip: {e}", file=sys.stderr)
         return 1
+    print("convert_nequip: PARITY UNPINNED -- the name rules and numerical conventions (docs/MODEL_SPEC.md) have never met a genuine "
+          "nequip-compile archive; check the result with `python -m pair_allegro_amd.tools.pin_real_model` before trusting it", file=sys.stderr)
     print(f"converted, {n} tensors mapped: l_max={cfg['l_max']} U={cfg['num_tensor_features']} S={cfg['num_scalar_features']} "
           f"layers={cfg['num_layers']} types={' '.join(cfg['type_names'])} r_max={cfg['r_max']}")
     if not a.dry_run:

@@ -13,6 +13,7 @@ from pair_allegro_amd import capi, lmp_like, md, model_file
 def run(lib, path, cell, pos, vel, cfg, grid, rank, d, nsteps, overlap):
     dev = torch.device("cuda", 0)
     model = capi.Model(path, 0, lib)
+    model.set_option("edge_schedule", "dynamic")      # several processes share this GPU: the resident-grid assumption of the static unit schedule does not hold
     sim = md.Simulation(md.HipBackend(model, [28.0855]), np.diag(cell), cfg["r_max"], 1.0, pos, np.zeros(len(pos), np.int32),
                         vel, dev, grid=grid, rank=rank, dist=d, dt=0.001, overlap=overlap)
     sim.setup()

@@ -36,7 +36,7 @@ class _Top(torch.nn.Module):
         return data
 
 
-def _nequip_style_archive(path, cfg, w, extra_tensor=False):
+def _nequip_style_archive(path, cfg, w, extra_tensor=False, with_avg=True):
     t = lambda a: torch.nn.Parameter(torch.tensor(np.asarray(a), dtype=torch.float32), requires_grad=False)
     model = _Box()
     se = _Box(); se.mlp = _Box(); se.bessel = _Box()
@@ -58,8 +58,10 @@ def _nequip_style_archive(path, cfg, w, extra_tensor=False):
         al.latents.append(b)
         if k < NL:
             b = _Box(); b.register_parameter("weight", t(w[f"l{k}.mix"])); al.linears.append(b)
-    beta2 = np.array([w[f"l{k}.res"][1] ** 2 for k in range(1, NL + 1)])
-    al.register_parameter("_latent_resnet_update_params", t(np.log(beta2 / (1.0 - beta2))))
+    sg = np.array([w[f"l{k}.res"][1] / w[f"l{k}.res"][0] for k in range(1, NL + 1)])      # upstream form: (alpha, beta) = (1, s) / sqrt(1 + s^2), s = sigmoid(p)
+    al.register_parameter("_latent_resnet_update_params", t(np.log(sg / (1.0 - sg))))
+    if with_avg:
+        al.register_buffer("avg_num_neighbors", torch.tensor(float(cfg["avg_num_neighbors"])))
     model.allegro = al
     ro = _Box()
     for k in range(cfg["readout_depth"] + 1):
@@ -77,22 +79,27 @@ def test_convert_synthetic_archive_and_load_it(emu_lib, tmp_path):
                              num_scalar_features=16, num_tensor_features=8, mlp_width=16, readout_width=8, num_layers=3, l_max=2,
                              avg_num_neighbors=37.0)
     w = {k: v.astype(np.float32).astype(np.float64) for k, v in model_file.init_weights(cfg).items()}     # what float32 storage keeps
+    for k in range(1, cfg["num_layers"] + 1):                 # residual coefficients the upstream parametrisation can express
+        sgm = 0.3 + 0.2 * k
+        w[f"l{k}.res"] = np.array([1.0, sgm]) / np.sqrt(1.0 + sgm * sgm)
     src, dst = str(tmp_path / "real.nequip.pth"), str(tmp_path / "converted.nequip.pth")
     _nequip_style_archive(src, cfg, w)
     # the library refuses the unconverted file with a message that names the converter
     from pair_allegro_amd import capi
     with pytest.raises(capi.AhipError, match="convert_nequip"):
         capi.Model(src, 0, emu_lib)
-    r = subprocess.run([sys.executable, "-m", "pair_allegro_amd.tools.convert_nequip", src, dst, "--avg-num-neighbors", "37.0"],
+    r = subprocess.run([sys.executable, "-m", "pair_allegro_amd.tools.convert_nequip", src, dst],          # avg_num_neighbors: the archive's buffer
                        cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()
+    assert b"PARITY UNPINNED" in r.stderr
     assert "converted, %d tensors mapped" % len(model_file.tensor_shapes(cfg)) in r.stdout.decode()
     cfg2, w2 = model_file.load(dst)
     for key in ("l_max", "num_layers", "num_scalar_features", "num_tensor_features", "mlp_depth", "mlp_width", "readout_width", "type_names"):
         assert cfg2[key] == cfg[key], key
     assert np.allclose(np.asarray(cfg2["per_edge_type_cutoff"]), np.asarray(cfg["per_edge_type_cutoff"]))
+    assert abs(cfg2["avg_num_neighbors"] - 37.0) < 1e-6
     for k in w:
-        np.testing.assert_allclose(w2[k], w[k], rtol=2e-7, atol=1e-9, err_msg=k)
+        np.testing.assert_allclose(w2[k], w[k], rtol=1e-6, atol=1e-7, err_msg=k)
     # the converted file evaluates like the natively exported model (float64 emulation of the same kernels)
     g = util.load_golden("Cu2AgO4_r5")
     types, names = util.lammps_types(g)
@@ -120,6 +127,24 @@ def test_unknown_tensor_stops_the_conversion(tmp_path):
     r = subprocess.run([sys.executable, "-m", "pair_allegro_amd.tools.convert_nequip", src, "--dry-run", "--map", str(rules)], cwd=ROOT,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0 and b"converted, " in r.stdout
+
+
+def test_avg_num_neighbors_is_never_guessed(tmp_path):
+    """No buffer in the archive and no flag: an error, not a silent 1.0; a flag that contradicts the buffer: an error."""
+    cfg = model_file.model_S(num_scalar_features=16, num_tensor_features=8, mlp_width=16, readout_width=8, avg_num_neighbors=21.5)
+    w = model_file.init_weights(cfg)
+    for k in range(1, cfg["num_layers"] + 1):
+        w[f"l{k}.res"] = np.array([1.0, 0.5]) / np.sqrt(1.25)
+    src = str(tmp_path / "noavg.nequip.pth")
+    _nequip_style_archive(src, cfg, w, with_avg=False)
+    with pytest.raises(convert_nequip.ConversionError, match="avg_num_neighbors"):
+        convert_nequip.convert(src)
+    cfg2, _, _ = convert_nequip.convert(src, avg_num_neighbors=21.5)
+    assert cfg2["avg_num_neighbors"] == 21.5
+    src2 = str(tmp_path / "avg.nequip.pth")
+    _nequip_style_archive(src2, cfg, w)
+    with pytest.raises(convert_nequip.ConversionError, match="contradicts"):
+        convert_nequip.convert(src2, avg_num_neighbors=30.0)
 
 
 def test_missing_tensor_is_named(tmp_path):

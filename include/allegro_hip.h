@@ -170,6 +170,12 @@ int ahip_debug_dump_edges(ahip_model *m, const int *tag);
 /* Per-stage device timings (ms) of the last compute; names is a static ';'-separated list. */
 int ahip_get_timings(ahip_model *m, const char **names, const double **ms, int *n);
 
+/* The model file's fifth metadata key, `allow_tf32` ("0" / "1").  The reference hands it to libtorch
+ * (pair_nequip_allegro.cpp:267-270: at::globalContext().setAllowTF32CuBLAS / CuDNN): 1 = the model's author permits TF32-class
+ * matrix arithmetic.  Here: with 1 (and option fused_arith=auto, the default) the fused model-S kernel runs its linears on the bf16
+ * matrix cores with a two-term split (ahip_last_path reports "fused_tf32eq"); with 0 every path is float32-exact or better. */
+int ahip_model_allow_tf32(const ahip_model *m, int *allow);
+
 /* Kernel family used by the last compute: "generic_f32" | "generic_f64" | "fused_f32" ("" before). */
 const char *ahip_last_path(ahip_model *m);
 /* Largest number of edges of any centre atom in the last compute. */

@@ -24,7 +24,7 @@ SYMBOLS = [
     "ahip_compute", "ahip_compute_dev", "ahip_output_register", "ahip_output_get", "ahip_get_edges", "ahip_debug_dump_edges", "ahip_get_timings",
     "ahip_compute_dev_range", "ahip_last_list_size", "ahip_neigh_update_dev_table", "ahip_map_types_dev", "ahip_reneighbor_flag_dev",
     "ahip_last_path", "ahip_last_max_degree", "ahip_debug_fused_linear", "ahip_debug_fused_edges", "ahip_build_neighbors_dev", "ahip_nve_dev",
-    "ahip_comm_unique_id", "ahip_comm_create_rccl", "ahip_comm_create_hosted", "ahip_comm_free", "ahip_comm_set_plan", "ahip_comm_set_plan_local",
+    "ahip_model_allow_tf32", "ahip_comm_unique_id", "ahip_comm_create_rccl", "ahip_comm_create_hosted", "ahip_comm_free", "ahip_comm_set_plan", "ahip_comm_set_plan_local",
     "ahip_comm_forward", "ahip_comm_reverse", "ahip_comm_allreduce", "ahip_comm_selftest", "ahip_fill_zero_dev",
 ]
 
@@ -71,6 +71,7 @@ class Library:
                                       C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
         L.ahip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.ahip_model_allow_tf32.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.ahip_neigh_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                         C.POINTER(C.POINTER(C.c_int)), C.c_int]
         L.ahip_neigh_update_csr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_longlong),
@@ -160,6 +161,9 @@ class Model:
         self.per_edge_type_cutoff = (np.ctypeslib.as_array(pc, shape=(nt.value, nt.value)).copy() if pc else None)
         self.l_max, self.num_tensor_features, self.num_scalar_features = lm.value, U.value, S.value
         self.num_layers, self.model_dtype = nl.value, dt.value.decode()
+        tf = C.c_int(0)
+        self.L.check(self.L.lib.ahip_model_allow_tf32(h, C.byref(tf)))
+        self.allow_tf32 = bool(tf.value)
 
     def close(self):
         if getattr(self, "h", None):

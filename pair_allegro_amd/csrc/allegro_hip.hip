@@ -151,6 +151,13 @@ void ahip_model_free(ahip_model *m) {
   delete m;
 }
 
+int ahip_model_allow_tf32(const ahip_model *m, int *allow) {
+  return guarded([&] {
+    if (!m || !allow) throw ArgError("ahip_model_allow_tf32: null argument");
+    *allow = m->hm.allow_tf32;
+  });
+}
+
 int ahip_model_meta(const ahip_model *m, double *r_max, int *num_types, const char **type_names,
                     const double **per_edge_type_cutoff, int *l_max, int *num_tensor_features,
                     int *num_scalar_features, int *num_layers, const char **model_dtype) {

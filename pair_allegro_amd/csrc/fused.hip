@@ -24,7 +24,7 @@
 //            terms, f32 accumulate; option fused_arith).
 //
 // Supported model shape (others run the generic path): l_max = 1, 32 tensor features, 64 scalars,
-// MLP 2 x 64, read-out 1 x 32, 8 Bessels, <= 3 layers, <= 4 types.  Reference graph:
+// MLP 2 x 64, read-out 1 x 32, 8 Bessels, <= 3 layers, <= 16 types.  Reference graph:
 // the TorchScript model executed at /root/reference/pair_nequip_allegro.cpp:409-430.
 #include <hip/hip_runtime.h>
 
@@ -93,8 +93,8 @@ template <int NW> struct __attribute__((aligned(16))) Lds {
   double eacc[MAXA];                      // energy accumulated over this workgroup's tiles, per centre slot (one owner thread each)
   double virw[NW][6];                     // virial accumulated per wave (owner: lanes 0..5 of the wave)
   int aoff[2][MAXA + 2];                  // slot offsets of the tile's centres, double-buffered by tile parity
-  float rc[16];                           // model cutoff table [T*T]
-  float scale[4], shift[4];               // per-type energy scale / shift
+  float rc[16];                           // model cutoff table [T*T] for T <= 4 (more types: read from A.rcut, the LDS budget of two workgroups per CU is spent)
+  float scale[16], shift[16];             // per-type energy scale / shift
   float res[MAXNL][2];                    // residual update coefficients per layer
   int chunk[2];                           // first tile of the current / next claimed chunk
 };
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
   else ring_prime(WB, wp, v16, ring.f);
   if (tid < MAXA) lds.eacc[tid] = 0.0;
   if (lane < 6) lds.virw[wave][lane] = 0.0;
-  if (tid < A.T * A.T) lds.rc[tid] = (float)A.rcut[tid];
+  if (A.T <= 4 && tid < A.T * A.T) lds.rc[tid] = (float)A.rcut[tid];
   if (tid < A.T) { lds.scale[tid] = Wb[A.o_scale + tid]; lds.shift[tid] = Wb[A.o_shift + tid]; }
   if (tid < 2 * A.NL) lds.res[tid >> 1][tid & 1] = Wb[A.o_res[tid >> 1] + (tid & 1)];
 
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     const float d = sqrtf(rx * rx + ry * ry + rz * rz);
     const float inv = 1.f / d;
     const float nx = rx * inv, ny = ry * inv, nz = rz * inv;
-    const float rc = lds.rc[ti * A.T + tj];
+    const float rc = A.T <= 4 ? lds.rc[ti * A.T + tj] : (float)A.rcut[ti * A.T + tj];
     const float xx = d / rc;
     float fc, dfc_dx;
     cutoff_poly(A.p, xx, fc, dfc_dx);
@@ -850,7 +850,7 @@ bool fused_model_supported(const Model &m, std::string *why) {
   if (h.mlp_depth != 2 || h.readout_depth != 1) return no("fused kernels need MLP depth 2 and read-out depth 1");
   if (h.num_bessels != 8) return no("fused kernels need 8 Bessel functions");
   if (h.num_layers < 1 || h.num_layers > MAXNL) return no("fused kernels need 1..3 layers");
-  if (h.num_types > 4) return no("fused kernels support at most 4 model types");
+  if (h.num_types > 16) return no("fused kernels support at most 16 model types (4-bit packed edge types)");
   return true;
 }
 

@@ -57,8 +57,8 @@ template <int L, int UT, int NW> struct __attribute__((aligned(16))) LdsX {
   double eacc[S::MAXA];
   double virw[NW][6];
   int aoff[2][S::MAXA + 2];
-  float rc[16];
-  float scale[4], shift[4];
+  float rc[256];                             // model cutoff table [T*T], T <= 16 (the edge build packs a type in 4 bits)
+  float scale[16], shift[16];
   float res[LX_MAXNL][2];
   int chunk[2];
 };
@@ -664,7 +664,7 @@ bool fusedlx_model_supported(const Model &m, std::string *why) {
   if (h.mlp_depth != 2 || h.readout_depth != 1) return no("fused kernels need MLP depth 2 and read-out depth 1");
   if (h.num_bessels != 8) return no("fused kernels need 8 Bessel functions");
   if (h.num_layers < 1 || h.num_layers > LX_MAXNL) return no("fused kernels need 1..3 layers");
-  if (h.num_types > 4) return no("fused kernels support at most 4 model types");
+  if (h.num_types > 16) return no("fused kernels support at most 16 model types (4-bit packed edge types)");
   return true;
 }
 

@@ -72,8 +72,8 @@ struct __attribute__((aligned(16))) LdsP {
   double eacc[S::MAXA];
   double virw[4][6];
   int aoff[2][S::MAXA + 2];
-  float rc[16];
-  float scale[4], shift[4];
+  float rc[256];                             // model cutoff table [T*T], T <= 16 (the edge build packs a type in 4 bits)
+  float scale[16], shift[16];
   float res[LX_MAXNL][2];
   int chunk[2];
 };

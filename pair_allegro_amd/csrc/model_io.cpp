@@ -153,6 +153,7 @@ HostModel parse_blob(const unsigned char *p, size_t n, const std::string &origin
     else if (key == "readout_depth") ls >> m.readout_depth;
     else if (key == "readout_width") ls >> m.readout_width;
     else if (key == "seed") ls >> m.seed;
+    else if (key == "allow_tf32") ls >> m.allow_tf32;
     else if (key == "version") { int v; ls >> v; if (v != 1) throw std::runtime_error(origin + ": unsupported AHIP version"); }
     // unknown keys are ignored (forward compatibility)
   }
@@ -199,7 +200,12 @@ HostModel load_model_file(const std::string &path) {
     throw std::runtime_error(path + ": " + err +
                              " -- this model file carries no allegro-hip weight section; add one with "
                              "`python -m pair_allegro_amd.tools.convert_nequip <in>.nequip.pth <out>.nequip.pth` (INTEGRATION.md section 2)");
-  return parse_blob(buf.data() + off, len, path);
+  HostModel m = parse_blob(buf.data() + off, len, path);
+  // the archive's own `extra/allow_tf32` member ("0" / "1"), the key the reference reads (pair_nequip_allegro.cpp:214-220, 267-270)
+  size_t toff = 0, tlen = 0;
+  std::string terr;
+  if (zip_find_member(buf, "extra/allow_tf32", toff, tlen, terr) && tlen >= 1) m.allow_tf32 = buf[toff] == '1' ? 1 : 0;
+  return m;
 }
 
 }  // namespace ahip

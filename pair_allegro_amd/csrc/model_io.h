@@ -21,6 +21,7 @@ struct HostModel {
   int num_types = 0, num_bessels = 0, poly_p = 0, l_max = 0, num_layers = 0;
   int S = 0, U = 0, mlp_depth = 0, mlp_width = 0, readout_depth = 0, readout_width = 0;
   double avg_num_neighbors = 1;
+  int allow_tf32 = 0;                       // the reference's fifth metadata key (pair_nequip_allegro.cpp:267-270): the model file permits TF32-class matrix arithmetic
   long long seed = 0;
   std::map<std::string, HostTensor> tensors;
 

@@ -136,6 +136,13 @@ void PairAllegroHIP::coeff(int narg, char **arg)
   const char *type_names;
   const double *pc;
   ahip_model_meta(model, &r_max, &num_model_types, &type_names, &pc, nullptr, nullptr, nullptr, nullptr, nullptr);
+  {
+    // :267-270: the reference hands the key to at::globalContext().setAllowTF32CuBLAS / CuDNN; the library selects its reduced-split
+    // matrix arithmetic from it (ahip_model_allow_tf32)
+    int allow_tf32 = 0;
+    ahip_model_allow_tf32(model, &allow_tf32);
+    if (comm->me == 0 && (allow_tf32 || debug_mode)) std::cout << "NequIP/Allegro: model metadata allow_tf32 = " << allow_tf32 << "\n";
+  }
   cutoff = r_max;    // :272
 
   type_mapper.assign(ntypes, -1);    // :274

@@ -145,6 +145,8 @@ def dumps(cfg: dict, weights: Dict[str, np.ndarray]) -> bytes:
               "readout_depth", "readout_width", "avg_num_neighbors", "seed"):
         lines.append(f"{k} {_fmt(cfg[k])}")
     lines.append(f"num_types {T}")
+    if int(cfg.get("allow_tf32", 0)):
+        lines.append("allow_tf32 1")
     lines.append("type_names " + " ".join(cfg["type_names"]))
     pc = cfg.get("per_edge_type_cutoff")
     if pc is not None:
@@ -216,7 +218,7 @@ def reference_metadata(cfg: dict) -> Dict[str, str]:
             repr(float(x)) for x in np.asarray(pc, dtype=np.float64).reshape(T * T)),
         "type_names": " ".join(cfg["type_names"]),
         "num_types": str(T),
-        "allow_tf32": "0",
+        "allow_tf32": "1" if int(cfg.get("allow_tf32", 0)) else "0",
     }
 
 

@@ -112,6 +112,11 @@ class PairAllegro:
             if e.code == capi.AHIP_ERR_FILE:
                 raise RuntimeError(e.msg) from None      # reference throws std::runtime_error (:205)
             raise LammpsError(e.msg) from None
+        # :267-270 -- the reference hands the key to at::globalContext().setAllowTF32*; here it selects the reduced-split matrix arithmetic
+        # of the fused kernel (include/allegro_hip.h: ahip_model_allow_tf32)
+        self.allow_tf32 = self.model.allow_tf32
+        if self.me == 0 and not self.quiet and (self.allow_tf32 or self.debug_mode):
+            print(f"NequIP/Allegro: model metadata allow_tf32 = {int(self.allow_tf32)}")
         self.cutoff = self.model.r_max                                                     # :272
         names = self.model.type_names
         self.type_mapper = [-1] * ntypes                                                   # :274

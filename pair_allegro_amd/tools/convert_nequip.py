@@ -217,7 +217,7 @@ def main(argv=None) -> int:
         print(f"convert_nequip: {e}", file=sys.stderr)
         return 1
     print("convert_nequip: PARITY UNPINNED -- the name rules and numerical conventions (docs/MODEL_SPEC.md) have never met a genuine "
-          "nequip-compile archive; check the result with `python -m pair_allegro_amd.tools.pin_real_model` before trusting it", file=sys.stderr)
+          "nequip-compile archive; check the result with `python tests/pin_real_model.py <model> <structure.xyz>` before trusting it", file=sys.stderr)
     print(f"converted, {n} tensors mapped: l_max={cfg['l_max']} U={cfg['num_tensor_features']} S={cfg['num_scalar_features']} "
           f"layers={cfg['num_layers']} types={' '.join(cfg['type_names'])} r_max={cfg['r_max']}")
     if not a.dry_run:

@@ -59,6 +59,31 @@ def test_fused_vs_oracle_two_types(hip_lib, model_dir, nl):
     np.testing.assert_allclose(fused["forces"], gen["forces"], atol=2e-5)
 
 
+@pytest.mark.parametrize("ntypes", [8, 16])
+def test_fused_many_species(hip_lib, model_dir, ntypes):
+    """More than four model types (the fused kernels took at most 4 until round 3; real Allegro models routinely carry more): the 256-atom
+    CuPd box relabelled into 8 and 16 species, per-edge-type cutoffs between 4.2 and 5 A, on the fused kernel against the float64 oracle
+    (64 and 256 two-body spline tables, cutoff table read from memory instead of LDS)."""
+    g = util.load_golden("CuPd-cubic-big_r5")
+    names = [f"X{k:02d}" for k in range(ntypes)]
+    rng = np.random.RandomState(ntypes)
+    symbols = [names[k] for k in rng.randint(0, ntypes, size=len(g["pos"]))]
+    for k in range(ntypes):
+        symbols[k] = names[k]                                     # every species occurs
+    pc_ = 5.0 - 0.8 * rng.rand(ntypes, ntypes)
+    pc_ = 0.5 * (pc_ + pc_.T)
+    cfg = model_file.model_S(type_names=names, per_edge_type_cutoff=pc_.tolist(), avg_num_neighbors=40.0)
+    w = model_file.init_weights(cfg)
+    path = f"{model_dir}/species{ntypes}.nequip.pth"
+    allegro_torch.export_nequip_pth(path, cfg, w)
+    types = np.array([names.index(s_) + 1 for s_ in symbols], dtype=np.int32)
+    ref = util.oracle_run(dict(cfg, model_dtype="float64"), w, g["cell"], g["pos"], types, names)
+    fused = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused"})
+    assert fused["info"]["path"] == "fused_f32"
+    util.assert_close_to(fused, ref, 5e-4, what=f"{ntypes} species, fused vs f64 oracle")
+    assert np.abs(fused["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
+
+
 def test_fused_bf16x3_arithmetic_matches_f32(hip_lib, model_dir):
     """Option fused_arith=bf16x3 (exact 3-way bf16 split, six MFMA terms, f32 accumulate) is float32-equivalent:
     same distance to the float64 oracle as the f32-input MFMA kernel."""

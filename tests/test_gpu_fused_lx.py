@@ -93,3 +93,17 @@ def test_model_L_centres_with_more_than_64_edges(hip_lib, model_dir):
     pos3 = np.concatenate([g["pos"] + s @ g["cell"] for s in shifts])
     all_heavy = util.run_pair(hip_lib, path15, cell3, pos3, np.ones(len(pos3), np.int32), ["Cu"])
     assert all_heavy["info"]["path"] == "generic_f32"
+
+
+def test_model_L_six_species(hip_lib, model_dir):
+    """Model L (l_max 2, 64 tensor features: the wave-pair kernel) with 6 model types."""
+    g = util.load_golden("CuPd-cubic-big_r5")
+    names = ["A", "B", "C", "D", "E", "F"]
+    rng = np.random.RandomState(6)
+    symbols = [names[k] for k in rng.randint(0, 6, size=len(g["pos"]))]
+    cfg = model_file.model_L(type_names=names, avg_num_neighbors=42.0)
+    path, types, lnames, ref = _case(model_dir, "six_species_L", cfg, g["cell"], g["pos"], symbols)
+    res = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, lnames)
+    assert res["info"]["path"] == "fused_f32"
+    util.assert_close_to(res, ref, 5e-4, what="6 species model L")
+    assert np.abs(res["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF

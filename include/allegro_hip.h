@@ -176,7 +176,7 @@ int ahip_get_timings(ahip_model *m, const char **names, const double **ms, int *
  * matrix cores with a two-term split (ahip_last_path reports "fused_tf32eq"); with 0 every path is float32-exact or better. */
 int ahip_model_allow_tf32(const ahip_model *m, int *allow);
 
-/* Kernel family used by the last compute: "generic_f32" | "generic_f64" | "fused_f32" ("" before). */
+/* Kernel family used by the last compute: "generic_f32" | "generic_f64" | "fused_f32" | "fused_tf32eq" ("" before). */
 const char *ahip_last_path(ahip_model *m);
 /* Largest number of edges of any centre atom in the last compute. */
 int ahip_last_max_degree(ahip_model *m);

@@ -187,7 +187,7 @@ int ahip_set_option(ahip_model *m, const char *key, const char *value) {
       if (v != "model" && v != "float64") throw ArgError("option precision: expected model|float64");
       m->opt_precision = v;
     } else if (k == "fused_arith") {
-      if (v != "bf16x3" && v != "f32") throw ArgError("option fused_arith: expected bf16x3|f32");
+      if (v != "bf16x3" && v != "f32" && v != "tf32eq" && v != "auto") throw ArgError("option fused_arith: expected auto|f32|bf16x3|tf32eq");
       if (v != m->opt_fused_arith) { m->opt_fused_arith = v; fused_free(*m); }     // weight stream is rebuilt on the next compute
     } else if (k == "fused_tb") {
       if (v != "table" && v != "mlp") throw ArgError("option fused_tb: expected table|mlp");
@@ -386,6 +386,7 @@ static void run_model(ahip_model *m, const ComputeArgs &a) {
   std::string why;
   bool fused_ok = false;
   if (m->opt_path != "generic") {
+    m->last_fused_arith = 0;
     if (fused_model_supported(*m, &why)) fused_ok = fused_run(*m, a, &why);
     else {
       std::string why2;
@@ -396,7 +397,8 @@ static void run_model(ahip_model *m, const ComputeArgs &a) {
   }
   if (fused_ok) {
     if (m->nheavy > 0) heavy_generic(m, a);
-    m->last_path = "fused_f32";
+    // "fused_tf32eq": the two-term bf16 split the model file licensed with allow_tf32 = 1 (fused.hip); everything else is float32-exact
+    m->last_path = m->last_fused_arith == 2 ? "fused_tf32eq" : "fused_f32";
     return;
   }
   generic_run<float>(*m, a);
@@ -672,7 +674,7 @@ int ahip_get_timings(ahip_model *m, const char **names, const double **ms, int *
   });
 }
 
-// last kernel family used ("generic_f32" | "generic_f64" | "fused_f32")
+// last kernel family used ("generic_f32" | "generic_f64" | "fused_f32" | "fused_tf32eq")
 extern "C" const char *ahip_last_path(ahip_model *m) { return m ? m->last_path.c_str() : ""; }
 extern "C" int ahip_last_max_degree(ahip_model *m) { return m ? m->last_max_deg : 0; }
 

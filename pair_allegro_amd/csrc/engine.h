@@ -90,7 +90,8 @@ struct Model {
   std::string opt_path = "auto";            // auto | fused | generic
   std::string opt_precision = "model";      // model | float64
   std::string opt_fused_tb = "table";       // table | mlp: two-body embedding of the fused kernel from the spline table or as an MLP
-  std::string opt_fused_arith = "f32";      // f32 | bf16x3: arithmetic of the fused kernel's linears (fused.hip)
+  std::string opt_fused_arith = "auto";     // auto | f32 | bf16x3 | tf32eq: arithmetic of the fused kernel's linears (fused.hip); auto = tf32eq iff the model file sets allow_tf32
+  int last_fused_arith = 0;                 // what the last fused (model S) evaluation used: 0 f32, 1 bf16x3, 2 tf32eq
   long long chunk_edges = 2000000;
   int reserve_wgs = 0;                      // workgroup slots the persistent fused kernels leave free (for kernels of other streams)
   bool timing = false;

@@ -151,12 +151,22 @@ __device__ __forceinline__ Bop split_pair(const f32x4 &t0, const f32x4 &t1) {
 // tiles through the same epilogue functors as linear_s; SPLIT additionally emits the outputs as the next linear's
 // B operands (outb[p] = tiles 2p, 2p+1).  Fragments per (tile pair p, K-step): hi0 hi1 mid0 mid1 lo0 lo1, 1 KiB each,
 // in consumption order; RINGB of them are in flight (a multiple of 6: every linear consumes a multiple of 6).
-static constexpr int RINGB = 12;
-template <int KS, int NT, bool ACC, bool SPLIT, int RP, class Epi>
+static constexpr int RINGB = 12;              // fragments in flight, three-term split (2 steps of 6)
+static constexpr int RINGB2 = 8;              // two-term split (2 steps of 4): every linear of the tile sequence consumes a multiple of 8 fragments except the four mixing blocks (4 each, alternating phase) -- a deeper ring would need the per-layer fragment count to be a multiple of it
+template <int NTERM> struct RingB { static constexpr int N = NTERM == 3 ? RINGB : RINGB2; };
+// NTERM = 3: the float32-equivalent split above (six products).  NTERM = 2 ("tf32eq", used only when the model file sets allow_tf32,
+// the reference's own licence for TF32-class arithmetic, pair_nequip_allegro.cpp:267-270): hi + mid of both operands, the three products
+// w_hi x_hi + w_hi x_mid + w_mid x_hi; the dropped terms are <= 3 * 2^-17 |w x| (TF32 itself rounds both operands to 2^-11), the weight
+// stream is 4 fragments per step = the bytes of the f32 stream, and all of it runs on the bf16 matrix cores beside the VALU.
+template <int KS, int NT, bool ACC, bool SPLIT, int RP, class Epi, int NTERM = 3>
 __device__ __forceinline__ void linear_b(__amdgpu_buffer_rsrc_t W, int &wp, const Bop (&in)[KS], f32x4 (&out)[NT], Bop (&outb)[NT / 2],
-                                         int v16, u32x4 (&ring)[RINGB], Epi epi) {
+                                         int v16, u32x4 (&ring)[RingB<NTERM>::N], Epi epi) {
   static_assert(NT % 2 == 0, "output tiles are processed in pairs");
-  constexpr int NP = NT / 2, NSTEP = NP * KS, NS = 6 * NSTEP;
+  static_assert(NTERM == 2 || NTERM == 3, "two or three bf16 terms per operand");
+  constexpr int RB = RingB<NTERM>::N;
+  constexpr int NF = 2 * NTERM;                       // fragments per step: term-major, two output tiles each
+  constexpr int NPROD = NTERM == 3 ? 6 : 3, MF = 2 * NPROD;      // products per accumulator, MFMAs per step
+  constexpr int NP = NT / 2, NSTEP = NP * KS, NS = NF * NSTEP;
   f32x4 acc0, acc1, prev0, prev1;
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
@@ -165,35 +175,38 @@ __device__ __forceinline__ void linear_b(__amdgpu_buffer_rsrc_t W, int &wp, cons
       if (ACC) { acc0 = out[2 * p]; acc1 = out[2 * p + 1]; }
       else { acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
-    u32x4 a[6];
+    u32x4 a[NF];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      a[i] = ring[(RP + 6 * s + i) % RINGB];
-      ring[(RP + 6 * s + i) % RINGB] = __builtin_bit_cast(u32x4, bload(W, v16, (wp + (6 * s + i + RINGB) * 256) * 4));
+    for (int i = 0; i < NF; ++i) {
+      a[i] = ring[(RP + NF * s + i) % RB];
+      ring[(RP + NF * s + i) % RB] = __builtin_bit_cast(u32x4, bload(W, v16, (wp + (NF * s + i + RB) * 256) * 4));
     }
-    if (ks == 0 && p > 0 && Epi::STORES) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // the previous pair's accumulator stores have completed (see linear_s)
-    // 12 MFMAs, the two accumulators alternate; smallest terms first
+    if (ks == 0 && p > 0 && Epi::STORES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NF) : "memory");      // the previous pair's accumulator stores have completed (see linear_s)
+    // the two accumulators alternate; smallest terms first
 #pragma unroll
-    for (int m = 0; m < 6; ++m) {
-      // term m: (weight term, activation term) = (lo,hi) (mid,mid) (hi,lo) (mid,hi) (hi,mid) (hi,hi)
-      const int wt = m == 0 ? 2 : (m == 1 || m == 3) ? 1 : 0;
-      const u32x4 bx = (m == 0 || m == 3 || m == 5) ? in[ks].hi : (m == 1 || m == 4) ? in[ks].mid : in[ks].lo;
+    for (int m = 0; m < NPROD; ++m) {
+      // NTERM 3, term m: (weight term, activation term) = (lo,hi) (mid,mid) (hi,lo) (mid,hi) (hi,mid) (hi,hi);  NTERM 2: (mid,hi) (hi,mid) (hi,hi)
+      const int wt = NTERM == 3 ? (m == 0 ? 2 : (m == 1 || m == 3) ? 1 : 0) : (m == 0 ? 1 : 0);
+      const int xt = NTERM == 3 ? ((m == 0 || m == 3 || m == 5) ? 0 : (m == 1 || m == 4) ? 1 : 2) : (m == 1 ? 1 : 0);
+      const u32x4 bx = xt == 0 ? in[ks].hi : xt == 1 ? in[ks].mid : in[ks].lo;
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         if (hh == 0) acc0 = mfma_b(a[2 * wt], bx, acc0);
         else acc1 = mfma_b(a[2 * wt + 1], bx, acc1);
         if (p > 0) {
-          const int idx = ks * 12 + 2 * m + hh;       // MFMA index inside this pair
-          constexpr int PER = (KS * 12) / 8;          // MFMAs per epilogue element (>= 1)
-          if (idx % PER == 0 && idx / PER < 8) {
-            const int e = idx / PER;
-            if (e < 4) out[2 * (p - 1)][e] = epi.apply(2 * (p - 1), e, prev0[e]);
-            else out[2 * (p - 1) + 1][e - 4] = epi.apply(2 * (p - 1) + 1, e - 4, prev1[e - 4]);
-            if (e == 7) {
-              epi.flush(2 * (p - 1));
-              if (SPLIT) outb[p - 1] = split_pair(out[2 * (p - 1)], out[2 * (p - 1) + 1]);
+          // the 8 epilogue elements of the previous pair are spread over the KS * MF MFMAs of this pair
+          const int idx = ks * MF + 2 * m + hh, tot = KS * MF;
+          const int e0 = (idx * 8 + tot - 1) / tot, e1 = ((idx + 1) * 8 + tot - 1) / tot;
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (e >= e0 && e < e1) {
+              if (e < 4) out[2 * (p - 1)][e] = epi.apply(2 * (p - 1), e, prev0[e]);
+              else out[2 * (p - 1) + 1][e - 4] = epi.apply(2 * (p - 1) + 1, e - 4, prev1[e - 4]);
+              if (e == 7) {
+                epi.flush(2 * (p - 1));
+                if (SPLIT) outb[p - 1] = split_pair(out[2 * (p - 1)], out[2 * (p - 1) + 1]);
+              }
             }
-          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -212,9 +225,9 @@ __device__ __forceinline__ void linear_b(__amdgpu_buffer_rsrc_t W, int &wp, cons
   }
   wp += NS * 256;
 }
-__device__ __forceinline__ void ring_prime_b(__amdgpu_buffer_rsrc_t W, int wp, int v16, u32x4 (&ring)[RINGB]) {
+template <int RB> __device__ __forceinline__ void ring_prime_b(__amdgpu_buffer_rsrc_t W, int wp, int v16, u32x4 (&ring)[RB]) {
 #pragma unroll
-  for (int j = 0; j < RINGB; ++j) ring[j] = __builtin_bit_cast(u32x4, bload(W, v16, (wp + j * 256) * 4));
+  for (int j = 0; j < RB; ++j) ring[j] = __builtin_bit_cast(u32x4, bload(W, v16, (wp + j * 256) * 4));
 }
 
 // Per-centre sum of the staged tile: dst[a][f] = scale * sum_{slots of a} stage[slot][f], f < 128.
@@ -242,29 +255,32 @@ enum { PH_GEOM = 0, PH_TB, PH_EMB, PH_ENV, PH_TP, PH_MIX, PH_LAT, PH_OUT, PH_BLA
 
 // One weight-fragment ring per arithmetic (see linear_s / linear_b); lin<> dispatches a linear of the tile sequence to
 // the f32-input MFMA form or to the bf16x3 form (inputs are split into their three bf16 terms right here).
-template <bool B3> struct RingT {
-  f32x4 f[B3 ? 1 : RING];
-  u32x4 b[B3 ? RINGB : 1];
+// AR: arithmetic of the tile's linears: 0 = f32-input MFMA, 1 = bf16x3 (three-term split, float32-equivalent), 2 = tf32eq (two-term split)
+template <int AR> struct RingT {
+  f32x4 f[AR != 0 ? 1 : RING];
+  u32x4 b[AR == 0 ? 1 : (AR == 1 ? RINGB : RINGB2)];
   bool pend = false;           // the last linear ended with stores of its accumulators that have not been waited for (see linear_s)
 };
-template <bool B3, int KT, int NT, bool ACC, int RPI, class Epi>
-__device__ __forceinline__ void lin(__amdgpu_buffer_rsrc_t W, int &wp, const f32x4 (&in)[KT], f32x4 (&out)[NT], int v16, RingT<B3> &ring, Epi epi) {
+template <int AR, int KT, int NT, bool ACC, int RPI, class Epi>
+__device__ __forceinline__ void lin(__amdgpu_buffer_rsrc_t W, int &wp, const f32x4 (&in)[KT], f32x4 (&out)[NT], int v16, RingT<AR> &ring, Epi epi) {
   // accumulator stores of the previous linear's last tile pair complete before this linear's MFMAs are issued (linear_s); nothing younger
   // than those stores is in flight here, hence vmcnt(0)
   if (AHIP_LIN_WAIT_MODE != 0 && ring.pend) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   ring.pend = Epi::STORES;
-  if constexpr (B3) {
+  if constexpr (AR != 0) {
     static_assert(KT % 2 == 0, "K-steps are pairs of 16-feature tiles");
+    constexpr int NTERM = AR == 1 ? 3 : 2;
     Bop b[KT / 2], unused[NT / 2];
 #pragma unroll
     for (int ks = 0; ks < KT / 2; ++ks) b[ks] = split_pair(in[2 * ks], in[2 * ks + 1]);
-    linear_b<KT / 2, NT, ACC, false, 6 * RPI>(W, wp, b, out, unused, v16, ring.b, epi);
+    // ring phase: RPI counts the four 32x32 channel-mixing blocks, which consume less than a ring each (2 * NTERM fragments)
+    linear_b<KT / 2, NT, ACC, false, (2 * NTERM * RPI) % RingB<NTERM>::N, Epi, NTERM>(W, wp, b, out, unused, v16, ring.b, epi);
   } else {
-    linear_s<KT, NT, ACC, 4 * RPI, Epi, false>(W, wp, in, out, v16, ring.f, epi);
+    linear_s<KT, NT, ACC, (4 * RPI) % RING, Epi, false>(W, wp, in, out, v16, ring.f, epi);
   }
 }
 
-template <int NW, bool PROF, bool B3, bool TBT>
+template <int NW, bool PROF, int AR, bool TBT>
 __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
   constexpr int NTHREADS = NW * 64, MAXA = Lds<NW>::MAXA;
   __shared__ Lds<NW> lds;
@@ -295,9 +311,9 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     tprev = clock64();
   }
   float *const pk = lds.park[wave];
-  RingT<B3> ring;                              // the weight-fragment stream (see linear_s / linear_b)
+  RingT<AR> ring;                              // the weight-fragment stream (see linear_s / linear_b)
   int wp = A.o_stream;
-  if constexpr (B3) ring_prime_b(WB, wp, v16, ring.b);
+  if constexpr (AR != 0) ring_prime_b(WB, wp, v16, ring.b);
   else ring_prime(WB, wp, v16, ring.f);
   if (tid < MAXA) lds.eacc[tid] = 0.0;
   if (lane < 6) lds.virw[wave][lane] = 0.0;
@@ -396,16 +412,16 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         bfin[0][r] = g < 2 ? pref * __builtin_amdgcn_sinf(0.5f * n * xx) * inv * fc : 0.f;
         bfin[1][r] = 0.f;
       }
-      lin<B3, 2, 4, true, 0>(WB, wp, bfin, z, v16, ring, EpiSiluSaveD{SB, R_Z1TB(), v16});
-      lin<B3, 4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, R_Z2TB(), v16});
-      lin<B3, 4, 4, false, 0>(WB, wp, z2, x, v16, ring, EpiSaveScale{{SB, R_U0(), v16}, fc});
+      lin<AR, 2, 4, true, 0>(WB, wp, bfin, z, v16, ring, EpiSiluSaveD{SB, R_Z1TB(), v16});
+      lin<AR, 4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, R_Z2TB(), v16});
+      lin<AR, 4, 4, false, 0>(WB, wp, z2, x, v16, ring, EpiSaveScale{{SB, R_U0(), v16}, fc});
     }
     PHASE(PH_TB);
     // ---------------- tensor embedding weights (V^0 = w0 (x) Y is rebuilt where needed) -------------
     {
       f32x4 w0[4];
       // w0 goes to scratch (backward) and to the LDS park rows 0..3, where layer 0 picks it up
-      lin<B3, 4, 4, false, 0>(WB, wp, x, w0, v16, ring, EpiSavePark{{SB, R_W0(), v16}, pk, 0, lane});
+      lin<AR, 4, 4, false, 0>(WB, wp, x, w0, v16, ring, EpiSavePark{{SB, R_W0(), v16}, pk, 0, lane});
     }
     if (ck == 0 && tid == 0) lds.chunk[cpar ^ 1] = claimed;
     __syncthreads();          // aoff visible; previous tile's LDS users done
@@ -419,7 +435,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       f32x4 V[4][2];
       {
         f32x4 om[4];
-        lin<B3, 4, 4, false, 0>(WB, wp, x, om, v16, ring, EpiSave{SB, RL + 0, v16});
+        lin<AR, 4, 4, false, 0>(WB, wp, x, om, v16, ring, EpiSave{SB, RL + 0, v16});
         // environment sum over the centre's edges
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -475,21 +491,21 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       // channel mixing -> V^{kk+1}: saved in the next layer's VIN rows and parked in LDS
       if (!last) {
         f32x4 o2[2];
-        lin<B3, 2, 2, false, 0>(WB, wp, Vp[0], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1) + 16 + 0, v16}, pk, 0, lane});
-        lin<B3, 2, 2, false, 1>(WB, wp, Vp[1], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1) + 16 + 2, v16}, pk, 2, lane});
-        lin<B3, 2, 2, false, 0>(WB, wp, Vp[2], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1) + 16 + 4, v16}, pk, 4, lane});
-        lin<B3, 2, 2, false, 1>(WB, wp, Vp[3], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1) + 16 + 6, v16}, pk, 6, lane});
+        lin<AR, 2, 2, false, 0>(WB, wp, Vp[0], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1) + 16 + 0, v16}, pk, 0, lane});
+        lin<AR, 2, 2, false, 1>(WB, wp, Vp[1], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1) + 16 + 2, v16}, pk, 2, lane});
+        lin<AR, 2, 2, false, 2>(WB, wp, Vp[2], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1) + 16 + 4, v16}, pk, 4, lane});
+        lin<AR, 2, 2, false, 3>(WB, wp, Vp[3], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1) + 16 + 6, v16}, pk, 6, lane});
       }
       PHASE(PH_MIX);
       // latent MLP
       {
         f32x4 cat[6], z[4], z2[4];
         cat[0] = x[0]; cat[1] = x[1]; cat[2] = x[2]; cat[3] = x[3]; cat[4] = Vp[0][0]; cat[5] = Vp[0][1];
-        lin<B3, 6, 4, false, 0>(WB, wp, cat, z, v16, ring, EpiSiluSaveD{SB, RL + 4, v16});
-        lin<B3, 4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, RL + 8, v16});
+        lin<AR, 6, 4, false, 0>(WB, wp, cat, z, v16, ring, EpiSiluSaveD{SB, RL + 4, v16});
+        lin<AR, 4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, RL + 8, v16});
         const float ra = lds.res[kk][0], rbf = lds.res[kk][1] * fc;
         f32x4 xn[4];
-        lin<B3, 4, 4, false, 0>(WB, wp, z2, xn, v16, ring, EpiResidual<4>{{SB, RL + 12, v16}, x, ra, rbf});
+        lin<AR, 4, 4, false, 0>(WB, wp, z2, xn, v16, ring, EpiResidual<4>{{SB, RL + 12, v16}, x, ra, rbf});
         x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2]; x[3] = xn[3];
       }
       PHASE(PH_LAT);
@@ -503,7 +519,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     load_rows<4>(SB, R_LAYER(NL - 1) + 8, zt, v16);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 zr[2];
-    lin<B3, 4, 2, false, 0>(WB, wp, x, zr, v16, ring, EpiNone{});
+    lin<AR, 4, 2, false, 0>(WB, wp, x, zr, v16, ring, EpiNone{});
     f32x4 wo1[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) wo1[t] = *(const f32x4 *)(Wb + A.o_out1 + 16 * t + 4 * g);
@@ -524,7 +540,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dzr[t][r] = deps * wo1[t][r] * dsilu1(zr[t][r]);
-      lin<B3, 2, 4, false, 0>(WB, wp, dzr, dx, v16, ring, EpiNone{});
+      lin<AR, 2, 4, false, 0>(WB, wp, dzr, dx, v16, ring, EpiNone{});
     }
     float dfc_part = 0.f, dY1 = 0.f, dY2 = 0.f, dY3 = 0.f;
     PHASE(PH_OUT);
@@ -548,16 +564,16 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         f32x4 zt1[4];
         load_rows<4>(SB, RL + 4, zt1, v16);                  // z1: first used 96 MFMAs from here
         __builtin_amdgcn_sched_barrier(0);
-        lin<B3, 4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt});
+        lin<AR, 4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt});
         // prefetch V^{kk} (input of this layer's tensor product) under the MFMAs that follow
         if (kk > 0) {
 #pragma unroll
           for (int lm = 0; lm < 4; ++lm) load_rows<2>(SB, RL + 16 + 2 * lm, Vk[lm], v16);
         } else load_rows<4>(SB, R_W0(), W0b, v16);
         __builtin_amdgcn_sched_barrier(0);
-        lin<B3, 4, 4, false, 0>(WB, wp, dh, du, v16, ring, EpiMulRows<4>{zt1});
+        lin<AR, 4, 4, false, 0>(WB, wp, dh, du, v16, ring, EpiMulRows<4>{zt1});
         f32x4 dcat[6];
-        lin<B3, 4, 6, false, 0>(WB, wp, du, dcat, v16, ring, EpiNone{});
+        lin<AR, 4, 6, false, 0>(WB, wp, du, dcat, v16, ring, EpiNone{});
 #pragma unroll
         for (int t = 0; t < 4; ++t) dx[t] += dcat[t];
         dVp[0][0] = dcat[4]; dVp[0][1] = dcat[5];             // ds
@@ -576,14 +592,14 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       if (!last) {
         f32x4 in2[2], o2[2];
         in2[0] = park_load(pk, 0, lane); in2[1] = park_load(pk, 1, lane);
-        lin<B3, 2, 2, false, 0>(WB, wp, in2, o2, v16, ring, EpiNone{});
+        lin<AR, 2, 2, false, 0>(WB, wp, in2, o2, v16, ring, EpiNone{});
         dVp[0][0] += o2[0]; dVp[0][1] += o2[1];
         in2[0] = park_load(pk, 2, lane); in2[1] = park_load(pk, 3, lane);
-        lin<B3, 2, 2, false, 1>(WB, wp, in2, dVp[1], v16, ring, EpiNone{});
+        lin<AR, 2, 2, false, 1>(WB, wp, in2, dVp[1], v16, ring, EpiNone{});
         in2[0] = park_load(pk, 4, lane); in2[1] = park_load(pk, 5, lane);
-        lin<B3, 2, 2, false, 0>(WB, wp, in2, dVp[2], v16, ring, EpiNone{});
+        lin<AR, 2, 2, false, 2>(WB, wp, in2, dVp[2], v16, ring, EpiNone{});
         in2[0] = park_load(pk, 6, lane); in2[1] = park_load(pk, 7, lane);
-        lin<B3, 2, 2, false, 1>(WB, wp, in2, dVp[3], v16, ring, EpiNone{});
+        lin<AR, 2, 2, false, 3>(WB, wp, in2, dVp[3], v16, ring, EpiNone{});
       }
       __builtin_amdgcn_sched_barrier(0);
       PHASE(PH_BMIX);
@@ -652,7 +668,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
           load_rows<2>(SB, R_W0() + 2, w0h, v16);
         }
         __builtin_amdgcn_sched_barrier(0);
-        lin<B3, 4, 4, true, 0>(WB, wp, dom, dx, v16, ring, EpiNone{});
+        lin<AR, 4, 4, true, 0>(WB, wp, dom, dx, v16, ring, EpiNone{});
       }
       PHASE(PH_BENV);
     }
@@ -670,7 +686,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { dY1 += d1[r] * w0h[t][r]; dY2 += d2[r] * w0h[t][r]; dY3 += d3[r] * w0h[t][r]; }
       }
-      lin<B3, 4, 4, true, 0>(WB, wp, dw0, dx, v16, ring, EpiNone{});
+      lin<AR, 4, 4, true, 0>(WB, wp, dw0, dx, v16, ring, EpiNone{});
       if constexpr (TBT) wp = A.o_stream;                                 // last linear of the tile
     }
     PHASE(PH_BEMB);
@@ -691,10 +707,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         for (int r = 0; r < 4; ++r) { acc += upre[t][r] * dx[t][r]; du[t][r] = fc * dx[t][r]; }
       dfc_part += acc;
       __builtin_amdgcn_sched_barrier(0);
-      lin<B3, 4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt});
-      lin<B3, 4, 4, false, 0>(WB, wp, dh, du, v16, ring, EpiMulRows<4>{zt1b});
+      lin<AR, 4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt});
+      lin<AR, 4, 4, false, 0>(WB, wp, dh, du, v16, ring, EpiMulRows<4>{zt1b});
       f32x4 dbf[2];
-      lin<B3, 4, 2, false, 0>(WB, wp, du, dbf, v16, ring, EpiNone{});   // its prefetches already fetch the next tile's first fragments
+      lin<AR, 4, 2, false, 0>(WB, wp, du, dbf, v16, ring, EpiNone{});   // its prefetches already fetch the next tile's first fragments
       wp = A.o_stream;                                                    // (the stream ends with a copy of its first RING entries)
       const float dfdd = dfc_dx / rc;
 #pragma unroll
@@ -797,7 +813,7 @@ struct FusedState {
   FusedArgs args;
   bool ready = false, prof_on = false, dbg_on = false, clk_on = false;
   bool tbt = true;             // two-body embedding from the spline table (default) or evaluated as an MLP (option fused_tb=mlp)
-  bool b3 = false;             // f32-input MFMA (default) or bf16x3 arithmetic (option fused_arith=bf16x3 / AHIP_FUSED_ARITH=b3)
+  int arith = 0;               // 0: f32-input MFMA; 1: bf16x3 (option fused_arith=bf16x3 / AHIP_FUSED_ARITH=b3); 2: tf32eq (two-term bf16 split; fused_arith=auto picks it when the model file says allow_tf32 = 1)
   DevBuf prof, dbg;
   int ncu = 256;
   int force_nw = 0;            // AHIP_FUSED_NW=4|8 pins the workgroup shape (A/B measurements)
@@ -813,12 +829,12 @@ static void frag_dims_b(int K, int N, int &KS, int &NT) {
   NT = (N + 15) / 16;
   NT += NT & 1;
 }
-static int append_frag_b(std::vector<float> &out, const double *W, int K, int N, int ldw) {
+static int append_frag_b(std::vector<float> &out, const double *W, int K, int N, int ldw, int nterm = 3) {
   int KS, NT;
   frag_dims_b(K, N, KS, NT);
   for (int p = 0; p < NT / 2; ++p)
     for (int ks = 0; ks < KS; ++ks)
-      for (int term = 0; term < 3; ++term)
+      for (int term = 0; term < nterm; ++term)
         for (int half = 0; half < 2; ++half)
           for (int lane = 0; lane < 64; ++lane)
             for (int w = 0; w < 4; ++w) {
@@ -840,7 +856,7 @@ static int append_frag_b(std::vector<float> &out, const double *W, int K, int N,
               std::memcpy(&f, &word, 4);
               out.push_back(f);
             }
-  return 6 * KS * (NT / 2);
+  return 2 * nterm * KS * (NT / 2);
 }
 bool fused_model_supported(const Model &m, std::string *why) {
   const HostModel &h = m.hm;
@@ -876,18 +892,19 @@ static void fused_prepare(Model &m) {
   {
     const char *ar = std::getenv("AHIP_FUSED_ARITH");
     std::string arith = ar ? ar : m.opt_fused_arith;
-    st.b3 = arith == "b3" || arith == "bf16x3";
+    st.arith = (arith == "b3" || arith == "bf16x3") ? 1 : (arith == "tf32eq" || (arith == "auto" && h.allow_tf32)) ? 2 : 0;
   }
   {
     const char *tb = std::getenv("AHIP_FUSED_TB");
     std::string mode = tb ? tb : m.opt_fused_tb;
     st.tbt = mode != "mlp";
   }
-  const bool b3 = st.b3, tbt = st.tbt;
-  auto fwd = [&](const double *W, int K, int N) { if (b3) append_frag_b(w, W, K, N, N); else append_frag(w, W, K, N, N); };
+  const bool b3 = st.arith != 0, tbt = st.tbt;
+  const int nterm = st.arith == 1 ? 3 : 2;
+  auto fwd = [&](const double *W, int K, int N) { if (b3) append_frag_b(w, W, K, N, N, nterm); else append_frag(w, W, K, N, N); };
   auto bwd = [&](const double *W, int K, int N) {
     auto t = transpose(W, K, N);
-    if (b3) append_frag_b(w, t.data(), N, K, K); else append_frag(w, t.data(), N, K, K);
+    if (b3) append_frag_b(w, t.data(), N, K, K, nterm); else append_frag(w, t.data(), N, K, K);
   };
   auto T_ = [&](const std::string &name) -> const double * { return h.get(name).data.data(); };
   const double *wc = w0.data.data() + (size_t)2 * T * 64;       // Bessel block [8][64]
@@ -930,7 +947,7 @@ static void fused_prepare(Model &m) {
     bwd(wc, 8, 64);
   }
   {   // wrap-around copy: the last linear of a tile prefetches the first fragments of the next tile
-    const size_t n = (size_t)(b3 ? RINGB : RING) * 256;
+    const size_t n = (size_t)(st.arith == 1 ? RINGB : st.arith == 2 ? RINGB2 : RING) * 256;
     for (size_t i = 0; i < n; ++i) w.push_back(w[stream0 + i]);
   }
   // two-body embedding table (see k_fused): per type pair, cubic Hermite in d on [0, r_c(pair)] from the float64 MLP
@@ -985,6 +1002,7 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
   if (m.edges_T_size != 4) { if (why) *why = "edge vectors are not float32"; return false; }
   fused_prepare(m);
   FusedState &st = *(FusedState *)m.fused_state;
+  m.last_fused_arith = st.arith;
   hipStream_t s = a.stream;
   const int inum = m.inum;
   int nw = m.last_max_deg <= 64 ? 4 : 8;
@@ -1040,9 +1058,9 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
 #define AHIP_LAUNCH_TB(NWV, PROFV, B3V) do { if (st.tbt) AHIP_LAUNCH(NWV, PROFV, B3V, true); else AHIP_LAUNCH(NWV, PROFV, B3V, false); } while (0)
 #define AHIP_LAUNCH_NW(PROFV, B3V) do { if (nw == 4) AHIP_LAUNCH_TB(4, PROFV, B3V); else AHIP_LAUNCH_TB(8, PROFV, B3V); } while (0)
     if (st.prof_on) {
-      if (st.b3) AHIP_LAUNCH_NW(true, true); else AHIP_LAUNCH_NW(true, false);
+      if (st.arith == 1) AHIP_LAUNCH_NW(true, 1); else if (st.arith == 2) AHIP_LAUNCH_NW(true, 2); else AHIP_LAUNCH_NW(true, 0);
     } else {
-      if (st.b3) AHIP_LAUNCH_NW(false, true); else AHIP_LAUNCH_NW(false, false);
+      if (st.arith == 1) AHIP_LAUNCH_NW(false, 1); else if (st.arith == 2) AHIP_LAUNCH_NW(false, 2); else AHIP_LAUNCH_NW(false, 0);
     }
 #undef AHIP_LAUNCH_NW
 #undef AHIP_LAUNCH_TB
@@ -1124,7 +1142,7 @@ __global__ void __launch_bounds__(128) k_selftest_linear(const float *Wf, int wb
     }
 }
 
-template <int KS, int NT>
+template <int KS, int NT, int NTERM>
 __global__ void __launch_bounds__(128) k_selftest_linear_b(const float *Wf, int wbytes, const float *in, int K, float *out, int N) {
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, row = (threadIdx.x >> 6) * 16 + j;
   f32x4 a[2 * KS], o[NT];
@@ -1139,10 +1157,10 @@ __global__ void __launch_bounds__(128) k_selftest_linear_b(const float *Wf, int 
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) b[ks] = split_pair(a[2 * ks], a[2 * ks + 1]);
   __amdgpu_buffer_rsrc_t WB = __builtin_amdgcn_make_buffer_rsrc((void *)Wf, 0, wbytes, 0x00020000);
-  u32x4 ring[RINGB];
+  u32x4 ring[RingB<NTERM>::N];
   int wp = 0;
   ring_prime_b(WB, wp, lane * 16, ring);
-  linear_b<KS, NT, false, false, 0>(WB, wp, b, o, ob, lane * 16, ring, EpiNone{});
+  linear_b<KS, NT, false, false, 0, EpiNone, NTERM>(WB, wp, b, o, ob, lane * 16, ring, EpiNone{});
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -1169,12 +1187,13 @@ extern "C" int ahip_debug_fused_edges(ahip_model *mh, float *out, long long nedg
 extern "C" int ahip_debug_fused_linear(int K, int N, const double *W, const float *in, float *out) {
   try {
     const char *ar = std::getenv("AHIP_FUSED_ARITH");
-    const bool b3 = ar && (std::string(ar) == "b3" || std::string(ar) == "bf16x3");
+    const int nterm = (ar && std::string(ar) == "tf32eq") ? 2 : 3;
+    const bool b3 = ar && (std::string(ar) == "b3" || std::string(ar) == "bf16x3" || std::string(ar) == "tf32eq");
     std::vector<float> frag;
     int KT, NT;
-    if (b3) { append_frag_b(frag, W, K, N, N); frag_dims_b(K, N, KT, NT); }
+    if (b3) { append_frag_b(frag, W, K, N, N, nterm); frag_dims_b(K, N, KT, NT); }
     else { append_frag(frag, W, K, N, N); frag_dims(K, N, KT, NT); }
-    frag.resize(frag.size() + (size_t)(RINGB + 2) * 256, 0.f);      // the ring prefetches past the end
+    frag.resize(frag.size() + (size_t)(RINGB2 + 2) * 256, 0.f);      // the ring prefetches past the end
     float *dW = nullptr, *din = nullptr, *dout = nullptr;
     AHIP_CHECK(hipMalloc((void **)&dW, frag.size() * sizeof(float)));
     AHIP_CHECK(hipMalloc((void **)&din, (size_t)32 * K * sizeof(float)));
@@ -1183,7 +1202,8 @@ extern "C" int ahip_debug_fused_linear(int K, int N, const double *W, const floa
     AHIP_CHECK(hipMemcpy(din, in, (size_t)32 * K * sizeof(float), hipMemcpyHostToDevice));
     bool ok = true;
     const int wbytes = (int)(frag.size() * sizeof(float));
-#define CASEB(ks, nt) hipLaunchKernelGGL((k_selftest_linear_b<ks, nt>), dim3(1), dim3(128), 0, 0, dW, wbytes, din, K, dout, N)
+#define CASEB(ks, nt) do { if (nterm == 3) hipLaunchKernelGGL((k_selftest_linear_b<ks, nt, 3>), dim3(1), dim3(128), 0, 0, dW, wbytes, din, K, dout, N); \
+                           else hipLaunchKernelGGL((k_selftest_linear_b<ks, nt, 2>), dim3(1), dim3(128), 0, 0, dW, wbytes, din, K, dout, N); } while (0)
     if (b3) {
       if (KT == 1 && NT == 2) CASEB(1, 2);
       else if (KT == 1 && NT == 4) CASEB(1, 4);

@@ -11,7 +11,7 @@ from pair_allegro_amd import cg, lmp_like, model_file
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("arith", ["f32", "bf16x3"])
+@pytest.mark.parametrize("arith", ["f32", "bf16x3", "tf32eq"])
 @pytest.mark.parametrize("K,N", [(8, 64), (32, 32), (32, 64), (64, 32), (64, 64), (96, 64), (64, 96), (64, 8)])
 def test_mfma_linear_primitive(hip_lib, K, N, arith, monkeypatch):
     """The streamed register-chain linear, on the f32-input MFMA and on the bf16x3 split (six bf16 MFMA terms):
@@ -22,7 +22,9 @@ def test_mfma_linear_primitive(hip_lib, K, N, arith, monkeypatch):
     x = rng.normal(size=(32, K)).astype(np.float32)
     out = hip_lib.debug_fused_linear(W, x)
     ref = x.astype(np.float64) @ W
-    np.testing.assert_allclose(out, ref, atol=2e-5 * np.abs(ref).max(), rtol=1e-5)
+    # tf32eq: two-term bf16 split, dropped terms <= 3 * 2^-17 per product (TF32 itself: 2^-11 per operand)
+    tol = 1e-4 if arith == "tf32eq" else 2e-5
+    np.testing.assert_allclose(out, ref, atol=tol * np.abs(ref).max(), rtol=tol / 2)
 
 
 @pytest.mark.parametrize("tag", ["Si64_r5", "Li3PO4_128_r5"])
@@ -82,6 +84,37 @@ def test_fused_many_species(hip_lib, model_dir, ntypes):
     assert fused["info"]["path"] == "fused_f32"
     util.assert_close_to(fused, ref, 5e-4, what=f"{ntypes} species, fused vs f64 oracle")
     assert np.abs(fused["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
+
+
+def test_allow_tf32_selects_the_two_term_split(hip_lib, model_dir):
+    """A model file with allow_tf32 = 1 (the reference hands the key to libtorch, pair_nequip_allegro.cpp:267-270) runs the fused kernel's
+    linears on the bf16 matrix cores with the two-term split ("fused_tf32eq"); its error against the float64 oracle must not exceed that of
+    a TF32 run of the torch oracle (emulated: operands of every matmul rounded to 10 mantissa bits, util.tf32_emulation); option
+    fused_arith=f32 keeps the exact float32 arithmetic; a file with allow_tf32 = 0 never leaves it."""
+    g = util.load_golden("CuPd-cubic-big_r5")
+    nb = float(len(util.glue.brute_force_edges(g["cell"], g["pos"], 5.0)[0])) / len(g["pos"])
+    cfg = model_file.model_S(type_names=["Cu", "Pd"], avg_num_neighbors=nb, allow_tf32=1)
+    w = model_file.init_weights(cfg)
+    path = f"{model_dir}/tf32.nequip.pth"
+    allegro_torch.export_nequip_pth(path, cfg, w)
+    names = ["Cu", "Pd"]
+    types = np.array([names.index(s_) + 1 for s_ in g["symbols"]], dtype=np.int32)
+    ref = util.oracle_run(dict(cfg, model_dtype="float64"), w, g["cell"], g["pos"], types, names)
+    with util.tf32_emulation():
+        tf = util.oracle_run(dict(cfg, model_dtype="float32"), w, g["cell"], g["pos"], types, names)
+    err_tf32 = np.abs(tf["forces"] - ref["forces"]).max()
+    res = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names)
+    assert res["info"]["path"] == "fused_tf32eq"
+    err = np.abs(res["forces"] - ref["forces"]).max()
+    print(f"max|dF| vs f64 oracle: tf32eq kernel {err:.3e}, TF32-emulated torch oracle {err_tf32:.3e}")
+    assert err <= err_tf32 and err < 5e-4
+    util.assert_close_to(res, ref, 5e-4, what="tf32eq vs f64 oracle (reference tolerance)")
+    exact = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"fused_arith": "f32"})
+    assert exact["info"]["path"] == "fused_f32" and np.abs(exact["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
+    cfg0 = dict(cfg, allow_tf32=0)
+    path0 = f"{model_dir}/notf32.nequip.pth"
+    allegro_torch.export_nequip_pth(path0, cfg0, w)
+    assert util.run_pair(hip_lib, path0, g["cell"], g["pos"], types, names)["info"]["path"] == "fused_f32"
 
 
 def test_fused_bf16x3_arithmetic_matches_f32(hip_lib, model_dir):

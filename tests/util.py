@@ -119,3 +119,61 @@ def assert_close_to(res, ref, tol, stress_factor=20.0, what=""):
     np.testing.assert_allclose(res["eatom"].sum(), res["pe"], atol=1e-9 * max(1.0, abs(res["pe"])), rtol=1e-9, err_msg="PE != sum eatom")
     np.testing.assert_allclose(res["virial"], ref["virial"], atol=tol * stress_factor * max(1, len(ref["eatom"]) ** 0.5),
                                rtol=tol * stress_factor, err_msg=f"virial {what}")
+
+
+# ---- TF32 emulation of the torch oracle (what `allow_tf32 = 1` licenses in the reference: /root/reference/pair_nequip_allegro.cpp:267-270) ----
+class tf32_emulation:
+    """Context manager: inside it every `a @ b` and every two-operand `torch.einsum` of an EAGER float32 module rounds both operands to
+    TF32 (10 explicit mantissa bits, round to nearest even) before multiplying -- forward and, through a custom autograd function, the
+    operand / gradient pairs of the backward matmuls -- and accumulates in float32: the arithmetic of a TF32 tensor-core run.  The
+    three-operand tensor-product einsum stays float32 (fewer TF32 operations than a real run, i.e. a stricter bar for the kernel)."""
+
+    @staticmethod
+    def round_tf32(t):
+        import torch
+        if t.dtype != torch.float32:
+            return t
+        i = t.contiguous().view(torch.int32)
+        lsb = (i >> 13) & 1
+        i = (i + 0x0FFF + lsb) & ~0x1FFF
+        return i.view(torch.float32)
+
+    def __enter__(self):
+        import torch
+        r = tf32_emulation.round_tf32
+        orig_mm, orig_es = torch.Tensor.__matmul__, torch.einsum
+        self._orig = (orig_mm, orig_es)
+
+        class _Contract(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, eq, a, b):
+                ctx.eq = eq
+                ctx.save_for_backward(a, b)
+                return orig_es(eq, r(a), r(b)) if eq else orig_mm(r(a), r(b))
+
+            @staticmethod
+            def backward(ctx, g):
+                a, b = ctx.saved_tensors
+                with torch.enable_grad():
+                    a_ = r(a).detach().requires_grad_(True)
+                    b_ = r(b).detach().requires_grad_(True)
+                    out = orig_es(ctx.eq, a_, b_) if ctx.eq else orig_mm(a_, b_)
+                    ga, gb = torch.autograd.grad(out, [a_, b_], r(g.contiguous()))
+                return None, ga, gb
+
+        def mm(a, b):
+            return _Contract.apply("", a, b) if a.dtype == torch.float32 else orig_mm(a, b)
+
+        def es(eq, *ops):
+            if len(ops) == 2 and ops[0].dtype == torch.float32:
+                return _Contract.apply(eq, ops[0], ops[1])
+            return orig_es(eq, *ops)
+
+        torch.Tensor.__matmul__ = mm
+        torch.einsum = es
+        return self
+
+    def __exit__(self, *exc):
+        import torch
+        torch.Tensor.__matmul__, torch.einsum = self._orig
+        return False

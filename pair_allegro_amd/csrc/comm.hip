@@ -87,7 +87,8 @@ struct Rccl {
   bool load(std::string *why) {
     if (h) return true;
     const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    // a copy already in the process (PyTorch bundles one) is reused by soname
+    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
     if (!h) { if (why) *why = std::string("cannot open librccl.so: ") + dlerror(); return false; }
     auto sym = [&](const char *n) { void *p = dlsym(h, n); if (!p && why) *why = std::string("librccl.so lacks ") + n; return p; };
     GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");

@@ -218,11 +218,29 @@ class Simulation:
             return capi.Comm(model.L, 0, 1)
         is_rccl = self.dev.type == "cuda" and hasattr(self.dist, "get_backend") and self.dist.get_backend() == "nccl"
         if is_rccl:
-            idt = torch.zeros(128, dtype=torch.uint8, device=self.dev)
+            # the library's own RCCL communicator: rank 0's ncclUniqueId travels through the process group.  Every rank reports whether
+            # its communicator came up; if any did not (librccl.so missing, init failure) ALL ranks fall back to the hosted transport over the
+            # process group, so a first-contact problem costs speed, not the run.
+            idt = torch.zeros(129, dtype=torch.uint8, device=self.dev)
             if self.rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(capi.Comm.unique_id(model.L)), dtype=torch.uint8))
+                try:
+                    idt[:128].copy_(torch.frombuffer(bytearray(capi.Comm.unique_id(model.L)), dtype=torch.uint8))
+                    idt[128] = 1
+                except capi.AhipError as e:
+                    print(f"[md] ahip_comm_unique_id failed ({e}); ghost exchange through torch.distributed", flush=True)
             self.dist.broadcast(idt, src=0)
-            return capi.Comm(model.L, self.rank, self.nranks, rccl_id=bytes(idt.cpu().numpy().tobytes()), device=self.dev.index or 0)
+            comm, ok = None, torch.zeros(1, dtype=torch.int32, device=self.dev)
+            if int(idt[128].item()) == 1:
+                try:
+                    comm = capi.Comm(model.L, self.rank, self.nranks, rccl_id=bytes(idt[:128].cpu().numpy().tobytes()), device=self.dev.index or 0)
+                    ok[0] = 1
+                except capi.AhipError as e:
+                    print(f"[md] rank {self.rank}: ahip_comm_create_rccl failed ({e})", flush=True)
+            self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                return comm
+            if comm is not None:
+                comm.close()
         return capi.Comm(model.L, self.rank, self.nranks, xfer=self._hosted_xfer)
 
     def _set_comm_plan(self) -> None:

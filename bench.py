@@ -11,8 +11,9 @@
 Workload (BASELINE.json metric / configs[3]): 1 000 000-atom bulk Si (50^3 diamond cells, a = 5.431 A,
 Gaussian jitter 0.05 A seed 0), model S (l_max = 1, 32 tensor features, 64 scalars, 2 layers,
 seeded random weights), r_max 5 A, skin 1 A, NVE, dt 1 fs, velocities 300 K.  STRONG scaling: the
-same 1 M atoms are brick-decomposed over N GPUs (one process per GPU, ghost exchange via
-torch.distributed == RCCL over xGMI).  A "step" is one full MD step: integrate, ghost forward comm
+same 1 M atoms are brick-decomposed over N GPUs (one process per GPU; the per-step ghost exchange is the
+library's own -- HIP pack / unpack kernels + RCCL send / receive groups over xGMI, csrc/comm.hip -- and
+torch.distributed (backend nccl = RCCL) carries the setup and the re-neighboring steps).  A "step" is one full MD step: integrate, ghost forward comm
 (or re-neighbor when an atom moved > skin/2), force evaluation through the C-ABI, ghost reverse
 comm, integrate.  Inputs are resident in HBM before the timed region.
 
@@ -278,6 +279,7 @@ def main():
                        "steps_per_rebuild": (round(args.steps / rebuilds_timed, 1) if rebuilds_timed else None),
                        "rebuild_share_of_step_at_1_per_50": round(rebuild_ms / 50.0 / ms_per_step, 5),
                        "comm": "overlapped" if sim.overlap else "serial",
+                       "comm_transport": (("library/" + sim.comm.transport + ("/single-rank gather-scatter" if world == 1 else "")) if getattr(sim, "comm", None) is not None else "torch.distributed"),
                        "stage_ms_rank0": {k: round(v, 3) for k, v in stage_avg.items()},
                        "pe_per_atom": th["pe"] / natoms},
             "max_abs_dF_vs_oracle": max_df,

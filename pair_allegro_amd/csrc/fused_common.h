@@ -148,6 +148,9 @@ __device__ __forceinline__ void linear_s(__amdgpu_buffer_rsrc_t W, int &wp, cons
   // each one back with v_readlane + hazard nops where it is used (1 450 lane operations per wave-tile in fused_lx2.hip).
   int wo = (wp + RING * 256) * 4;
   pin_s(wo);
+#ifdef AHIP_LIN_PRIO
+  __builtin_amdgcn_s_setprio(AHIP_LIN_PRIO);
+#endif
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
     const int p = s / KT, kt = s % KT;
@@ -206,6 +209,9 @@ __device__ __forceinline__ void linear_s(__amdgpu_buffer_rsrc_t W, int &wp, cons
   }
   wp += NS * 256;
   pin_s(wp);
+#ifdef AHIP_LIN_PRIO
+  __builtin_amdgcn_s_setprio(AHIP_LIN_PRIO_OUT);
+#endif
 }
 // first RING fragments of the stream at wp into the ring
 __device__ __forceinline__ void ring_prime(__amdgpu_buffer_rsrc_t W, int wp, int v16, f32x4 (&ring)[RING]) {

@@ -147,6 +147,9 @@ void ahip_model_free(ahip_model *m) {
                     &m->b_ws, &m->b_misc, &m->hv_eoff, &m->hv_eii, &m->hv_ej, &m->hv_rvec, &m->hv_ilist, &m->hv_engvir})
     b->release();
   for (auto &t : m->slots) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
+#ifndef AHIP_HOST_EMU
+  for (auto &kv : m->pinned) (void)hipHostUnregister(kv.second.first);
+#endif
   if (m->counted) g_models_alive.fetch_sub(1);
   delete m;
 }
@@ -405,6 +408,20 @@ static void run_model(ahip_model *m, const ComputeArgs &a) {
   m->last_path = "generic_f32";
 }
 
+// Page-locks a persistent host vector for as long as it keeps its storage: copies from / into pageable memory are staged by the runtime
+// and "asynchronous" in name only; the vectors of the host-pointer path only ever grow, so this registers once per growth.
+template <class T> static void pin_host(ahip::Model *m, std::vector<T> &v) {
+#ifndef AHIP_HOST_EMU
+  void *p = (void *)v.data();
+  const size_t bytes = v.capacity() * sizeof(T);
+  auto it = m->pinned.find((const void *)&v);
+  if (it != m->pinned.end() && it->second.first == p && it->second.second == bytes) return;
+  if (it != m->pinned.end()) { (void)hipHostUnregister(it->second.first); m->pinned.erase(it); }
+  if (p && bytes && hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) m->pinned[(const void *)&v] = {p, bytes};
+  else (void)hipGetLastError();          // registration is an optimisation: pageable copies still work
+#endif
+}
+
 int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const int *type, int ntypes,
                  const int *type_mapper, const double *cutoff_matrix, double *f, double *eatom, double *eng,
                  double *virial) {
@@ -446,7 +463,11 @@ int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const i
     m->b_eatom.reserve((size_t)nall * sizeof(double));
     m->b_engvir.reserve(8 * sizeof(double));
     m->b_cutsq.reserve(cutsq.size() * sizeof(double));
-    AHIP_CHECK(hipMemcpyAsync(m->b_x.p, x, (size_t)nall * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    // positions: one host copy into a page-locked buffer, then a true DMA (LAMMPS' atom->x itself is pageable and not ours to register)
+    m->h_x.resize((size_t)nall * 3);
+    pin_host(m, m->h_x); pin_host(m, m->h_ftype); pin_host(m, m->h_mtype);
+    std::memcpy(m->h_x.data(), x, (size_t)nall * 3 * sizeof(double));
+    AHIP_CHECK(hipMemcpyAsync(m->b_x.p, m->h_x.data(), (size_t)nall * 3 * sizeof(double), hipMemcpyHostToDevice, s));
     AHIP_CHECK(hipMemcpyAsync(m->b_ftype.p, m->h_ftype.data(), (size_t)nall * sizeof(int), hipMemcpyHostToDevice, s));
     AHIP_CHECK(hipMemcpyAsync(m->b_mtype.p, m->h_mtype.data(), (size_t)nall * sizeof(int), hipMemcpyHostToDevice, s));
     AHIP_CHECK(hipMemcpyAsync(m->b_cutsq.p, cutsq.data(), cutsq.size() * sizeof(double), hipMemcpyHostToDevice, s));
@@ -460,10 +481,12 @@ int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const i
     run_model(m, a);
 
     m->h_f.resize((size_t)nall * 3);
+    pin_host(m, m->h_f);
     double ev[7];
     AHIP_CHECK(hipMemcpyAsync(m->h_f.data(), m->b_f.p, (size_t)nall * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     if (want_eatom) {
       m->h_eatom.resize(nall);
+      pin_host(m, m->h_eatom);
       AHIP_CHECK(hipMemcpyAsync(m->h_eatom.data(), m->b_eatom.p, (size_t)nall * sizeof(double), hipMemcpyDeviceToHost, s));
     }
     AHIP_CHECK(hipMemcpyAsync(ev, m->b_engvir.p, 7 * sizeof(double), hipMemcpyDeviceToHost, s));

@@ -117,7 +117,8 @@ struct Model {
   // per-call host-path staging
   DevBuf b_x, b_ftype, b_mtype, b_f, b_eatom, b_engvir, b_cutsq, b_flagwork;
   std::vector<int> h_ftype, h_mtype;
-  std::vector<double> h_f, h_eatom, h_cutsq_dev;      // h_cutsq_dev: what b_cutsq currently holds (device path)
+  std::vector<double> h_x, h_f, h_eatom, h_cutsq_dev;      // h_cutsq_dev: what b_cutsq currently holds (device path); h_x: page-locked copy of the caller's positions
+  std::map<const void *, std::pair<void *, size_t>> pinned;   // host vectors currently page-locked (allegro_hip.hip: pin_host)
 
   // edge list + workspace
   DevBuf b_cnt, b_eoff, b_eii, b_ej, b_rvec, b_partial, b_ws, b_misc;

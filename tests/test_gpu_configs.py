@@ -140,7 +140,7 @@ def _edges_of(lib, path, rs, mapper, cm, options=None):
     return ei, rij, info
 
 
-@pytest.mark.parametrize("case", ["si_single_pass", "cu_r15_two_pass", "cupd_2x2x1_ghosts", "shuffled_rows"])
+@pytest.mark.parametrize("case", ["si_single_pass", "si_single_pass_dynamic", "cu_r15_two_pass", "cupd_2x2x1_ghosts", "shuffled_rows"])
 def test_edge_index_ordered_bit_exact(hip_lib, model_dir, case):
     """ahip_get_edges == the reference's edge_index, ELEMENT BY ELEMENT: grouped by centre in ilist order, neighbours in list
     order, ghost indices kept (pair_nequip_allegro.cpp:566-629, restated in oracle/glue.py::preprocess).  Covers the
@@ -148,9 +148,13 @@ def test_edge_index_ordered_bit_exact(hip_lib, model_dir, case):
     scrambled (non-sorted) order."""
     cfg = model_file.model_S(type_names=["Cu", "Pd"])
     rng = np.random.RandomState(5)
-    if case == "si_single_pass":
+    options = None
+    if case.startswith("si_single_pass"):
         cfg = model_file.model_S()
-        cell, pos, types = lmp_like.diamond_si(5)
+        # 13 824 atoms = 216 scan units of 64 centres: more units than one claim per workgroup
+        cell, pos, types = lmp_like.diamond_si(12 if case.endswith("dynamic") else 5)
+        if case.endswith("dynamic"):
+            options = {"edge_schedule": "dynamic"}         # one ticket per scan unit (no co-residency assumption): same list, same order
         rs = lmp_like.build_rank_system(cell, pos, types, 6.0)
         names = ["Si"]
     elif case == "cu_r15_two_pass":
@@ -169,7 +173,7 @@ def test_edge_index_ordered_bit_exact(hip_lib, model_dir, case):
     path, _ = _export(model_dir, "edges_" + case, cfg)
     mapper = np.array([cfg["type_names"].index(s) for s in names], dtype=np.int32)
     cm = np.full((len(names), len(names)), cfg["r_max"])
-    ei, rij, (used, maxdeg) = _edges_of(hip_lib, path, rs, mapper, cm)
+    ei, rij, (used, maxdeg) = _edges_of(hip_lib, path, rs, mapper, cm, options)
     ref = glue.preprocess(rs.x, rs.type, rs.nlocal, rs.ilist, rs.numneigh, rs.firstneigh, mapper, cm)["edge_index"]
     assert ei.dtype == np.int64 and ei.shape == ref.shape
     assert np.array_equal(ei, ref)

@@ -38,7 +38,8 @@
 
 #include "../../include/allegro_hip.h"
 #ifndef AHIP_ROW_AUX
-#define AHIP_ROW_AUX 2          // saved rows: non-temporal (fused_common.h)
+#define AHIP_ROW_AUX 0          // saved rows: default cache policy.  (fused_lx.hip streams them non-temporally, which paid while that kernel spilled 1.4 KB per lane; here, with 50 dwords
+                                // of spill traffic per wave-tile, the default policy is 4 % faster: 25.65 vs 26.8 ms on the 41k-atom water box; sc0 26.65, sc0 + nt 26.9)
 #endif
 #define AHIP_NO_ACC_PARK 1
 #include "engine.h"

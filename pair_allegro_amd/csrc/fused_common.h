@@ -45,9 +45,13 @@ __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, int voff, int s
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, AHIP_ROW_AUX);
 }
 #endif
+#ifdef ABL_NOW       // timing experiment only (results are wrong): no weight-fragment traffic
+__device__ __forceinline__ f32x4 bload_w(__amdgpu_buffer_rsrc_t, int voff, int soff) { const float q = __builtin_bit_cast(float, ((voff + soff) & 0xffff) | 0x3c000000); return f32x4{q, q, q, q}; }
+#else
 __device__ __forceinline__ f32x4 bload_w(__amdgpu_buffer_rsrc_t r, int voff, int soff) {        // weight fragments: default policy
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+#endif
 
 __device__ __forceinline__ float sigmoidf_fast(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
 __device__ __forceinline__ float silu1(float z) { return z * sigmoidf_fast(z); }

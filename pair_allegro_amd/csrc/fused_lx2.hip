@@ -64,6 +64,7 @@ struct ShapeP {
 struct __attribute__((aligned(16))) LdsP {
   using S = ShapeP;
   float stage[2][S::SLOTS * S::STG_LD];      // [wave half][slot][lm][16]: one K-tile of each half
+  float zero16[4];                           // zeros: where the per-centre reduction's reads past a centre's last slot land
   float env[LX_MAXNL][S::MAXA * S::ENVA];
   float denv[S::MAXA * S::ENVA];
   float tp[LX_MAXNL][S::NP * S::U];          // tensor-product path weights [layer][path][u]
@@ -80,9 +81,12 @@ struct __attribute__((aligned(16))) LdsP {
 };
 static_assert(sizeof(LdsP) <= 160 * 1024, "LDS budget of one CU");
 
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void *)p; }
 // Per-centre sum of the two staged K-tiles (one per wave half): env[a][lm][16 (2 h + t) + f] = scale * sum_{slots of a} stage[h][slot][lm][f].
 // Work item = (centre, half, 4-feature column); 4 lanes per item take every 4th slot (see reduce_stage_x in fused_lx.hip for the lane mapping).
-__device__ __forceinline__ void reduce_stage_p(const float *stg, const int *aoff, float *dst, int na, float scale, int t, int uwave) {
+// A lane's reads past its centre's last slot go to a 16-byte block of zeros behind the staging area (one select per read) instead of
+// being masked out of the sum value by value: 105 instead of 216 vector instructions per call, twelve calls per tile.
+__device__ __forceinline__ void reduce_stage_p(const float *stg, const float *zero16, const int *aoff, float *dst, int na, float scale, int t, int uwave) {
   using S = ShapeP;
   constexpr int LPI = 4, NC1 = S::D * 4, NC = 2 * NC1, PER_ROUND = S::NW * 64 / LPI, NRD = S::SLOTS / LPI;
   const int lane = fresh_lane();
@@ -91,20 +95,26 @@ __device__ __forceinline__ void reduce_stage_p(const float *stg, const int *aoff
     const bool live = it < na * NC;
     const int a = live ? it / NC : 0, c2 = live ? it - a * NC : 0;
     const int h = c2 >= NC1 ? 1 : 0, c = c2 - h * NC1;
-    const float *sh = stg + h * (S::SLOTS * S::STG_LD) + 4 * c;
     const int s0 = aoff[a] + p, s1 = live ? aoff[a + 1] : 0;
+    const float *sh = stg + h * (S::SLOTS * S::STG_LD) + 4 * c + s0 * S::STG_LD;
+    const int cnt = (s1 - s0 + LPI - 1) >> 2;          // reads of this lane that fall inside the centre's slots (<= 0: none)
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    // batches of RB reads in flight, issued and waited for by hand: left to itself the scheduler (short of registers here) waits for
+    // every read before it issues the next one, 16 LDS round trips in a row with all eight waves of the CU in this same phase
+    constexpr int RB = 4;
+    const unsigned shb = lds_addr(sh), zb = lds_addr(zero16);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {          // two batches of 8 reads in flight
-      f32x4 v[NRD / 2];
+    for (int b = 0; b < NRD / RB; ++b) {
+      f32x4 v[RB];
 #pragma unroll
-      for (int k = 0; k < NRD / 2; ++k) {
-        const int sl = s0 + LPI * (k + b * (NRD / 2));
-        v[k] = *(const f32x4 *)(sh + (sl < s1 ? sl : 0) * S::STG_LD);
+      for (int k = 0; k < RB; ++k) {
+        const int kk = k + b * RB;
+        const unsigned ad = kk < cnt ? shb + kk * (LPI * S::STG_LD * 4) : zb;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v[k]) : "v"(ad));
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));      // the sums below consume the values as they leave this statement
 #pragma unroll
-      for (int k = 0; k < NRD / 2; ++k)
-        if ((s0 + LPI * (k + b * (NRD / 2))) < s1) acc += v[k];
+      for (int k = 0; k < RB; ++k) acc += v[k];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -225,6 +235,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
   int wp = wp0;
   ring_prime(WB, wp, V16(), ring);
   if (tid < MAXA) lds.eacc[tid] = 0.0;
+  if (tid < 4) lds.zero16[tid] = 0.f;
   if (hf == 0 && lane < 6) lds.virw[q][lane] = 0.0;
   if (tid < A.T * A.T) lds.rc[tid] = (float)A.rcut[tid];
   if (tid < A.T) { lds.scale[tid] = Wb[A.o_scale + tid]; lds.shift[tid] = Wb[A.o_shift + tid]; }
@@ -343,7 +354,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
           for (int lm = 0; lm < D; ++lm) *(f32x4 *)(stw + lm * 16) = lm == 0 ? om[t] : om[l_of_lm(lm) * HT + t] * Y[lm];
           __syncthreads();
           #ifndef ABL_NOREDUCE
-          reduce_stage_p(lds.stage[0], aoffp, envk, na, A.cenv, t, uwave);
+          reduce_stage_p(lds.stage[0], lds.zero16, aoffp, envk, na, A.cenv, t, uwave);
 #endif
           __builtin_amdgcn_sched_barrier(0);
           __syncthreads();
@@ -570,7 +581,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
           if (t == HT - 1) load_rows<L * HT>(SB, RL + S::O_OM + HT, omall, V16());
           __syncthreads();
           #ifndef ABL_NOREDUCE
-          reduce_stage_p(lds.stage[0], aoffp, lds.denv, na, A.cenv, t, uwave);
+          reduce_stage_p(lds.stage[0], lds.zero16, aoffp, lds.denv, na, A.cenv, t, uwave);
 #endif
           __builtin_amdgcn_sched_barrier(0);
           __syncthreads();

@@ -219,6 +219,10 @@ __device__ __forceinline__ void tp_g(const f32x2 (&A)[NA], const f32x2 (&B)[NB],
   for (int k = 0; k < NO; ++k) O[k] = f32x2{0.f, 0.f};
   f32x2 sa[2 * L + 1];
   f32x2 s = f32x2{0.f, 0.f};
+  // the path weights are requested ONE PATH AHEAD (the tables run through the paths 0, 1, 2, ... in order): read where a path starts, every
+  // path began with an LDS round trip that nothing covered -- 15 per table pass, 12 passes per layer
+  f32x2 pwn = f32x2{0.f, 0.f};
+  if (!SCALAR) pwn = *(const f32x2 *)(tp + CgG<L, VAR>::tab[0].path * U);
 #pragma unroll
   for (int q = 0; q < N; ++q) {
     constexpr const AhipCgG *tab = CgG<L, VAR>::tab;
@@ -226,7 +230,12 @@ __device__ __forceinline__ void tp_g(const f32x2 (&A)[NA], const f32x2 (&B)[NB],
     if (!(SCALAR && l3 != 0)) {
       const int la = l_of_lm(tab[q].a), ba = la * la;
       if (q == 0 || tab[q - 1].path != tab[q].path) {
-        const f32x2 pwp = *(const f32x2 *)(tp + tab[q].path * U);
+        f32x2 pwp;
+        if (SCALAR) pwp = *(const f32x2 *)(tp + tab[q].path * U);
+        else {
+          pwp = pwn;
+          if (tab[q].path + 1 < CgX<L>::NP) pwn = *(const f32x2 *)(tp + (tab[q].path + 1) * U);
+        }
 #pragma unroll
         for (int k = 0; k < 2 * L + 1; ++k)
           if (k < 2 * la + 1) sa[k] = pwp * A[ba + k];

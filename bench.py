@@ -38,9 +38,10 @@ SI_MASS = 28.0855
 
 # Algorithmic work per edge of model S (DESIGN.md "Roofline accounting"): MACs of every dense
 # contraction, forward; the backward pass needs input gradients only, i.e. the same MAC count again.
-def model_macs_per_edge(cfg, two_body_tabulated=False):
+def model_macs_per_edge(cfg, two_body_tabulated=False, readout_folded=False):
     """Dense multiply-accumulates per edge of one forward pass.  With the fused kernel's tabulated two-body embedding
-    (default) the two-body MLP is not executed per edge and is left out of the count."""
+    (default) the two-body MLP is not executed per edge and is left out of the count; readout_folded: k_fused
+    multiplies the last layer's third latent linear into the read-out's first one (W -> S and S -> R become W -> R and S -> R)."""
     T = len(cfg["type_names"]); B = cfg["num_bessels"]; S = cfg["num_scalar_features"]
     U = cfg["num_tensor_features"]; L = cfg["l_max"]; W = cfg["mlp_width"]; R = cfg["readout_width"]
     NL = cfg["num_layers"]; D = (L + 1) ** 2; dep = cfg["mlp_depth"]
@@ -53,6 +54,8 @@ def model_macs_per_edge(cfg, two_body_tabulated=False):
         if k < NL:
             fwd += U * U * D
     fwd += mlp(S, cfg["readout_depth"], R, 1)
+    if readout_folded:
+        fwd += (W * R + S * R) - (W * S + S * R)
     return fwd
 
 
@@ -221,7 +224,7 @@ def main():
         # ALGORITHMIC flops = the model's dense contractions (SURVEY 8d / DESIGN 4.2), whatever the kernel does with them;
         # the fused kernels' tabulated two-body embedding executes fewer: frac_executed is priced on those.
         flops_per_edge = 2.0 * model_macs_per_edge(cfg) * 2.0       # 2 flop per MAC x (forward + input-gradient backward)
-        executed_flops_per_edge = 2.0 * model_macs_per_edge(cfg, two_body_tabulated=tb_tab) * 2.0
+        executed_flops_per_edge = 2.0 * model_macs_per_edge(cfg, two_body_tabulated=tb_tab, readout_folded=tb_tab and cfg["l_max"] == 1) * 2.0
         edges_rank0 = int(np.mean(edges_step))          # all centres of this rank (summed over the calls of a step)
         stage_avg = {k: float(np.mean(v)) for k, v in stage_ms.items()}
         dom = max((k for k in stage_avg if k.startswith("model")), key=lambda k: stage_avg[k], default=None)

@@ -280,7 +280,7 @@ __device__ __forceinline__ void lin(__amdgpu_buffer_rsrc_t W, int &wp, const f32
   }
 }
 
-template <int NW, bool PROF, int AR, bool TBT>
+template <int NW, bool PROF, int AR, bool TBT, int NLT>
 __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
   constexpr int NTHREADS = NW * 64, MAXA = Lds<NW>::MAXA;
   __shared__ Lds<NW> lds;
@@ -300,7 +300,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     lds.tp[k / 160][k % 160] = Wb[A.o_tpl + k] * (pth == 1 ? C_P1 : pth == 4 ? C_P4 : 1.f);
   }
   const int ntiles = *A.ntiles;
-  const int NL = A.NL;
+  // The layer count is a template parameter and both layer loops are unrolled: "last layer" is then a compile-time fact (the folded
+  // read-out below has a different shape there), nothing is carried around a loop edge, and the register allocation of each layer
+  // is its own.  With a run-time loop the same fold cost more in spills than its 64 MFMAs saved (64.3 -> 67.7 ms; unrolled: 61.0).
+  constexpr int NL = NLT;
   double acc_part = 0.0;       // thread 0: energy; threads 64..69: virial components
   long long pacc[PH_N];
   long long tprev = 0;
@@ -428,6 +431,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     PHASE(PH_EMB);
 
     // ---------------- layers, forward ----------------
+    f32x4 zr[2];               // read-out pre-activations: produced by the last layer (see its latent MLP)
+#pragma unroll
     for (int kk = 0; kk < NL; ++kk) {
       const bool last = (kk == NL - 1);
       const int RL = R_LAYER(kk);
@@ -504,9 +509,20 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         lin<AR, 6, 4, false, 0>(WB, wp, cat, z, v16, ring, EpiSiluSaveD{SB, RL + 4, v16});
         lin<AR, 4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, RL + 8, v16});
         const float ra = lds.res[kk][0], rbf = lds.res[kk][1] * fc;
-        f32x4 xn[4];
-        lin<AR, 4, 4, false, 0>(WB, wp, z2, xn, v16, ring, EpiResidual<4>{{SB, RL + 12, v16}, x, ra, rbf});
-        x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2]; x[3] = xn[3];
+        if (!last) {
+          f32x4 xn[4];
+          lin<AR, 4, 4, false, 0>(WB, wp, z2, xn, v16, ring, EpiResidual<4>{{SB, RL + 12, v16}, x, ra, rbf});
+          x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2]; x[3] = xn[3];
+        } else {
+          // Last layer: its new latent x' = ra x + rb fc (z2 W3) feeds nothing but the read-out's first linear, and no non-linearity
+          // sits between the two, so  x' Wr = ra (x Wr) + rb fc (z2 (W3 Wr))  with W3 Wr multiplied out by the host in float64: two
+          // 64 -> 32 linears instead of a 64 -> 64 and a 64 -> 32 one, here and (transposed) in the backward pass: 64 of the tile's
+          // 1776 MFMAs per wave and two saved rows less.  z2 first: it dies there.
+          f32x4 za[2], up[2];
+          lin<AR, 4, 2, false, 0>(WB, wp, z2, up, v16, ring, EpiSave{SB, RL + 12, v16});
+          lin<AR, 4, 2, false, 0>(WB, wp, x, za, v16, ring, EpiNone{});
+          zr[0] = ra * za[0] + rbf * up[0]; zr[1] = ra * za[1] + rbf * up[1];
+        }
       }
       PHASE(PH_LAT);
     }
@@ -515,11 +531,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     // saved rows are requested one linear ahead of their first use all through the backward pass (their
     // round trip is an L2 miss: ~2 us): u and z2 of the last layer now, under the read-out MFMAs
     f32x4 upre[4], zt[4], w0h[2];
-    load_rows<4>(SB, R_LAYER(NL - 1) + 12, upre, v16);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) upre[t] = bload(SB, v16, (R_LAYER(NL - 1) + 12 + t) * ROW * 4);       // the last layer saved two rows: z2 (W3 Wr)
     load_rows<4>(SB, R_LAYER(NL - 1) + 8, zt, v16);
     __builtin_amdgcn_sched_barrier(0);
-    f32x4 zr[2];
-    lin<AR, 4, 2, false, 0>(WB, wp, x, zr, v16, ring, EpiNone{});
     f32x4 wo1[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) wo1[t] = *(const f32x4 *)(Wb + A.o_out1 + 16 * t + 4 * g);
@@ -534,24 +549,24 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     // =========================== backward ===========================
     const float deps = valid ? lds.scale[ti] * A.cenv : 0.f;
     f32x4 dx[4];
-    {
-      f32x4 dzr[2];
+    f32x4 dzr[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dzr[t][r] = deps * wo1[t][r] * dsilu1(zr[t][r]);
-      lin<AR, 2, 4, false, 0>(WB, wp, dzr, dx, v16, ring, EpiNone{});
-    }
+      for (int r = 0; r < 4; ++r) dzr[t][r] = deps * wo1[t][r] * dsilu1(zr[t][r]);
+    lin<AR, 2, 4, false, 0>(WB, wp, dzr, dx, v16, ring, EpiNone{});               // dzr Wr^T = the gradient w.r.t. x' of the last layer
     float dfc_part = 0.f, dY1 = 0.f, dY2 = 0.f, dY3 = 0.f;
     PHASE(PH_OUT);
 
+#pragma unroll
     for (int kk = NL - 1; kk >= 0; --kk) {
       const bool last = (kk == NL - 1);
       const int RL = R_LAYER(kk);
       f32x4 dVp[4][2], Vk[4][2], W0b[4];
       {
         f32x4 du[4], dh[4];
-        {
+        f32x4 zt1[4];
+        if (!last) {
           const float ra = lds.res[kk][0], rb = lds.res[kk][1];
           f32x4 accv = upre[0] * dx[0];
 #pragma unroll
@@ -560,11 +575,25 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) { du[t] = rbfc * dx[t]; dx[t] = ra * dx[t]; }
           dfc_part += rb * ((accv[0] + accv[1]) + (accv[2] + accv[3]));
+          load_rows<4>(SB, RL + 4, zt1, v16);                  // z1: first used 96 MFMAs from here
+          __builtin_amdgcn_sched_barrier(0);
+          lin<AR, 4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt});
+        } else {
+          // last layer (read-out folded in, see the forward pass): upre = the two rows z2 (W3 Wr); the z2 gradient comes straight
+          // from dzr through (W3 Wr)^T
+          const float ra = lds.res[kk][0], rb = lds.res[kk][1];
+          const f32x4 accv = upre[0] * dzr[0] + upre[1] * dzr[1];
+          const float rbfc = rb * fc;
+          f32x4 du2[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) du2[t] = rbfc * dzr[t];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) dx[t] = ra * dx[t];
+          dfc_part += rb * ((accv[0] + accv[1]) + (accv[2] + accv[3]));
+          load_rows<4>(SB, RL + 4, zt1, v16);
+          __builtin_amdgcn_sched_barrier(0);
+          lin<AR, 2, 4, false, 0>(WB, wp, du2, dh, v16, ring, EpiMulRows<4>{zt});
         }
-        f32x4 zt1[4];
-        load_rows<4>(SB, RL + 4, zt1, v16);                  // z1: first used 96 MFMAs from here
-        __builtin_amdgcn_sched_barrier(0);
-        lin<AR, 4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt});
         // prefetch V^{kk} (input of this layer's tensor product) under the MFMAs that follow
         if (kk > 0) {
 #pragma unroll
@@ -908,6 +937,13 @@ static void fused_prepare(Model &m) {
   };
   auto T_ = [&](const std::string &name) -> const double * { return h.get(name).data.data(); };
   const double *wc = w0.data.data() + (size_t)2 * T * 64;       // Bessel block [8][64]
+  std::vector<double> w3r((size_t)64 * 32, 0.0);                // W3 (last layer) @ Wr (read-out), float64
+  {
+    const double *W3 = T_("l" + std::to_string(NL) + ".lat.w2"), *Wr = T_("out.w0");
+    for (int i = 0; i < 64; ++i)
+      for (int q = 0; q < 64; ++q)
+        for (int n = 0; n < 32; ++n) w3r[(size_t)i * 32 + n] += W3[(size_t)i * 64 + q] * Wr[(size_t)q * 32 + n];
+  }
   if (!tbt) {
     fwd(wc, 8, 64);
     fwd(T_("tb.w1"), 64, 64);
@@ -924,13 +960,17 @@ static void fused_prepare(Model &m) {
     }
     fwd(T_(lk + ".lat.w0"), 96, 64);
     fwd(T_(lk + ".lat.w1"), 64, 64);
-    fwd(T_(lk + ".lat.w2"), 64, 64);
+    if (k < NL - 1) fwd(T_(lk + ".lat.w2"), 64, 64);
+    else {            // last layer: the read-out's first linear applied, multiplied into W3, to z2 and then to x (k_fused, latent MLP)
+      fwd(w3r.data(), 64, 32);
+      fwd(T_("out.w0"), 64, 32);
+    }
   }
-  fwd(T_("out.w0"), 64, 32);
   bwd(T_("out.w0"), 64, 32);
   for (int k = NL - 1; k >= 0; --k) {
     const std::string lk = "l" + std::to_string(k + 1);
-    bwd(T_(lk + ".lat.w2"), 64, 64);
+    if (k < NL - 1) bwd(T_(lk + ".lat.w2"), 64, 64);
+    else bwd(w3r.data(), 64, 32);
     bwd(T_(lk + ".lat.w1"), 64, 64);
     bwd(T_(lk + ".lat.w0"), 96, 64);
     if (k < NL - 1) {
@@ -1054,7 +1094,8 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
       AHIP_CHECK(hipMemsetAsync(st.prof.p, 0, (64 + 4 * (size_t)grid) * sizeof(long long), s));
       A.prof = st.prof.as<long long>();
     }
-#define AHIP_LAUNCH(NWV, PROFV, B3V, TBV) hipLaunchKernelGGL((k_fused<NWV, PROFV, B3V, TBV>), dim3(grid), dim3(NWV * 64), 0, s, A)
+#define AHIP_LAUNCH_NL(NWV, PROFV, B3V, TBV, NLV) hipLaunchKernelGGL((k_fused<NWV, PROFV, B3V, TBV, NLV>), dim3(grid), dim3(NWV * 64), 0, s, A)
+#define AHIP_LAUNCH(NWV, PROFV, B3V, TBV) do { if (A.NL == 1) AHIP_LAUNCH_NL(NWV, PROFV, B3V, TBV, 1); else if (A.NL == 2) AHIP_LAUNCH_NL(NWV, PROFV, B3V, TBV, 2); else AHIP_LAUNCH_NL(NWV, PROFV, B3V, TBV, 3); } while (0)
 #define AHIP_LAUNCH_TB(NWV, PROFV, B3V) do { if (st.tbt) AHIP_LAUNCH(NWV, PROFV, B3V, true); else AHIP_LAUNCH(NWV, PROFV, B3V, false); } while (0)
 #define AHIP_LAUNCH_NW(PROFV, B3V) do { if (nw == 4) AHIP_LAUNCH_TB(4, PROFV, B3V); else AHIP_LAUNCH_TB(8, PROFV, B3V); } while (0)
     if (st.prof_on) {
@@ -1065,6 +1106,7 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
 #undef AHIP_LAUNCH_NW
 #undef AHIP_LAUNCH_TB
 #undef AHIP_LAUNCH
+#undef AHIP_LAUNCH_NL
   }
   AHIP_CHECK(hipGetLastError());
   AHIP_CHECK(prim_sum_columns_f64(m.prim, st.partial.as<double>(), grid, 7, a.engvir, s));

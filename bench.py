@@ -148,13 +148,24 @@ def main():
     dist = None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: allegro-hip has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # AHIP_BENCH_ONE_DEVICE=1 (debugging / tests only, tests/test_gpu_md.py): every rank runs on cuda:0 and the messages are staged
+    # through gloo -- RCCL does not form a communicator between processes that share a GPU.  It exercises this file's multi-rank
+    # logic (decomposition, max-over-ranks timing, the JSON line) on a 1-GPU box; its numbers are not benchmark numbers.
+    one_device = world > 1 and os.environ.get("AHIP_BENCH_ONE_DEVICE") == "1"
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    dist_raw = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", device_id=device)
-        dist = dist_mod
+        dist_raw = dist_mod
+        if one_device:
+            dist_mod.init_process_group(backend="gloo")
+            dist = md.HostStagedDist(dist_mod)
+        else:
+            dist_mod.init_process_group(backend="nccl", device_id=device)
+            dist = dist_mod
 
     wl = workload(args.config, args.ncell)
     cfg = wl["cfg"]
@@ -164,7 +175,9 @@ def main():
     model_file.save_ahip(model_path, cfg, weights)
 
     lib = capi.Library()
-    model = capi.Model(model_path, local_rank, lib)
+    model = capi.Model(model_path, dev_index, lib)
+    if one_device:
+        model.set_option("edge_schedule", "dynamic")      # several processes share the GPU: no resident-grid assumption
     model.set_option("path", args.path)
     model.set_option("timing", "1")
 
@@ -270,7 +283,7 @@ def main():
         max_df = None
         parity = None
         if not args.no_cpu_baseline and world == 1:       # reported baseline: rank 0 at N = 1 only
-            cpu, parity = cpu_baseline_and_parity(lib, args.config, local_rank, args.cpu_sample_ncell, args.path)
+            cpu, parity = cpu_baseline_and_parity(lib, args.config, dev_index, args.cpu_sample_ncell, args.path)
             max_df = parity["max_abs_dF"]
         out = {
             "metric": "atom_steps_per_sec", "value": round(value, 1), "unit": "atom-steps/s", "n_gpus": world,
@@ -294,7 +307,7 @@ def main():
     model.close()
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        dist_raw.destroy_process_group()
 
 
 def cpu_sample(config: int, ncell: int):

@@ -121,3 +121,32 @@ def test_multi_rank_on_one_gpu(hip_lib, model_dir, tmp_path, world, port):
         assert np.abs(z["x" + k] - z["x1"]).max() < 1e-7
         np.testing.assert_allclose(z["e" + k], z["e1"], rtol=2e-7)
         np.testing.assert_allclose(z["v" + k], z["v1"], atol=2e-2, rtol=1e-4)
+
+
+@pytest.mark.parametrize("launcher", ["spawn", "torchrun"])
+def test_bench_two_ranks_on_one_gpu(launcher):
+    """`bench.py --gpus 2` end to end on a 1-GPU box (AHIP_BENCH_ONE_DEVICE=1: both ranks on cuda:0, messages staged through gloo):
+    the rank start-up both ways the contract allows (bench.py's own spawn and `python -m torch.distributed.run`), the brick
+    decomposition, the overlapped schedule through the library's ghost exchange, max-over-ranks timing and the ONE JSON line of rank 0.
+    What it cannot cover is the RCCL communicator between two devices."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AHIP_BENCH_ONE_DEVICE="1", OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1")
+    args = ["--gpus", "2", "--config", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    if launcher == "spawn":
+        cmd = [sys.executable, os.path.join(root, "bench.py")] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", "29761", os.path.join(root, "bench.py")] + args
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2
+    assert d["metric"] == "atom_steps_per_sec" and d["value"] > 0 and d["higher_is_better"] is True
+    assert abs(d["value"] - 10648 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-3 * d["value"]        # whole-job atoms / max-over-ranks time
+    assert d["config"]["grid"] == "2x1x1" and d["config"]["kernel_path"] == "fused_f32"
+    assert d["config"]["comm"] == "overlapped" and d["config"]["comm_transport"].startswith("library/")

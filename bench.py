@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-ncell", type=int, default=11)
     ap.add_argument("--no-overlap", action="store_true", help="serial ghost exchange (A/B against the overlapped schedule)")
+    ap.add_argument("--force-overlap", action="store_true", help="overlapped three-range schedule even on one rank (A/B: what the schedule itself costs)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -189,7 +190,7 @@ def main():
     grid = md.choose_grid(world)
     backend = md.HipBackend(model, wl["masses"])
     sim = md.Simulation(backend, box, cfg["r_max"], 1.0, pos, wl["mtype"], vel, device,
-                        grid=grid, rank=rank, dist=dist, dt=0.001, overlap=False if args.no_overlap else None)
+                        grid=grid, rank=rank, dist=dist, dt=0.001, overlap=False if args.no_overlap else (True if args.force_overlap else None))
     sim.setup()
     for _ in range(args.warmup):
         sim.step()

@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
           // Last layer: its new latent x' = ra x + rb fc (z2 W3) feeds nothing but the read-out's first linear, and no non-linearity
           // sits between the two, so  x' Wr = ra (x Wr) + rb fc (z2 (W3 Wr))  with W3 Wr multiplied out by the host in float64: two
           // 64 -> 32 linears instead of a 64 -> 64 and a 64 -> 32 one, here and (transposed) in the backward pass: 64 of the tile's
-          // 1776 MFMAs per wave and two saved rows less.  z2 first: it dies there.
+          // 1472 MFMAs per wave and two saved rows less.  z2 first: it dies there.
           f32x4 za[2], up[2];
           lin<AR, 4, 2, false, 0>(WB, wp, z2, up, v16, ring, EpiSave{SB, RL + 12, v16});
           lin<AR, 4, 2, false, 0>(WB, wp, x, za, v16, ring, EpiNone{});
@@ -1082,6 +1082,7 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
   // claims of TCHUNK tiles amortise the counter's round trip; with few tiles per workgroup the last claim decides the makespan
   // (10 648 Si atoms: 4 659 tiles on 512 workgroups = 12 instead of 10 tile times with claims of 4)
   A.tchunk = (m.nedges / tile_slots > (long long)grid * 256) ? TCHUNK : 1;
+  if (const char *tc = std::getenv("AHIP_TCHUNK")) A.tchunk = std::max(1, std::atoi(tc));       // experiments
   A.f = a.f; A.eatom = a.eatom; A.partial = st.partial.as<double>();
   {
     StageTimer tm(m, "model_fused", s);

@@ -96,7 +96,8 @@ def kernel_source_hash() -> str:
     import glob
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "pair_allegro_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "pair_allegro_amd", "csrc", "*.h"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "pair_allegro_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "pair_allegro_amd", "csrc", "*.h"))
+                    + [os.path.join(ROOT, "pair_allegro_amd", "csrc", "Makefile")]):      # the Makefile carries per-kernel compiler options
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 

@@ -15,7 +15,10 @@ namespace ahip {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 static constexpr int SEG = 128;          // atoms per sequential packing segment (one thread walks a segment: the chain of 512 cost 0.08 ms per pass whatever the system size; a segment ends its last tile early: < 1 % more tiles)
 static constexpr int ROW = 256;          // floats per saved register image of one 16-feature tile (4 regs x 64 lanes)
-static constexpr int RING = 8;           // weight fragments in flight per wave
+#ifndef AHIP_RING
+#define AHIP_RING 8
+#endif
+static constexpr int RING = AHIP_RING;   // weight fragments in flight per wave
 static constexpr int TCHUNK = 4;         // tiles per claim of the dynamic tile schedule
 
 __host__ __device__ inline int feat16(int t, int r, int g) { return 16 * t + 4 * g + r; }

@@ -96,9 +96,12 @@ def kernel_source_hash() -> str:
     import glob
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "pair_allegro_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "pair_allegro_amd", "csrc", "*.h"))
-                    + [os.path.join(ROOT, "pair_allegro_amd", "csrc", "Makefile")]):      # the Makefile carries per-kernel compiler options
+    for f in sorted(glob.glob(os.path.join(ROOT, "pair_allegro_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "pair_allegro_amd", "csrc", "*.h"))):
         h.update(open(f, "rb").read())
+    # the Makefile carries per-kernel compiler options: its rules count, its comments do not
+    for line in open(os.path.join(ROOT, "pair_allegro_amd", "csrc", "Makefile"), "rb").read().splitlines():
+        if not line.lstrip().startswith(b"#"):
+            h.update(line + b"\n")
     return h.hexdigest()[:16]
 
 

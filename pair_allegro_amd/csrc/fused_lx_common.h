@@ -66,19 +66,27 @@ static void lx_pack_tiles(Model &m, FusedLxState &st, const ComputeArgs &a, int 
   st.tile_e0.reserve((size_t)(inum + nseg + 2) * sizeof(int));
   StageTimer tm(m, "tile_pack", s);
   const unsigned B = 64;
-  hipLaunchKernelGGL(k_pack_tiles<false>, dim3((nseg + B - 1) / B), dim3(B), 0, s, inum, m.b_eoff.as<int>(), nseg, st.seg_count.as<int>(), (const int *)nullptr, (int *)nullptr, slots, maxa);
-  AHIP_CHECK(prim_exclusive_scan_i32(m.prim, st.seg_count.as<int>(), st.seg_base.as<int>(), nseg, s));
-  hipLaunchKernelGGL(k_pack_tiles<true>, dim3((nseg + B - 1) / B), dim3(B), 0, s, inum, m.b_eoff.as<int>(), nseg, (int *)nullptr, st.seg_base.as<int>(), st.tile_a0.as<int>(), slots, maxa);
-  hipLaunchKernelGGL(k_pack_finish, dim3(1), dim3(1), 0, s, inum, nseg, st.seg_base.as<int>(), st.tile_a0.as<int>(), st.ntiles.as<int>());
-  const int tcap = inum + nseg + 1;
   st.centre.reserve((size_t)std::max(inum, 1) * sizeof(int2));
-  hipLaunchKernelGGL(k_centre_info, dim3((inum + 255) / 256), dim3(256), 0, s, inum, m.d_ilist, a.mtype, st.centre.as<int2>());
+  const bool small = nseg <= PACK_SMALL_SEGS;
+  if (small)
+    hipLaunchKernelGGL(k_pack_small, dim3(1), dim3(PACK_SMALL_SEGS), 0, s, inum, m.b_eoff.as<int>(), nseg, st.tile_a0.as<int>(), st.tile_e0.as<int>(), st.ntiles.as<int>(), slots, maxa,
+                       m.d_ilist, a.mtype, st.centre.as<int2>());
+  else {
+    hipLaunchKernelGGL(k_pack_tiles<false>, dim3((nseg + B - 1) / B), dim3(B), 0, s, inum, m.b_eoff.as<int>(), nseg, st.seg_count.as<int>(), (const int *)nullptr, (int *)nullptr, slots, maxa);
+    AHIP_CHECK(prim_exclusive_scan_i32(m.prim, st.seg_count.as<int>(), st.seg_base.as<int>(), nseg, s));
+    hipLaunchKernelGGL(k_pack_tiles<true>, dim3((nseg + B - 1) / B), dim3(B), 0, s, inum, m.b_eoff.as<int>(), nseg, (int *)nullptr, st.seg_base.as<int>(), st.tile_a0.as<int>(), slots, maxa);
+    hipLaunchKernelGGL(k_pack_finish, dim3(1), dim3(1), 0, s, inum, nseg, st.seg_base.as<int>(), st.tile_a0.as<int>(), st.ntiles.as<int>());
+    hipLaunchKernelGGL(k_centre_info, dim3((inum + 255) / 256), dim3(256), 0, s, inum, m.d_ilist, a.mtype, st.centre.as<int2>());
+  }
   if (!m.have_ett) {
     m.b_ett.reserve((size_t)std::max<long long>(m.nedges, 1));
     hipLaunchKernelGGL(k_edge_types, dim3((unsigned)((m.nedges + 255) / 256)), dim3(256), 0, s, m.nedges, m.b_eii.as<int>(), m.b_ej.as<int>(), m.d_ilist, a.mtype, m.b_ett.as<unsigned char>());
     m.have_ett = true;
   }
-  hipLaunchKernelGGL(k_tile_e0, dim3((tcap + 255) / 256), dim3(256), 0, s, st.ntiles.as<int>(), st.tile_a0.as<int>(), m.b_eoff.as<int>(), st.tile_e0.as<int>());
+  if (!small) {
+    const int tcap = inum + nseg + 1;
+    hipLaunchKernelGGL(k_tile_e0, dim3((tcap + 255) / 256), dim3(256), 0, s, st.ntiles.as<int>(), st.tile_a0.as<int>(), m.b_eoff.as<int>(), st.tile_e0.as<int>());
+  }
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));

@@ -21,6 +21,11 @@ static constexpr int ROW = 256;          // floats per saved register image of o
 static constexpr int RING = AHIP_RING;   // weight fragments in flight per wave
 static constexpr int TCHUNK = 4;         // tiles per claim of the dynamic tile schedule
 
+// Switches that exist for timing experiments only and compute WRONG results (or drop a hazard pad) are refused outside an experiment build.
+#if (defined(ABL_NOROWS) || defined(ABL_NOW) || defined(AHIP_NO_STORE_PAD) || (defined(AHIP_LIN_WAIT_MODE) && AHIP_LIN_WAIT_MODE == 0)) && !defined(AHIP_EXPERIMENT_SWITCHES)
+#error "ABL_NOROWS / ABL_NOW / AHIP_NO_STORE_PAD / AHIP_LIN_WAIT_MODE=0 are timing-experiment switches (wrong results): add -DAHIP_EXPERIMENT_SWITCHES, never in the product build"
+#endif
+
 __host__ __device__ inline int feat16(int t, int r, int g) { return 16 * t + 4 * g + r; }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -44,8 +49,21 @@ __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t, int, int, f32x4 v
 __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AHIP_ROW_AUX));
 }
+// HAZARD (gfx950, found in round 4 by editing the assembly of a failing build one instruction class / region at a time, tools/asm_variant.sh):
+// a buffer_store_dwordx4 reads its 16 bytes of data AFTER it has issued; a VALU or MFMA instruction that overwrites one of the four data registers
+// in the next issue slot gets there first and the store writes the NEW value.  LLVM knows this hazard ("VMEM store of more than 8 bytes
+// followed by a write of its data registers", GCNHazardRecognizer::createsVALUHazard) and pads it -- except for MUBUF stores whose soffset is
+// an SGPR, which the ISA manuals exempt.  Every store here has its row offset in an SGPR, the saved rows die with the store, so the register
+// allocator hands the registers to the next instruction whenever the schedule allows it: wrong rows for the backward pass, only when no
+// other wave's instruction happens to be issued in between (forces off by a few per cent on a few edges, different ones on every launch;
+// rounds 2-3: "accumulator stores must have completed", "the bf16 instances break under two compiler options").  The s_nop below READS the
+// data registers (so nothing may overwrite them before it) and supplies the two wait states the hazard needs on gfx940+.
+// tools/store_hazard.hip reproduces it in 40 lines.
 __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, int voff, int soff, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, AHIP_ROW_AUX);
+#ifndef AHIP_NO_STORE_PAD          // experiment switch (tools/store_hazard.hip, A/B timing): builds the unsafe form
+  asm volatile("s_nop 1" ::"v"(v));
+#endif
 }
 #endif
 #ifdef ABL_NOW       // timing experiment only (results are wrong): no weight-fragment traffic

@@ -42,11 +42,9 @@
 #include "fused_common.h"
 #include "prims.h"
 
-// This file is compiled twice (Makefile): AHIP_FUSED_PART 0 = the host side + the f32-input MFMA instances of k_fused (fused.o, built with
-// scheduler / LICM options that this kernel profits from), AHIP_FUSED_PART 1 = the bf16-split instances (fused_bf.o, default options: the
-// two-term and three-term bf16 instances give WRONG forces -- a few per cent, different on every run -- when they are built with the
-// register-pressure trackers AND without machine LICM; either option alone is fine, waiting for every store and padding the MFMAs with
-// s_nops changes nothing.  Found by tests/test_gpu_fused.py, not understood: those instances keep the options they have always been tested with).
+// This file is compiled in two parts (Makefile; same options, halves the build time): AHIP_FUSED_PART 0 = the host side + the f32-input MFMA
+// instances of k_fused, AHIP_FUSED_PART 1 = the bf16-split instances.  (Rounds 2-3 gave part 1 other compiler options because it computed wrong
+// forces with part 0's: that was the store-data hazard described at fused_common.h: bstore, not the options.)
 #ifndef AHIP_FUSED_PART
 #define AHIP_FUSED_PART 0
 #endif

@@ -19,7 +19,8 @@ static constexpr int ROWS = 8;            // 1 KiB rows per wave and iteration: 
 static constexpr float GOOD = 1.0f, POISON = -7.0f;
 
 #define FILL(off) "buffer_store_dwordx4 v[14:17], %[vo], %[rs], 0 offen offset:" #off "\n"
-#define BODY(SOFF, PAD)                                                                                                      \
+#define BODY(SOFF, PAD) BODY2(SOFF, PAD, "v_mov_b32 v10, %[p]\n v_mov_b32 v11, %[p]\n v_mov_b32 v12, %[p]\n v_mov_b32 v13, %[p]\n")
+#define BODY2(SOFF, PAD, OVER)                                                                                                   \
   asm volatile("v_mov_b32 v10, %[g]\n v_mov_b32 v11, %[g]\n v_mov_b32 v12, %[g]\n v_mov_b32 v13, %[g]\n"                       \
                "v_mov_b32 v14, %[g]\n v_mov_b32 v15, %[g]\n v_mov_b32 v16, %[g]\n v_mov_b32 v17, %[g]\n s_nop 4\n"             \
                FILL(0) FILL(1024) FILL(2048) FILL(3072) "s_add_u32 %[so2], %[so], 4096\n"                                    \
@@ -27,7 +28,7 @@ static constexpr float GOOD = 1.0f, POISON = -7.0f;
                "buffer_store_dwordx4 v[14:17], %[vo], %[rs], %[so2] offen offset:1024\n"                                      \
                "buffer_store_dwordx4 v[14:17], %[vo], %[rs], %[so2] offen offset:2048\n"                                      \
                "buffer_store_dwordx4 v[10:13], %[vo], %[rs], " SOFF " offen offset:3072\n" /* the probed store */             \
-               PAD "v_mov_b32 v10, %[p]\n v_mov_b32 v11, %[p]\n v_mov_b32 v12, %[p]\n v_mov_b32 v13, %[p]\n"                   \
+               PAD OVER                                                                                                      \
                "s_waitcnt vmcnt(0)\n"                                                                                        \
                : [so2] "=&s"(so2)                                                                                            \
                : [g] "v"(good), [p] "v"(poison), [vo] "v"(voff), [rs] "s"(rs), [so] "s"(so)                                   \
@@ -50,6 +51,9 @@ template <int MODE> __global__ void __launch_bounds__(256) k_probe(float *out, i
     if (MODE == 0) BODY("%[so2]", "");
     if (MODE == 1) BODY("%[so2]", "s_nop 0\n");
     if (MODE == 2) BODY("%[so2]", "s_nop 1\n");
+    // the overwrite is an MFMA (the accumulator stores of a linear are followed by the next tile pair's first MFMA): all four registers become poison * 4 * 0 + ... = A x B with A = poison, B = 1
+    if (MODE == 8) BODY2("%[so2]", "", "v_mfma_f32_16x16x4_f32 v[10:13], %[p], %[g], 0\n s_nop 7\n");
+    if (MODE == 9) BODY2("%[so2]", "s_nop 0\n", "v_mfma_f32_16x16x4_f32 v[10:13], %[p], %[g], 0\n s_nop 7\n");
     if (MODE == 4) { BODY("0", ""); }
     if (MODE == 5) { BODY("0", "s_nop 0\n"); }
     if (MODE == 6) { BODY("0", "s_nop 1\n"); }
@@ -86,6 +90,8 @@ int main() {
   run<0>("soffset = SGPR, overwrite in the next slot");
   run<1>("soffset = SGPR, s_nop 0 (1 wait state)");
   run<2>("soffset = SGPR, s_nop 1 (2 wait states)");
+  run<8>("soffset = SGPR, MFMA writes the data registers");
+  run<9>("soffset = SGPR, s_nop 0, then the MFMA");
   run<4>("soffset = 0,    overwrite in the next slot");
   run<5>("soffset = 0,    s_nop 0 (1 wait state)");
   run<6>("soffset = 0,    s_nop 1 (2 wait states)");

@@ -105,23 +105,54 @@ def kernel_source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def spawn_ranks(n: int) -> int:
+def spawn_ranks(n: int, budget_s: float = None) -> int:
     """`python bench.py --gpus N` typed as is (no launcher): start N fresh rank processes BEFORE anything touches the GPU
-    (never re-exec a process that has initialised HIP) and relay their exit status; rank 0 prints the JSON line."""
+    (never re-exec a process that has initialised HIP) and relay their exit status; rank 0 prints the JSON line.
+    Fail fast: all children are polled; the first one that exits non-zero -- or a wall-clock budget
+    (AHIP_BENCH_BUDGET_S, default 900 s) running out -- ends the others (a rank dying inside ncclCommInitRank would otherwise leave its
+    peers in a collective for the launcher's whole timeout) and the parent exits non-zero.  What mpirun does for the reference
+    (/root/reference/README.md:37-40)."""
+    import signal
     import socket
     import subprocess
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    if budget_s is None:
+        budget_s = float(os.environ.get("AHIP_BENCH_BUDGET_S", "900"))
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    t0 = time.monotonic()
+    rc, why = 0, None
+    live = set(range(n))
+    while live and why is None:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                rc, why = abs(code) or 1, f"rank {r} exited with status {code}"
+                break
+        if why is None and live and time.monotonic() - t0 > budget_s:
+            rc, why = 124, f"wall-clock budget of {budget_s:.0f} s spent"
+        if why is None and live:
+            time.sleep(0.1)
+    if why is not None:
+        print(f"bench.py: {why}; stopping the other ranks", file=sys.stderr, flush=True)
+        for r in live:                       # exactly the processes started above
+            procs[r].send_signal(signal.SIGTERM)
+        t1 = time.monotonic()
+        for r in live:
+            try:
+                procs[r].wait(timeout=max(0.1, 10.0 - (time.monotonic() - t1)))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                procs[r].wait()
     return rc
 
 
@@ -196,6 +227,12 @@ def main():
     sim = md.Simulation(backend, box, cfg["r_max"], 1.0, pos, wl["mtype"], vel, device,
                         grid=grid, rank=rank, dist=dist, dt=0.001, overlap=False if args.no_overlap else (True if args.force_overlap else None))
     sim.setup()
+    ci = getattr(sim, "comm_info", None) or {"transport": "none", "rccl_version": 0, "init_ms": 0.0}
+    if world > 1:          # one line per rank on stderr: what a first multi-GPU contact needs to see
+        print(f"[bench] rank {rank}/{world} device {dev_index}: ghost exchange transport={ci['transport']} rccl_version={ci['rccl_version']} "
+              f"comm_init_ms={ci['init_ms']} nlocal={sim.nlocal} nghost={sim.nall - sim.nlocal}", file=sys.stderr, flush=True)
+    if os.environ.get("AHIP_BENCH_TEST_KILL_RANK", "") == str(rank):        # tests only (tests/test_gpu_md.py): a rank that dies after start-up
+        os._exit(17)
     for _ in range(args.warmup):
         sim.step()
 
@@ -204,25 +241,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    stage_ms = {}
     nrebuild0 = sim.nrebuild
+    # Stage timings: the library records HIP events on its launch stream around every stage of every call and nobody waits for them
+    # inside the timed region; they are read once behind the closing barrier (sums and launch counts over exactly the K timed steps).
+    backend.stats = {}
+    backend.defer_stats = True
+    model.timings()                        # drop what warm-up and setup recorded
+    sim.time_comm = True
+    sim.comm_ms()
     barrier()
     t0 = time.perf_counter()
-    edges_step = []
     for _ in range(args.steps):
-        backend.stats = {}
         sim.step()
-        edges_step.append(backend.stats.pop("edges", 0))
-        backend.stats.pop("calls", None)
-        for k, v in backend.stats.items():
-            stage_ms.setdefault(k, []).append(v)
-    backend.stats = None
     barrier()
     dt = time.perf_counter() - t0
+    stage_sum, stage_cnt = model.timings_and_counts()
+    stage_sum["comm"] = sim.comm_ms()                 # device time of the library's forward + reverse exchanges (events on their stream)
+    stage_cnt["comm"] = 2 * args.steps
+    sim.time_comm = False
+    backend.stats = None
+    STAGES = ["edge_build", "tile_pack", "model_fused", "model_generic", "comm"]
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        # max over ranks of the wall time and of every stage's summed device time (the slowest rank sets the step)
+        tmax = torch.tensor([dt] + [stage_sum.get(k, 0.0) for k in STAGES], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt = float(tmax[0].item())
+        stage_max = {k: float(tmax[1 + i].item()) for i, k in enumerate(STAGES) if float(tmax[1 + i].item()) > 0.0}
+    else:
+        stage_max = dict(stage_sum)
+    # edges of this rank's centres: one un-timed evaluation of all of them in a single call (the timed calls do not read their counts back)
+    scratch_f = torch.zeros_like(sim.f)
+    scratch_ev = torch.zeros(7, dtype=torch.float64, device=device)
+    backend.compute(sim.x, sim.mtype, scratch_f, sim.nlocal, scratch_ev)
+    edges_rank0 = model.nedges()
+    slots_used, slots_total = model.tile_occupancy()
+    model.timings()
+    del scratch_f
     th = sim.thermo(wl["masses"])
     rebuilds_timed = sim.nrebuild - nrebuild0
     # cost of one re-neighboring (migration, borders, cell list + neighbor table), measured outside the timed region: the metric counts
@@ -243,8 +297,8 @@ def main():
         # the fused kernels' tabulated two-body embedding executes fewer: frac_executed is priced on those.
         flops_per_edge = 2.0 * model_macs_per_edge(cfg) * 2.0       # 2 flop per MAC x (forward + input-gradient backward)
         executed_flops_per_edge = 2.0 * model_macs_per_edge(cfg, two_body_tabulated=tb_tab, readout_folded=tb_tab and cfg["l_max"] == 1) * 2.0
-        edges_rank0 = int(np.mean(edges_step))          # all centres of this rank (summed over the calls of a step)
-        stage_avg = {k: float(np.mean(v)) for k, v in stage_ms.items()}
+        stage_avg = {k: float(v) / args.steps for k, v in stage_sum.items()}          # ms per step, summed over the calls of a step
+        launches_per_step = {k: stage_cnt[k] / args.steps for k in stage_cnt}
         dom = max((k for k in stage_avg if k.startswith("model")), key=lambda k: stage_avg[k], default=None)
         roof = None
         traffic, traffic_src, traffic_hash = None, None, None
@@ -258,10 +312,12 @@ def main():
             ach = flops_per_edge * edges_rank0 / (stage_avg[dom] * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": 157.3, "unit": "TFLOP/s",
                     "frac": round(ach / 157.3, 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": dom,
-                    "avg_ms": round(stage_avg[dom], 3), "edges_per_launch": edges_rank0,
+                    "avg_ms": round(stage_avg[dom], 3), "edges_per_launch": edges_rank0, "launches_per_step": launches_per_step[dom],
                     "flops_per_edge": flops_per_edge, "executed_flops_per_edge": executed_flops_per_edge,
                     "frac_executed": round(ach / 157.3 * executed_flops_per_edge / flops_per_edge, 4),
-                    "two_body": "table" if tb_tab else "mlp"}
+                    "two_body": "table" if tb_tab else "mlp",
+                    # padding tax of the tile packing: edge slots that held an edge / slots of all tiles (one full evaluation)
+                    "slots_used": slots_used, "slots_total": slots_total, "slot_occupancy": (round(slots_used / slots_total, 4) if slots_total else None)}
             if traffic:
                 # the byte counts come from committed --pmc passes: flag them when the kernel sources changed since
                 roof["traffic_kernel_hash"] = traffic_hash
@@ -302,6 +358,9 @@ def main():
                        "comm": "overlapped" if sim.overlap else "serial",
                        "comm_transport": (("library/" + sim.comm.transport + ("/single-rank gather-scatter" if world == 1 else "")) if getattr(sim, "comm", None) is not None else "torch.distributed"),
                        "stage_ms_rank0": {k: round(v, 3) for k, v in stage_avg.items()},
+                       "stage_ms": {k: round(v / args.steps, 3) for k, v in stage_max.items()},          # max over ranks, per step
+                       "comm_ms": round(stage_max.get("comm", 0.0) / args.steps, 4),
+                       "rccl_version": ci["rccl_version"], "comm_init_ms": ci["init_ms"],
                        "pe_per_atom": th["pe"] / natoms},
             "max_abs_dF_vs_oracle": max_df,
             "parity_vs_oracle": parity,

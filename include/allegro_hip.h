@@ -87,7 +87,8 @@ int ahip_neigh_update(ahip_model *m, int inum, int nall, const int *ilist, const
 int ahip_neigh_update_csr(ahip_model *m, int inum, int nall, const int *ilist,
                           const long long *offsets, const int *neigh, int neighmask);
 /* Same, CSR arrays already on the device (int32 offsets [inum+1]); no copy is made of `neigh`
- * -- the caller keeps it alive until the next update. */
+ * -- the caller keeps it alive until the next update.  Synchronises the device once (the longest row is measured here: it bounds
+ * every centre's degree until the next hand-over, which is what lets ahip_compute_dev* run without any device -> host read-back). */
 int ahip_neigh_update_dev(ahip_model *m, int inum, int nall, const int *ilist_dev,
                           const int *offsets_dev, const int *neigh_dev, long long nneigh_total);
 
@@ -167,8 +168,16 @@ int ahip_get_edges(ahip_model *m, long long *nedges, long long *edge_index, doub
  * (then atom indices are printed). */
 int ahip_debug_dump_edges(ahip_model *m, const int *tag);
 
-/* Per-stage device timings (ms) of the last compute; names is a static ';'-separated list. */
+/* Per-stage device timings (option timing=1; HIP events on the launch stream): for every stage the SUM of its durations (ms) over the calls
+ * since the previous ahip_get_timings -- called after every compute it is that compute's timing; names is a ';'-separated list valid until
+ * the next call.  Waits for the recorded stages to finish; the compute calls themselves never wait for their events.
+ * ahip_get_timing_counts: the number of launches behind each of those sums (same order), valid until the next ahip_get_timings. */
 int ahip_get_timings(ahip_model *m, const char **names, const double **ms, int *n);
+int ahip_get_timing_counts(ahip_model *m, const double **counts, int *n);
+
+/* Diagnostics: edge slots of the tiles of the last fused evaluation (tiles x slots per tile) and the number that held an edge (= edges of
+ * that call); their ratio is the packing efficiency bench.py reports as slots_used / slots_total.  0 / 0 after a non-fused evaluation. */
+int ahip_last_tile_occupancy(ahip_model *m, long long *slots_used, long long *slots_total);
 
 /* The model file's fifth metadata key, `allow_tf32` ("0" / "1").  The reference hands it to libtorch
  * (pair_nequip_allegro.cpp:267-270: at::globalContext().setAllowTF32CuBLAS / CuDNN): 1 = the model's author permits TF32-class
@@ -225,6 +234,9 @@ typedef struct ahip_xfer_op {
 } ahip_xfer_op;
 /* performs all ops of one group (they may only complete together: post the receives before waiting for the sends); 0 = success */
 typedef int (*ahip_xfer_fn)(void *user, int nops, const ahip_xfer_op *ops);
+
+/* ncclGetVersion() of the librccl.so the RCCL transport opens (0: not available).  Reporting only (bench.py prints it per rank). */
+int ahip_comm_rccl_version(void);
 
 /* 128-byte RCCL unique id (ncclGetUniqueId): rank 0 creates it, the host program hands it to every rank */
 int ahip_comm_unique_id(unsigned char id[128]);

@@ -20,11 +20,11 @@ AHIP_OK, AHIP_ERR_ARG, AHIP_ERR_FILE, AHIP_ERR_DEVICE, AHIP_ERR_STATE, AHIP_ERR_
 # every symbol declared in include/allegro_hip.h (tests check the .so exports all of them)
 SYMBOLS = [
     "ahip_last_error", "ahip_device_count", "ahip_model_load", "ahip_model_free", "ahip_model_meta",
-    "ahip_set_option", "ahip_neigh_update", "ahip_neigh_update_csr", "ahip_neigh_update_dev",
+    "ahip_set_option", "ahip_get_timing_counts", "ahip_last_tile_occupancy", "ahip_neigh_update", "ahip_neigh_update_csr", "ahip_neigh_update_dev",
     "ahip_compute", "ahip_compute_dev", "ahip_output_register", "ahip_output_get", "ahip_get_edges", "ahip_debug_dump_edges", "ahip_get_timings",
     "ahip_compute_dev_range", "ahip_last_list_size", "ahip_neigh_update_dev_table", "ahip_map_types_dev", "ahip_reneighbor_flag_dev",
     "ahip_last_path", "ahip_last_max_degree", "ahip_debug_fused_linear", "ahip_debug_fused_edges", "ahip_build_neighbors_dev", "ahip_nve_dev",
-    "ahip_model_allow_tf32", "ahip_comm_unique_id", "ahip_comm_create_rccl", "ahip_comm_create_hosted", "ahip_comm_free", "ahip_comm_set_plan", "ahip_comm_set_plan_local",
+    "ahip_model_allow_tf32", "ahip_comm_unique_id", "ahip_comm_create_rccl", "ahip_comm_create_hosted", "ahip_comm_rccl_version", "ahip_comm_free", "ahip_comm_set_plan", "ahip_comm_set_plan_local",
     "ahip_comm_forward", "ahip_comm_reverse", "ahip_comm_allreduce", "ahip_comm_selftest", "ahip_fill_zero_dev",
 ]
 
@@ -93,6 +93,7 @@ class Library:
         L.ahip_get_edges.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
         L.ahip_debug_dump_edges.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.ahip_get_timings.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int)]
+        L.ahip_get_timing_counts.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int)]
         L.ahip_build_neighbors_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double),
                                                C.POINTER(C.c_double), C.c_double, C.c_void_p]
         L.ahip_nve_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -288,6 +289,24 @@ class Model:
         if n.value == 0:
             return {}
         return dict(zip(names.value.decode().split(";"), [ms[k] for k in range(n.value)]))
+
+    def tile_occupancy(self):
+        """(slots holding an edge, slots of all tiles) of the last fused evaluation."""
+        a = C.c_longlong(0); b = C.c_longlong(0)
+        self.L.lib.ahip_last_tile_occupancy.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        self.L.check(self.L.lib.ahip_last_tile_occupancy(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def timings_and_counts(self):
+        """({stage: summed ms}, {stage: launches}) since the previous timings() / timings_and_counts() call."""
+        names = C.c_char_p(); ms = C.POINTER(C.c_double)(); n = C.c_int(0)
+        self.L.check(self.L.lib.ahip_get_timings(self.h, C.byref(names), C.byref(ms), C.byref(n)))
+        if n.value == 0:
+            return {}, {}
+        cnt = C.POINTER(C.c_double)(); n2 = C.c_int(0)
+        self.L.check(self.L.lib.ahip_get_timing_counts(self.h, C.byref(cnt), C.byref(n2)))
+        keys = names.value.decode().split(";")
+        return dict(zip(keys, [ms[k] for k in range(n.value)])), dict(zip(keys, [int(cnt[k]) for k in range(n2.value)]))
 
     @property
     def last_path(self) -> str:

@@ -84,6 +84,7 @@ struct Rccl {
   int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
+  int (*GetVersion)(int *) = nullptr;
   bool load(std::string *why) {
     if (h) return true;
     const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
@@ -100,6 +101,7 @@ struct Rccl {
     Recv = (decltype(Recv))sym("ncclRecv");
     AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
     GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+    GetVersion = (decltype(GetVersion))dlsym(h, "ncclGetVersion");          // optional (reporting only)
     return GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv && AllReduce && GetErrorString;
   }
 };
@@ -155,6 +157,14 @@ struct Xfer {
   }
 };
 
+// swaps k, k+1 (one dimension) both exchange with one and the same remote rank and their ghost rows are consecutive
+static bool pair_has_one_peer(const Comm &c, size_t k) {
+  if (k + 1 >= c.swaps.size()) return false;
+  const Swap &a = c.swaps[k], &b = c.swaps[k + 1];
+  return a.sendrank != c.rank && a.sendrank == a.recvrank && b.sendrank == a.sendrank && b.recvrank == a.sendrank &&
+         b.first_recv == a.first_recv + a.nrecv;
+}
+
 static void comm_forward(Comm &c, double *x, hipStream_t s) {
   if (c.local_plan) {
     if (c.loc_nghost > 0)
@@ -164,6 +174,20 @@ static void comm_forward(Comm &c, double *x, hipStream_t s) {
   for (size_t k = 0; k < c.swaps.size(); k += 2) {
     Xfer X{c, s, {}};
     const size_t kend = std::min(k + 2, c.swaps.size());
+    if (pair_has_one_peer(c, k)) {
+      // two ranks along this dimension: both swaps go to and come from the SAME peer.  One send and one receive of the concatenated slabs
+      // instead of two of each inside one group (matching order of several operations per peer in a group is the transport's business;
+      // a single pair cannot be mismatched): my [swap k | swap k+1] lands in the peer's consecutive ghost rows of swaps k, k+1.
+      const Swap &a = c.swaps[k], &b = c.swaps[k + 1];
+      c.sendbuf[0].reserve((size_t)std::max(a.nsend + b.nsend, 1) * 24);
+      double *buf = c.sendbuf[0].as<double>();
+      if (a.nsend > 0) hipLaunchKernelGGL(k_comm_pack, dim3((a.nsend + 255) / 256), dim3(256), 0, s, a.nsend, a.send_idx, x, a.dim, a.shift, buf);
+      if (b.nsend > 0) hipLaunchKernelGGL(k_comm_pack, dim3((b.nsend + 255) / 256), dim3(256), 0, s, b.nsend, b.send_idx, x, b.dim, b.shift, buf + 3 * (size_t)a.nsend);
+      X.send(buf, (long long)(a.nsend + b.nsend) * 24, a.sendrank);
+      X.recv(x + 3 * (size_t)a.first_recv, (long long)(a.nrecv + b.nrecv) * 24, a.sendrank);
+      X.run();
+      continue;
+    }
     for (size_t q = k; q < kend; ++q) {
       const Swap &sw = c.swaps[q];
       const bool self = sw.sendrank == c.rank && sw.recvrank == c.rank;
@@ -191,6 +215,17 @@ static void comm_reverse(Comm &c, double *f, hipStream_t s) {
   for (int k = (n - 1) & ~1; k >= 0; k -= 2) {
     Xfer X{c, s, {}};
     const int kend = std::min(k + 2, n);
+    if (pair_has_one_peer(c, (size_t)k)) {          // see comm_forward: the peer's ghost rows of both swaps come back as one message, in the order they went
+      const Swap &a = c.swaps[k], &b = c.swaps[k + 1];
+      c.recvbuf[0].reserve((size_t)std::max(a.nsend + b.nsend, 1) * 24);
+      double *buf = c.recvbuf[0].as<double>();
+      X.send(f + 3 * (size_t)a.first_recv, (long long)(a.nrecv + b.nrecv) * 24, a.sendrank);
+      X.recv(buf, (long long)(a.nsend + b.nsend) * 24, a.sendrank);
+      X.run();
+      if (a.nsend > 0) hipLaunchKernelGGL(k_comm_unpack_add, dim3((a.nsend + 255) / 256), dim3(256), 0, s, a.nsend, a.send_idx, buf, f);
+      if (b.nsend > 0) hipLaunchKernelGGL(k_comm_unpack_add, dim3((b.nsend + 255) / 256), dim3(256), 0, s, b.nsend, b.send_idx, buf + 3 * (size_t)a.nsend, f);
+      continue;
+    }
     for (int q = k; q < kend; ++q) {
       const Swap &sw = c.swaps[q];
       if (sw.sendrank == c.rank && sw.recvrank == c.rank) continue;
@@ -247,6 +282,14 @@ extern "C" int ahip_comm_create_rccl(int rank, int nranks, const unsigned char i
   if (r != 0) { delete c; throw HipError(std::string("ncclCommInitRank failed: ") + g_rccl.GetErrorString(r)); }
   *out = (ahip_comm *)c;
   COMM_CATCH
+}
+
+// RCCL version code (e.g. 22205) of the library the RCCL transport uses, 0 when it cannot be opened (reporting only)
+extern "C" int ahip_comm_rccl_version(void) {
+  std::string why;
+  int v = 0;
+  if (!g_rccl.load(&why) || !g_rccl.GetVersion || g_rccl.GetVersion(&v) != 0) return 0;
+  return v;
 }
 
 extern "C" int ahip_comm_create_hosted(int rank, int nranks, ahip_xfer_fn fn, void *user, ahip_comm **out) {

@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(EB_THREADS) k_build_edges(int inum, const int 
                                                        int *heavy_cnt, int *heavy_list) {
   __shared__ int s_cnt2[2][EB_ATOMS];          // counters of two consecutive units (no barrier between the stores of one and the
   __shared__ int s_base2[2][EB_ATOMS + 1];     // counting of the next)
-  __shared__ int s_blk, s_claim;
+  __shared__ int s_blk, s_claim2[2];           // claims double-buffered by unit parity like the counters: a wave may still be reading one while thread 0 posts the next
   __shared__ long long s_prefix2[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // Two unit schedules.  DYN = false: the workgroup takes ONE ticket t and walks the units t, t + G, t + 2 G ... (G = grid size).  The
@@ -68,10 +68,10 @@ __global__ void __launch_bounds__(EB_THREADS) k_build_edges(int inum, const int 
   // wait for a workgroup that has not started -- whatever the grid size and whatever else occupies the chip (a second model on another
   // stream, ranks sharing the GPU, exchange kernels).  It costs one device-scope atomic per unit on one address: +0.19 ms at 1 M atoms
   // (0.55 -> 0.74 ms), so the host picks it only where co-residency is not a given (edges_build_f32).
-  if (tid == 0) { s_blk = (int)atomicAdd(ticket, 1u); if (DYN) s_claim = (int)atomicAdd(ticket, 1u); }
+  if (tid == 0) { s_blk = (int)atomicAdd(ticket, 1u); if (DYN) s_claim2[0] = (int)atomicAdd(ticket, 1u); }
   __syncthreads();
   const int b0 = s_blk;
-  int bn = DYN ? s_claim : b0 + (int)gridDim.x;       // the unit after the current one
+  int bn = DYN ? s_claim2[0] : b0 + (int)gridDim.x;       // the unit after the current one
   const int uwave = __builtin_amdgcn_readfirstlane(wave);
   int run_max = 0;                       // largest edge count seen by this workgroup (thread 0), published once at the end
   constexpr int NB = EB_CHUNKS == 1 ? EB_PER_WAVE : 2;
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(EB_THREADS) k_build_edges(int inum, const int 
   int par = 0, bnn = 0;
   for (int b = b0; b < nunits; b = bn, bn = bnn, par ^= 1) {
   const int a_begin = b * EB_ATOMS;
-  if (DYN && tid == 0) s_claim = (int)atomicAdd(ticket, 1u);        // the unit after next; read behind this unit's second barrier
+  if (DYN && tid == 0) s_claim2[par ^ 1] = (int)atomicAdd(ticket, 1u);        // the unit after next; read behind this unit's second barrier
   int *s_cnt = s_cnt2[par], *s_base = s_base2[par];
   long long &s_prefix = s_prefix2[par];
 
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(EB_THREADS) k_build_edges(int inum, const int 
   }
   __syncthreads();
   const long long gbase = s_prefix;
-  bnn = DYN ? s_claim : bn + (int)gridDim.x;
+  bnn = DYN ? s_claim2[par ^ 1] : bn + (int)gridDim.x;
 
   // ---- offsets + edges -------------------------------------------------------------------------------
   take_rows();                           // next unit's rows have arrived; its neighbour indices travel during the stores
@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(EB_THREADS) k_build_edges(int inum, const int 
   if (tid == 0 && run_max > 0) atomicMax(maxdeg, run_max);
 }
 
-struct EdgeState { DevBuf flags, heavy, hoff, xt; int ncu = 0, occ[2] = {1, 1}; int *h_back = nullptr; };     // h_back: pinned read-back words
+struct EdgeState { DevBuf flags, heavy, hoff, xt; int ncu = 0, occ[2] = {1, 1}; int *h_back = nullptr; hipEvent_t ev_back = nullptr, chain = nullptr; };     // h_back: pinned read-back words; ev_back: recorded behind their copy
 
 // ---- compact copy of the edges of the listed ("heavy") centres: the edge list the layer-at-a-time kernels run on ----
 static __global__ void k_heavy_offsets(int nh, const int *heavy, const int *eoff, int *hoff) {
@@ -292,6 +292,36 @@ static __global__ void k_heavy_copy(int nh, const int *heavy, const int *ilist, 
     h_rvec[3 * (size_t)(o + q) + 1] = rvec[3 * (size_t)(e0 + q) + 1];
     h_rvec[3 * (size_t)(o + q) + 2] = rvec[3 * (size_t)(e0 + q) + 2];
   }
+}
+
+static __global__ void k_max_row(int inum, const int *off, int *out) {
+  int ii = blockIdx.x * blockDim.x + threadIdx.x;
+  int v = ii < inum ? off[ii + 1] - off[ii] : 0;
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(out, v);
+}
+int edges_max_row(Model &m, int inum, const int *offsets_dev) {
+  if (inum <= 0) return 0;
+  AHIP_CHECK(hipDeviceSynchronize());        // the list may have been written on any stream of the caller
+  m.b_misc.reserve(64);
+  int *out = m.b_misc.as<int>();
+  AHIP_CHECK(hipMemsetAsync(out, 0, sizeof(int), nullptr));
+  hipLaunchKernelGGL(k_max_row, dim3((inum + 255) / 256), dim3(256), 0, nullptr, inum, offsets_dev, out);
+  int h = 0;
+  AHIP_CHECK(hipMemcpy(&h, out, sizeof(int), hipMemcpyDeviceToHost));
+  return h;
+}
+
+void edges_counts(Model &m) {
+  if (!m.counts_pending) return;
+  EdgeState &st = *(EdgeState *)m.edge_state;
+  AHIP_CHECK(hipEventSynchronize(st.ev_back));       // the copy sits right behind the edge build in its stream: this does not wait for the model kernel
+  const int *h3 = st.h_back;
+  m.nedges = h3[4];
+  m.nedges_hint = m.nedges;
+  m.last_max_deg = h3[1];
+  m.nheavy = m.heavy_thresh > 0 ? h3[3] : 0;
+  m.counts_pending = false;
 }
 
 void edges_compact_heavy(Model &m, const ComputeArgs &a) {
@@ -325,7 +355,11 @@ bool edges_build_f32(Model &m, const ComputeArgs &a) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&st.occ[0], k_build_edges<1, false>, EB_THREADS, 0) != hipSuccess || st.occ[0] < 1) st.occ[0] = 1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&st.occ[1], k_build_edges<2, false>, EB_THREADS, 0) != hipSuccess || st.occ[1] < 1) st.occ[1] = 1;
     AHIP_CHECK(hipHostMalloc((void **)&st.h_back, 8 * sizeof(int), hipHostMallocDefault));
+    AHIP_CHECK(hipEventCreateWithFlags(&st.ev_back, hipEventDisableTiming));
   }
+  m.counts_pending = false;
+  // a row of more than 128 entries cannot go through the register-resident single pass: known from the list, no launch needed to find out
+  if (m.max_list_row > 128) return false;
   const bool one_chunk = m.max_list_row >= 0 && m.max_list_row <= 64;
   // a grid the size of the residency (more workgroups would only queue)
   const int nblocks = std::max(1, std::min(nunits, st.ncu * st.occ[one_chunk ? 0 : 1] - m.reserve_wgs));
@@ -335,12 +369,11 @@ bool edges_build_f32(Model &m, const ComputeArgs &a) {
   // device (option edge_schedule=dynamic) -- and then units are claimed one at a time, which cannot wait on a workgroup that has not
   // started.  Launches with the fixed stride are additionally chained by an event, so that two of them never overlap in one process.
   const bool dyn = m.opt_edge_schedule == "dynamic" || (m.opt_edge_schedule == "auto" && (m.reserve_wgs > 0 || g_models_alive.load() > 1));
-  static hipEvent_t chain = nullptr;
-  static std::mutex chain_mu;
+  // (one event per model, i.e. per device: ADVICE r03 -- a process-wide one belonged to whichever device ran first; with a second model alive the
+  // dynamic schedule is chosen anyway)
   if (!dyn) {
-    std::lock_guard<std::mutex> lk(chain_mu);
-    if (!chain) AHIP_CHECK(hipEventCreateWithFlags(&chain, hipEventDisableTiming));
-    else AHIP_CHECK(hipStreamWaitEvent(a.stream, chain, 0));
+    if (!st.chain) AHIP_CHECK(hipEventCreateWithFlags(&st.chain, hipEventDisableTiming));
+    else AHIP_CHECK(hipStreamWaitEvent(a.stream, st.chain, 0));
   }
   // header: [0] ticket (u32), [1] maxdeg, [2] overflow, [3] number of heavy centres; status array starts at byte 64
   const size_t bytes = 64 + (size_t)nunits * sizeof(unsigned long long);
@@ -365,22 +398,25 @@ bool edges_build_f32(Model &m, const ComputeArgs &a) {
   if (dyn) { if (one_chunk) EB_LAUNCH(1, true); else EB_LAUNCH(2, true); }
   else {
     if (one_chunk) EB_LAUNCH(1, false); else EB_LAUNCH(2, false);
-    std::lock_guard<std::mutex> lk(chain_mu);
-    AHIP_CHECK(hipEventRecord(chain, a.stream));
+    AHIP_CHECK(hipEventRecord(st.chain, a.stream));
   }
 #undef EB_LAUNCH
   AHIP_CHECK(hipGetLastError());
-  // the scalar read-back per step (the Kokkos path has the same one: pair_nequip_allegro_kokkos.cpp:203-206), into pinned memory
+  // The counters go to pinned memory asynchronously.  The reference's Kokkos path reads its edge total back in every step
+  // (pair_nequip_allegro_kokkos.cpp:203-206); here nobody waits for the copy unless a value is needed on the host: with every row <= 128
+  // entries (known since the list was installed) no row can overflow, the degree is bounded by the row length, and the kernels that follow
+  // read the totals from device memory.
   int *h3 = st.h_back;
   AHIP_CHECK(hipMemcpyAsync(h3, hdr, 4 * sizeof(int), hipMemcpyDeviceToHost, a.stream));
   AHIP_CHECK(hipMemcpyAsync(h3 + 4, m.b_eoff.as<int>() + inum, sizeof(int), hipMemcpyDeviceToHost, a.stream));
-  AHIP_CHECK(hipStreamSynchronize(a.stream));
-  const int tot = h3[4];
-  if (h3[2] != 0) return false;                     // a row longer than 128 entries: caller uses the two-pass kernels
-  m.nedges = tot;
-  m.last_max_deg = h3[1];
-  m.nheavy = m.heavy_thresh > 0 ? h3[3] : 0;
+  AHIP_CHECK(hipEventRecord(st.ev_back, a.stream));
+  m.d_maxdeg = hdr + 1;
   m.have_ett = true;
+  m.counts_pending = true;
+  if (m.max_list_row < 0) {                         // row lengths unknown (cannot happen through the C-ABI, which measures them at every list hand-over): check the overflow flag now
+    edges_counts(m);
+    if (h3[2] != 0) { m.have_ett = false; return false; }
+  }
   return true;
 }
 
@@ -392,6 +428,8 @@ void edges_free(Model &m) {
   st->heavy.release();
   st->hoff.release();
   if (st->h_back) (void)hipHostFree(st->h_back);
+  if (st->ev_back) (void)hipEventDestroy(st->ev_back);
+  if (st->chain) (void)hipEventDestroy(st->chain);
   delete st;
   m.edge_state = nullptr;
 }

@@ -77,7 +77,16 @@ template <typename T> struct DeviceWeights {
 
 extern std::atomic<int> g_models_alive;     // models of this process (allegro_hip.hip)
 
-struct TimingSlot { std::string name; hipEvent_t a = nullptr, b = nullptr; bool used = false; };
+// Stage timing (option timing=1): HIP events on the launch stream around every stage of a call.  Nothing waits for them when they are recorded
+// (round 4: reading them back at the end of every call was a full synchronisation per ahip_compute_dev*); the pairs queue up in a ring and are
+// turned into milliseconds when the caller asks (ahip_get_timings: the sum and the number of launches per stage since the last call of it).
+struct TimingSlot {
+  std::string name;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ring;      // event pairs, reused round-robin
+  size_t head = 0, tail = 0;                                // pairs [tail, head) are recorded and not yet read
+  double sum_ms = 0; long long count = 0;                   // read so far, not yet reported
+};
+static constexpr size_t TIMING_RING = 1024;
 
 struct Model {
   HostModel hm;
@@ -129,6 +138,14 @@ struct Model {
   std::vector<int> h_eoff;
   int last_max_deg = 0;
   std::string last_path;
+  // The single-pass edge build (edges.hip) leaves its counters -- edge total, largest degree, number of heavy centres -- on the device and
+  // copies them to pinned memory asynchronously; the host waits for that copy (edges_counts) only where it needs one of the values, never on
+  // the fused path of a bounded list (no hipStreamSynchronize per ahip_compute_dev* call).
+  bool counts_pending = false;               // nedges / last_max_deg / nheavy are not valid yet: call edges_counts()
+  long long nedges_hint = 0;                 // edge total of the last read-back that was waited for, else an estimate (heuristics only)
+  const int *d_maxdeg = nullptr;             // device word holding the largest degree of the current edge list (single-pass build)
+  const int *d_ntiles_last = nullptr;        // device word with the tile count of the last fused launch; last_tile_slots: its edge slots per tile (0: chosen on the device from the largest degree)
+  int last_tile_slots = 0;
 
   // Centres with more edges than a tile of the wide fused kernel holds (fused_lx.hip): found by the edge build when
   // heavy_thresh > 0, evaluated by the layer-at-a-time kernels on a compact copy of their edges (hv_*)
@@ -143,7 +160,7 @@ struct Model {
   // timings
   std::vector<TimingSlot> slots;
   std::string timing_names;
-  std::vector<double> timing_ms;
+  std::vector<double> timing_ms, timing_counts;
 
   // scratch of the device-wide primitives (scan, column sums): per model, see prims.h
   PrimScratch prim;
@@ -160,20 +177,25 @@ struct Model {
 };
 
 // ---- stage timing ------------------------------------------------------------------------------
+void timing_drain(Model &m, TimingSlot &t, size_t keep);          // allegro_hip.hip: reads pairs until at most `keep` are outstanding (waits for them)
 struct StageTimer {
-  Model &m; hipStream_t s; int idx = -1;
+  Model &m; hipStream_t s; int idx = -1; hipEvent_t eb = nullptr;
   StageTimer(Model &m_, const char *name, hipStream_t s_) : m(m_), s(s_) {
     if (!m.timing) return;
     for (size_t i = 0; i < m.slots.size(); ++i) if (m.slots[i].name == name) idx = (int)i;
-    if (idx < 0) {
-      TimingSlot t; t.name = name;
-      AHIP_CHECK(hipEventCreate(&t.a)); AHIP_CHECK(hipEventCreate(&t.b));
-      m.slots.push_back(t); idx = (int)m.slots.size() - 1;
+    if (idx < 0) { TimingSlot t; t.name = name; m.slots.push_back(t); idx = (int)m.slots.size() - 1; }
+    TimingSlot &t = m.slots[idx];
+    if (t.head - t.tail >= TIMING_RING) timing_drain(m, t, TIMING_RING / 2);
+    const size_t k = t.head % TIMING_RING;
+    if (k >= t.ring.size()) {
+      std::pair<hipEvent_t, hipEvent_t> e{nullptr, nullptr};
+      AHIP_CHECK(hipEventCreate(&e.first)); AHIP_CHECK(hipEventCreate(&e.second));
+      t.ring.push_back(e);
     }
-    m.slots[idx].used = true;
-    AHIP_CHECK(hipEventRecord(m.slots[idx].a, s));
+    eb = t.ring[k].second;
+    AHIP_CHECK(hipEventRecord(t.ring[k].first, s));
   }
-  ~StageTimer() { if (idx >= 0) (void)hipEventRecord(m.slots[idx].b, s); }
+  ~StageTimer() { if (idx >= 0) { (void)hipEventRecord(eb, s); ++m.slots[idx].head; } }
 };
 
 // ---- generic path (generic_engine.h via allegro_hip.hip) -------------------------------
@@ -209,6 +231,10 @@ void fusedlx2_free(Model &m);
 // Fills m.nedges, m.last_max_deg, b_eoff/b_eii/b_ej/b_rvec exactly like build_edges<float>; false = a list
 // row is too long for the register-resident version and the caller must run the two-pass kernels.
 bool edges_build_f32(Model &m, const ComputeArgs &a);
+// waits for the counters of the last edges_build_f32 if they are still in flight (m.counts_pending) and installs them in m
+void edges_counts(Model &m);
+// longest row of a device-resident CSR list (list hand-over only: one small kernel + a 4-byte read-back)
+int edges_max_row(Model &m, int inum, const int *offsets_dev);
 void edges_free(Model &m);
 // compact copy (m.hv_*) of the edges of the m.nheavy centres the last edges_build_f32 listed
 void edges_compact_heavy(Model &m, const ComputeArgs &a);

@@ -75,6 +75,7 @@ struct FusedArgs {
   unsigned int *tile_counter;
   int tchunk;                    // tiles per claim of the dynamic schedule (1 for small systems: a workgroup's last claim sets the makespan)    // dynamic tile schedule (zeroed by k_pack_finish)
   const int *tile_a0, *tile_e0, *ntiles;   // tile t = centres [tile_a0[t], tile_a0[t+1]), edges [tile_e0[t], tile_e0[t+1])
+  const int *maxdeg_sel;         // null, or the device word with the list's largest degree: the 4-wave shape runs iff it is <= 64, the 8-wave shape iff not (fused_run)
   // weights (offsets in floats into wbase)
   const float *wbase;
   int wbytes;
@@ -303,6 +304,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     SB = __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, (int)(A.wave_scratch * 4), 0x00020000);
     WB = __builtin_amdgcn_make_buffer_rsrc((void *)A.wbase, 0, A.wbytes, 0x00020000);
   }
+  if (A.maxdeg_sel && ((*A.maxdeg_sel <= 64) != (NW == 4))) return;     // both shapes were launched: the tiles were packed for the other one
   const float *__restrict__ Wb = A.wbase;
   for (int k = tid; k < A.NL * 160; k += NTHREADS) {      // path weights with their CG constants folded in
     const int pth = (k % 160) / 32;
@@ -1062,22 +1064,29 @@ static void fused_prepare(Model &m) {
 }
 
 bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
-  if (m.last_max_deg > MAX_TILE_SLOTS) {
-    if (why) *why = "an atom has " + std::to_string(m.last_max_deg) + " edges (> 128 per tile)";
-    return false;
-  }
+  // Tile shape (4 waves / 64 slots or 8 waves / 128 slots) follows the largest degree of THIS step's edge list.  The host does not read that
+  // back: a degree cannot exceed the row length of the list it was filtered from, which is known since the list was handed
+  // over -- rows <= 64: 4 waves, no question; rows <= 128: both shapes are launched and the device word decides (the other kernel returns
+  // at once, ~3 us); only lists with longer rows (two-pass edge build, counts read back there) take the decision on the host.
   if (m.edges_T_size != 4) { if (why) *why = "edge vectors are not float32"; return false; }
   fused_prepare(m);
   FusedState &st = *(FusedState *)m.fused_state;
+  if (st.prof_on || st.clk_on || st.dbg_on) edges_counts(m);      // instrumented runs size their buffers / reports from the counts
+  int nw = 0;                                   // 0: decided on the device
+  if (!m.counts_pending) {
+    if (m.last_max_deg > MAX_TILE_SLOTS) {
+      if (why) *why = "an atom has " + std::to_string(m.last_max_deg) + " edges (> 128 per tile)";
+      return false;
+    }
+    nw = m.last_max_deg <= 64 ? 4 : 8;
+    if (st.force_nw == 8 || (st.force_nw == 4 && m.last_max_deg <= 64)) nw = st.force_nw;
+  } else if (st.force_nw == 8) nw = 8;
+  else if (m.max_list_row >= 0 && m.max_list_row <= 64) nw = 4;
+  const int *maxdeg_sel = nw == 0 ? m.d_maxdeg : nullptr;
   m.last_fused_arith = st.arith;
   hipStream_t s = a.stream;
   const int inum = m.inum;
-  int nw = m.last_max_deg <= 64 ? 4 : 8;
-  if (st.force_nw == 8 || (st.force_nw == 4 && m.last_max_deg <= 64)) nw = st.force_nw;
-  const int tile_slots = 16 * nw, maxa = nw == 4 ? Lds<4>::MAXA : Lds<8>::MAXA;
-  // persistent workgroups fill every CU; reserve_wgs leaves a few slots free so that the exchange kernels of another stream
-  // (ghost pack / unpack, RCCL send / recv) can be scheduled while this kernel runs (md.py, overlapped schedule)
-  const int grid = std::max(1, st.ncu * (8 / nw) - m.reserve_wgs);
+  const int tile_slots = nw == 8 ? 128 : 64, maxa = nw == 8 ? Lds<8>::MAXA : Lds<4>::MAXA;      // nw == 0: the packing kernels widen them themselves
   const int nseg = (inum + SEG - 1) / SEG;
   st.seg_count.reserve((size_t)(nseg + 1) * sizeof(int));
   st.seg_base.reserve((size_t)(nseg + 2) * sizeof(int));
@@ -1090,15 +1099,15 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
     const bool small = nseg <= PACK_SMALL_SEGS;
     if (small)
       hipLaunchKernelGGL(k_pack_small, dim3(1), dim3(PACK_SMALL_SEGS), 0, s, inum, m.b_eoff.as<int>(), nseg, st.tile_a0.as<int>(), st.tile_e0.as<int>(), st.ntiles.as<int>(), tile_slots, maxa,
-                         m.d_ilist, a.mtype, st.centre.as<int2>());
+                         m.d_ilist, a.mtype, st.centre.as<int2>(), maxdeg_sel);
     else {
-      hipLaunchKernelGGL(k_pack_tiles<false>, dim3((nseg + B - 1) / B), dim3(B), 0, s, inum, m.b_eoff.as<int>(), nseg, st.seg_count.as<int>(), (const int *)nullptr, (int *)nullptr, tile_slots, maxa);
+      hipLaunchKernelGGL(k_pack_tiles<false>, dim3((nseg + B - 1) / B), dim3(B), 0, s, inum, m.b_eoff.as<int>(), nseg, st.seg_count.as<int>(), (const int *)nullptr, (int *)nullptr, tile_slots, maxa, maxdeg_sel);
       AHIP_CHECK(prim_exclusive_scan_i32(m.prim, st.seg_count.as<int>(), st.seg_base.as<int>(), nseg, s));
-      hipLaunchKernelGGL(k_pack_tiles<true>, dim3((nseg + B - 1) / B), dim3(B), 0, s, inum, m.b_eoff.as<int>(), nseg, (int *)nullptr, st.seg_base.as<int>(), st.tile_a0.as<int>(), tile_slots, maxa);
+      hipLaunchKernelGGL(k_pack_tiles<true>, dim3((nseg + B - 1) / B), dim3(B), 0, s, inum, m.b_eoff.as<int>(), nseg, (int *)nullptr, st.seg_base.as<int>(), st.tile_a0.as<int>(), tile_slots, maxa, maxdeg_sel);
       hipLaunchKernelGGL(k_pack_finish, dim3(1), dim3(1), 0, s, inum, nseg, st.seg_base.as<int>(), st.tile_a0.as<int>(), st.ntiles.as<int>());
       hipLaunchKernelGGL(k_centre_info, dim3((inum + 255) / 256), dim3(256), 0, s, inum, m.d_ilist, a.mtype, st.centre.as<int2>());
     }
-    if (!m.have_ett) {
+    if (!m.have_ett) {            // two-pass edge build: its counts are on the host
       m.b_ett.reserve((size_t)std::max<long long>(m.nedges, 1));
       hipLaunchKernelGGL(k_edge_types, dim3((unsigned)((m.nedges + 255) / 256)), dim3(256), 0, s, m.nedges, m.b_eii.as<int>(), m.b_ej.as<int>(), m.d_ilist, a.mtype, m.b_ett.as<unsigned char>());
       m.have_ett = true;
@@ -1109,16 +1118,21 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
     }
   }
   FusedArgs A = st.args;
-  A.wg_scratch = nw * A.wave_scratch;
   A.eoff = m.b_eoff.as<int>(); A.e_ii = m.b_eii.as<int>(); A.e_j = m.b_ej.as<int>();
   A.e_tt = m.b_ett.as<unsigned char>(); A.centre = st.centre.as<int2>(); A.rvec = m.b_rvec.as<float>(); A.rcut = m.rcut_model_dev;
   A.tile_a0 = st.tile_a0.as<int>(); A.tile_e0 = st.tile_e0.as<int>(); A.ntiles = st.ntiles.as<int>();
   A.tile_counter = (unsigned int *)(st.ntiles.as<int>() + 1);
-  // claims of TCHUNK tiles amortise the counter's round trip; with few tiles per workgroup the last claim decides the makespan
-  // (10 648 Si atoms: 4 659 tiles on 512 workgroups = 12 instead of 10 tile times with claims of 4)
-  A.tchunk = (m.nedges / tile_slots > (long long)grid * 256) ? TCHUNK : 1;
-  if (const char *tc = std::getenv("AHIP_TCHUNK")) A.tchunk = std::max(1, std::atoi(tc));       // experiments
+  A.maxdeg_sel = maxdeg_sel;
+  m.d_ntiles_last = st.ntiles.as<int>(); m.last_tile_slots = nw == 0 ? 0 : 16 * nw;
   A.f = a.f; A.eatom = a.eatom; A.partial = st.partial.as<double>();
+  // edge total for the claim size below: the value itself when it is on the host, else the last one that was, else the list's size
+  // scaled by the volume ratio of cutoff and list spheres at a skin of 1 A
+  const long long nedges_est = !m.counts_pending ? m.nedges : m.nedges_hint > 0 ? m.nedges_hint : (long long)(0.58 * (double)m.nneigh);
+  // persistent workgroups fill every CU; reserve_wgs leaves a few slots free so that the exchange kernels of another stream
+  // (ghost pack / unpack, RCCL send / recv) can be scheduled while this kernel runs (md.py, overlapped schedule)
+  const int grid4 = std::max(1, st.ncu * 2 - m.reserve_wgs), grid8 = std::max(1, st.ncu - m.reserve_wgs);
+  const int grid = nw == 8 ? grid8 : grid4;     // rows of `partial` that are summed
+  if (nw == 0) AHIP_CHECK(hipMemsetAsync(st.partial.p, 0, (size_t)grid * 7 * sizeof(double), s));     // the shape that returns at once writes nothing
   {
     StageTimer tm(m, "model_fused", s);
     if (st.dbg_on) {
@@ -1130,12 +1144,19 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
       AHIP_CHECK(hipMemsetAsync(st.prof.p, 0, (64 + 4 * (size_t)grid) * sizeof(long long), s));
       A.prof = st.prof.as<long long>();
     }
-    if (st.arith != 0) fused_launch_bf16(nw, st.prof_on, st.arith, st.tbt, grid, s, A);       // fused_bf.o
-    else {
-#define AHIP_LAUNCH_NL(NWV, PROFV, TBV, NLV) hipLaunchKernelGGL((k_fused<NWV, PROFV, 0, TBV, NLV>), dim3(grid), dim3(NWV * 64), 0, s, A)
+    for (int shape = 4; shape <= 8; shape += 4) {
+      if (nw != 0 && nw != shape) continue;
+      const int g = shape == 8 ? grid8 : grid4;
+      A.wg_scratch = shape * A.wave_scratch;
+      // claims of TCHUNK tiles amortise the counter's round trip; with few tiles per workgroup the last claim decides the makespan
+      // (10 648 Si atoms: 4 659 tiles on 512 workgroups = 12 instead of 10 tile times with claims of 4)
+      A.tchunk = (nedges_est / (16 * shape) > (long long)g * 256) ? TCHUNK : 1;
+      if (const char *tc = std::getenv("AHIP_TCHUNK")) A.tchunk = std::max(1, std::atoi(tc));       // experiments
+      if (st.arith != 0) { fused_launch_bf16(shape, st.prof_on, st.arith, st.tbt, g, s, A); continue; }     // fused_bf.o
+#define AHIP_LAUNCH_NL(NWV, PROFV, TBV, NLV) hipLaunchKernelGGL((k_fused<NWV, PROFV, 0, TBV, NLV>), dim3(g), dim3(NWV * 64), 0, s, A)
 #define AHIP_LAUNCH(NWV, PROFV, TBV) do { if (A.NL == 1) AHIP_LAUNCH_NL(NWV, PROFV, TBV, 1); else if (A.NL == 2) AHIP_LAUNCH_NL(NWV, PROFV, TBV, 2); else AHIP_LAUNCH_NL(NWV, PROFV, TBV, 3); } while (0)
 #define AHIP_LAUNCH_TB(NWV, PROFV) do { if (st.tbt) AHIP_LAUNCH(NWV, PROFV, true); else AHIP_LAUNCH(NWV, PROFV, false); } while (0)
-#define AHIP_LAUNCH_NW(PROFV) do { if (nw == 4) AHIP_LAUNCH_TB(4, PROFV); else AHIP_LAUNCH_TB(8, PROFV); } while (0)
+#define AHIP_LAUNCH_NW(PROFV) do { if (shape == 4) AHIP_LAUNCH_TB(4, PROFV); else AHIP_LAUNCH_TB(8, PROFV); } while (0)
       if (st.prof_on) AHIP_LAUNCH_NW(true); else AHIP_LAUNCH_NW(false);
 #undef AHIP_LAUNCH_NW
 #undef AHIP_LAUNCH_TB

@@ -256,10 +256,17 @@ __device__ __forceinline__ float gsum(float v) {       // sum over the 4 lanes (
 // ---------------------------------------------------------------------------- tile packing
 // Greedy packing of consecutive centre atoms into tiles (<= tile_slots edges, <= maxa atoms), done
 // sequentially inside independent segments of SEG atoms so it parallelises.
+// maxdeg != null: the tile shape is chosen HERE from the largest degree of the current edge list, which the host has not read back
+// (k_fused: 64 slots / 6 centres while every centre has <= 64 edges, else 128 / 12; the host launches both shapes of the model kernel and the one
+// that does not match returns at once).
+__device__ __forceinline__ void pack_shape(const int *maxdeg, int &tile_slots, int &maxa) {
+  if (maxdeg && *maxdeg > 64) { tile_slots = 128; maxa = 12; }
+}
 template <bool FILL>
-static __global__ void k_pack_tiles(int inum, const int *eoff, int nseg, int *seg_count, const int *seg_base, int *tile_a0, int tile_slots, int maxa) {
+static __global__ void k_pack_tiles(int inum, const int *eoff, int nseg, int *seg_count, const int *seg_base, int *tile_a0, int tile_slots, int maxa, const int *maxdeg = nullptr) {
   int sg = blockIdx.x * blockDim.x + threadIdx.x;
   if (sg >= nseg) return;
+  pack_shape(maxdeg, tile_slots, maxa);
   int a = sg * SEG, end = min(inum, a + SEG);
   int nt = 0, cur_e = 0, cur_a = 0;
   int base = FILL ? seg_base[sg] : 0;
@@ -290,10 +297,11 @@ static __global__ void k_centre_info(int inum, const int *ilist, const int *mtyp
 // and the per-centre {atom, type} records -- in ONE single-workgroup launch instead of six (a 10 648-atom step is launch-bound: 0.056 -> 0.03 ms).
 static constexpr int PACK_SMALL_SEGS = 1024;
 static __global__ void __launch_bounds__(PACK_SMALL_SEGS) k_pack_small(int inum, const int *eoff, int nseg, int *tile_a0, int *tile_e0, int *ntiles, int tile_slots, int maxa,
-                                                                       const int *ilist, const int *mtype, int2 *centre) {
+                                                                       const int *ilist, const int *mtype, int2 *centre, const int *maxdeg = nullptr) {
   __shared__ int cnt[PACK_SMALL_SEGS];
   __shared__ int total;
   const int sg = threadIdx.x;
+  pack_shape(maxdeg, tile_slots, maxa);
   int nt = 0;
   const int a = sg * SEG, end = min(inum, a + SEG);
   if (sg < nseg && a < end) {

@@ -770,7 +770,9 @@ static void fusedlx_prepare(Model &m) {
 
 bool fusedlx_run(Model &m, const ComputeArgs &a, std::string *why) {
   constexpr int NW = 4, SLOTS = 16 * NW;
-  if (m.last_max_deg > SLOTS && (m.heavy_thresh != SLOTS || (long long)m.nheavy * 8 > m.inum)) {
+  // (counts still in flight = single-pass edge build with heavy_thresh = SLOTS: every centre with more edges is listed, gets a tile of its own that the
+  // kernel skips, and is evaluated by heavy_generic after the kernel has been enqueued -- the host reads the counts only then)
+  if (!m.counts_pending && m.last_max_deg > SLOTS && (m.heavy_thresh != SLOTS || (long long)m.nheavy * 8 > m.inum)) {
     // centres with more than 64 edges are listed by the edge build and evaluated by the layer-at-a-time kernels; when the edge
     // build did not list them (two-pass fallback) or they are not a small minority, the whole system goes that way
     if (why) *why = "an atom has " + std::to_string(m.last_max_deg) + " edges (> " + std::to_string(SLOTS) + " per tile of the wide fused kernel)";
@@ -795,9 +797,10 @@ bool fusedlx_run(Model &m, const ComputeArgs &a, std::string *why) {
   A.e_tt = m.b_ett.as<unsigned char>(); A.centre = st.centre.as<int2>(); A.rvec = m.b_rvec.as<float>(); A.rcut = m.rcut_model_dev;
   A.tile_a0 = st.tile_a0.as<int>(); A.tile_e0 = st.tile_e0.as<int>(); A.ntiles = st.ntiles.as<int>();
   A.tile_counter = (unsigned int *)(st.ntiles.as<int>() + 1);
+  m.d_ntiles_last = st.ntiles.as<int>(); m.last_tile_slots = SLOTS;
   // claims of TCHUNK tiles amortise the counter's round trip; with few tiles per workgroup the last claim decides the makespan
   // (10 648 Si atoms: 4 659 tiles on 512 workgroups = 12 instead of 10 tile times with claims of 4)
-  A.tchunk = (m.nedges / 64 > (long long)grid * 256) ? TCHUNK : 1;
+  A.tchunk = (lx_nedges_estimate(m) / 64 > (long long)grid * 256) ? TCHUNK : 1;
   A.f = a.f; A.eatom = a.eatom; A.partial = st.partial.as<double>();
   {
     StageTimer tm(m, "model_fused", s);

@@ -54,6 +54,10 @@ struct FusedLxState {
   int L = 0, UT = 0;
 };
 
+// edge total for the claim-size heuristic: the value itself when it is on the host, else the last one that was, else from the list's size
+static long long lx_nedges_estimate(const Model &m) {
+  return !m.counts_pending ? m.nedges : m.nedges_hint > 0 ? m.nedges_hint : (long long)(0.58 * (double)m.nneigh);
+}
 // Tile packing shared by the wide fused kernels: consecutive centres into tiles of <= slots edges and <= maxa centres
 // (k_pack_tiles, fused_common.h), per-centre {atom, type}, per-edge packed types, first edge of every tile.
 static void lx_pack_tiles(Model &m, FusedLxState &st, const ComputeArgs &a, int slots, int maxa) {

@@ -21,6 +21,8 @@ decomposition / exchange logic with gloo.
 from __future__ import annotations
 
 import math
+import os
+import time
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -57,7 +59,10 @@ class HipBackend:
         self.stats = None          # bench.py sets this to a dict: per-stage ms and edge counts are summed over the calls of a step
 
     def _collect(self) -> None:
-        if self.stats is None:
+        # stats = None: nothing is read back.  stats = {} with defer_stats: the library keeps recording its stage events and the caller
+        # reads the sums once (model.timings_and_counts()) -- per-call collection waits for the call's kernels and for its edge count,
+        # i.e. it synchronises host and device at every force evaluation (fine for tests, wrong inside a timed loop).
+        if self.stats is None or getattr(self, "defer_stats", False):
             return
         for k, v in self.model.timings().items():
             self.stats[k] = self.stats.get(k, 0.0) + v
@@ -171,6 +176,29 @@ class Simulation:
         self.rebuild()
 
     # ---- the library's ghost exchange (csrc/comm.hip) -----------------------------------------------
+    def _comm_timed(self, fn, ptr: int) -> None:
+        """One library exchange on the current stream; with `time_comm` set (bench.py) bracketed by events on that stream -- read by
+        comm_ms() after the timed region, never inside it."""
+        if not getattr(self, "time_comm", False) or self.dev.type != "cuda":
+            fn(ptr, self._stream())
+            return
+        st = torch.cuda.current_stream(self.dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(st)
+        fn(ptr, self._stream())
+        b.record(st)
+        self._comm_events = getattr(self, "_comm_events", [])
+        self._comm_events.append((a, b))
+
+    def comm_ms(self) -> float:
+        """device time (ms) of the exchanges recorded since the last call (stream time of pack / transport / unpack, both directions)."""
+        ev, self._comm_events = getattr(self, "_comm_events", []), []
+        tot = 0.0
+        for a, b in ev:
+            b.synchronize()
+            tot += a.elapsed_time(b)
+        return tot
+
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else 0
 
@@ -217,7 +245,11 @@ class Simulation:
         if self.nranks == 1:
             return capi.Comm(model.L, 0, 1)
         is_rccl = self.dev.type == "cuda" and hasattr(self.dist, "get_backend") and self.dist.get_backend() == "nccl"
+        if os.environ.get("AHIP_COMM", "") == "hosted":        # A/B and first-contact debugging: force the host-staged transport over the process group
+            is_rccl = False
+        self.comm_info = {"transport": "hosted", "rccl_version": 0, "init_ms": 0.0}
         if is_rccl:
+            t_init = time.perf_counter()
             # the library's own RCCL communicator: rank 0's ncclUniqueId travels through the process group.  Every rank reports whether
             # its communicator came up; if any did not (librccl.so missing, init failure) ALL ranks fall back to the hosted transport over the
             # process group, so a first-contact problem costs speed, not the run.
@@ -238,6 +270,8 @@ class Simulation:
                     print(f"[md] rank {self.rank}: ahip_comm_create_rccl failed ({e})", flush=True)
             self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
             if int(ok.item()) == 1:
+                self.comm_info = {"transport": "rccl", "rccl_version": int(model.L.lib.ahip_comm_rccl_version()),
+                                  "init_ms": round(1e3 * (time.perf_counter() - t_init), 1)}
                 return comm
             if comm is not None:
                 comm.close()
@@ -246,7 +280,9 @@ class Simulation:
     def _set_comm_plan(self) -> None:
         if self.comm is None:
             return
-        if self._ghost_src is not None or self.nall == self.nlocal:
+        # the single-rank plan (image chains resolved locally) only on ONE rank: with several ranks a brick that received no ghosts may still
+        # have slabs to send (a cluster or slab next to an empty neighbour brick) and its peer posts the matching receive
+        if self.nranks == 1 and (self._ghost_src is not None or self.nall == self.nlocal):
             ng = self.nall - self.nlocal
             self.comm.set_plan_local(self.nlocal, ng, self._ghost_src.data_ptr() if ng else 0, self._ghost_shift.data_ptr() if ng else 0)
             return
@@ -418,7 +454,7 @@ class Simulation:
     # ---- per-step communication -------------------------------------------------------------------
     def forward_comm(self) -> None:
         if self.comm is not None:                                  # HIP pack kernels + RCCL groups inside the library
-            self.comm.forward(self.x.data_ptr(), self._stream())
+            self._comm_timed(self.comm.forward, self.x.data_ptr())
             return
         if self._ghost_src is not None:                            # one rank: all ghosts are images of local atoms
             self.x[self.nlocal:] = self.x[self._ghost_src] + self._ghost_shift
@@ -436,7 +472,7 @@ class Simulation:
 
     def reverse_comm(self) -> None:
         if self.comm is not None:
-            self.comm.reverse(self.f.data_ptr(), self._stream())
+            self._comm_timed(self.comm.reverse, self.f.data_ptr())
             return
         if self._ghost_src is not None:
             self.f[: self.nlocal].index_add_(0, self._ghost_src, self.f[self.nlocal:])      # sources are local rows: disjoint from the ghost rows read

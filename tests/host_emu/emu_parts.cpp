@@ -53,6 +53,8 @@ void fusedlx2_free(Model &) {}
 void edges_compact_heavy(Model &, const ComputeArgs &) {}
 bool edges_build_f32(Model &, const ComputeArgs &) { return false; }   // emulation runs the two-pass kernels
 void edges_free(Model &) {}
+void edges_counts(Model &) {}
+int edges_max_row(Model &, int, const int *) { return -1; }
 bool gemm_f32(hipStream_t, long long, int, int, const float *, int, const float *, int, bool, float *, int, bool, float *, const float *) { return false; }
 bool latent_update_bwd_f32(hipStream_t, long long, int, const float *, const float *, const float *, const float *, float *, float *, float *) { return false; }
 bool embed_bwd_Y_f32(hipStream_t, long long, int, int, const float *, const float *, float *) { return false; }

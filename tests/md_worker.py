@@ -44,6 +44,12 @@ def main():
     path = os.path.join(model_dir, f"md_small_r{rank}.ahip")
     model_file.save_ahip(path, cfg, w)
     cell, pos, _ = lmp_like.diamond_si(3)
+    if len(sys.argv) > 7 and sys.argv[7] == "cluster":
+        # a 64-atom cluster in a 40 A box, all of it inside the first brick of a 2x1x1 grid and within reach of the second: rank 0 owns every
+        # atom, receives no ghost and still has a slab to send; rank 1 owns nothing and receives ghosts (the peer's receive must be met)
+        _, pos, _ = lmp_like.diamond_si(2)
+        pos = pos - pos.min(axis=0) + np.array([8.5, 14.0, 14.0])
+        cell = np.diag([40.0, 40.0, 40.0])
     vel = md.maxwell_boltzmann(len(pos), np.full(len(pos), 28.0855), temperature, 12345)
     f2, x2, e2, nreb, nloc = run(lib, path, cell, pos, vel, cfg, grid, rank, dist, nsteps, skin)
     nl = torch.tensor([nloc]); dist.all_reduce(nl)

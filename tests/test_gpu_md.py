@@ -150,3 +150,25 @@ def test_bench_two_ranks_on_one_gpu(launcher):
     assert abs(d["value"] - 10648 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-3 * d["value"]        # whole-job atoms / max-over-ranks time
     assert d["config"]["grid"] == "2x1x1" and d["config"]["kernel_path"] == "fused_f32"
     assert d["config"]["comm"] == "overlapped" and d["config"]["comm_transport"].startswith("library/")
+    # the N > 1 line carries the exchange's device time and the max-over-ranks stage times
+    assert d["config"]["comm_ms"] > 0 and d["config"]["stage_ms"]["model_fused"] >= d["config"]["stage_ms_rank0"]["model_fused"] - 1e-3
+    assert d["roofline"]["launches_per_step"] == 3                 # three centre ranges per step in the overlapped schedule
+
+def test_bench_fails_fast_when_a_rank_dies():
+    """`bench.py --gpus 2`, rank 1 exits with status 17 after start-up (AHIP_BENCH_TEST_KILL_RANK): the parent must stop rank 0 -- which is
+    waiting for its peer in the first exchange -- and return non-zero within seconds, not sit in a collective until the launcher's timeout
+    (VERDICT r03 #3; the reference leaves this to mpirun, /root/reference/README.md:37-40)."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AHIP_BENCH_ONE_DEVICE="1", OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1", AHIP_BENCH_TEST_KILL_RANK="1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    t0 = time.monotonic()
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    took = time.monotonic() - t0
+    assert r.returncode != 0, "a dead rank must make bench.py fail"
+    assert "rank 1 exited with status 17" in r.stderr.decode(), r.stderr.decode()[-2000:]
+    assert not [l for l in r.stdout.decode().splitlines() if l.startswith("{")], "no JSON line from a failed run"
+    # start-up (two torch imports, model load, neighbor build) dominates; after rank 1's exit the parent needs 0.1 s to notice and <= 10 s to stop rank 0
+    assert took < 120, f"took {took:.0f} s"

@@ -77,6 +77,17 @@ def test_gloo_rebuild_and_migration(emu_lib, model_dir, tmp_path):
     np.testing.assert_allclose(z["e2"], z["e1"], rtol=1e-9)
 
 
+def test_gloo_empty_brick_next_to_a_cluster(emu_lib, model_dir, tmp_path):
+    """2x1x1 bricks, every atom in brick 0 (a cluster in a large box): rank 0 receives no ghosts but sends a slab, rank 1 owns nothing.
+    The exchange plan of a rank without ghosts must still post its sends (the single-rank plan was taken whenever
+    nall == nlocal and the peer's receive waited forever); trajectory and energy equal the single-rank run."""
+    z = _run_workers(emu_lib, model_dir, tmp_path, 2, 29739, extra=(300.0, 3, 1.0, "cluster"))
+    np.testing.assert_allclose(z["f2"], z["f1"], atol=1e-10)
+    np.testing.assert_allclose(z["x2"], z["x1"], atol=1e-12)
+    np.testing.assert_allclose(z["e2"], z["e1"], rtol=1e-12)
+    assert np.abs(z["f1"]).max() > 1e-3
+
+
 def test_interior_boundary_split_equals_one_call(emu_lib, model_dir):
     """The overlapped schedule (interior-first ordering, three ahip_compute_dev_range calls per evaluation, exchange between
     them) gives the forces, energy and virial of the single ahip_compute_dev call on the unordered atoms -- equal up to

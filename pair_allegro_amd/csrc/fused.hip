@@ -191,7 +191,6 @@ __device__ __forceinline__ void linear_b(__amdgpu_buffer_rsrc_t W, int &wp, cons
       a[i] = ring[(RP + NF * s + i) % RB];
       ring[(RP + NF * s + i) % RB] = __builtin_bit_cast(u32x4, bload(W, v16, (wp + (NF * s + i + RB) * 256) * 4));
     }
-    if (ks == 0 && p > 0 && Epi::STORES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NF) : "memory");      // the previous pair's accumulator stores have completed (see linear_s)
     // the two accumulators alternate; smallest terms first
 #pragma unroll
     for (int m = 0; m < NPROD; ++m) {
@@ -269,14 +268,9 @@ enum { PH_GEOM = 0, PH_TB, PH_EMB, PH_ENV, PH_TP, PH_MIX, PH_LAT, PH_OUT, PH_BLA
 template <int AR> struct RingT {
   f32x4 f[AR != 0 ? 1 : RING];
   u32x4 b[AR == 0 ? 1 : (AR == 1 ? RINGB : RINGB2)];
-  bool pend = false;           // the last linear ended with stores of its accumulators that have not been waited for (see linear_s)
 };
 template <int AR, int KT, int NT, bool ACC, int RPI, class Epi>
 __device__ __forceinline__ void lin(__amdgpu_buffer_rsrc_t W, int &wp, const f32x4 (&in)[KT], f32x4 (&out)[NT], int v16, RingT<AR> &ring, Epi epi) {
-  // accumulator stores of the previous linear's last tile pair complete before this linear's MFMAs are issued (linear_s); nothing younger
-  // than those stores is in flight here, hence vmcnt(0)
-  if (AHIP_LIN_WAIT_MODE != 0 && ring.pend) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  ring.pend = Epi::STORES;
   if constexpr (AR != 0) {
     static_assert(KT % 2 == 0, "K-steps are pairs of 16-feature tiles");
     constexpr int NTERM = AR == 1 ? 3 : 2;
@@ -286,7 +280,7 @@ __device__ __forceinline__ void lin(__amdgpu_buffer_rsrc_t W, int &wp, const f32
     // ring phase: RPI counts the four 32x32 channel-mixing blocks, which consume less than a ring each (2 * NTERM fragments)
     linear_b<KT / 2, NT, ACC, false, (2 * NTERM * RPI) % RingB<NTERM>::N, Epi, NTERM>(W, wp, b, out, unused, v16, ring.b, epi);
   } else {
-    linear_s<KT, NT, ACC, (4 * RPI) % RING, Epi, false>(W, wp, in, out, v16, ring.f, epi);
+    linear_s<KT, NT, ACC, (4 * RPI) % RING, Epi>(W, wp, in, out, v16, ring.f, epi);
   }
 }
 

@@ -22,8 +22,8 @@ static constexpr int RING = AHIP_RING;   // weight fragments in flight per wave
 static constexpr int TCHUNK = 4;         // tiles per claim of the dynamic tile schedule
 
 // Switches that exist for timing experiments only and compute WRONG results (or drop a hazard pad) are refused outside an experiment build.
-#if (defined(ABL_NOROWS) || defined(ABL_NOW) || defined(AHIP_NO_STORE_PAD) || (defined(AHIP_LIN_WAIT_MODE) && AHIP_LIN_WAIT_MODE == 0)) && !defined(AHIP_EXPERIMENT_SWITCHES)
-#error "ABL_NOROWS / ABL_NOW / AHIP_NO_STORE_PAD / AHIP_LIN_WAIT_MODE=0 are timing-experiment switches (wrong results): add -DAHIP_EXPERIMENT_SWITCHES, never in the product build"
+#if (defined(ABL_NOROWS) || defined(ABL_NOW) || defined(AHIP_NO_STORE_PAD)) && !defined(AHIP_EXPERIMENT_SWITCHES)
+#error "ABL_NOROWS / ABL_NOW / AHIP_NO_STORE_PAD are timing-experiment switches (wrong results): add -DAHIP_EXPERIMENT_SWITCHES, never in the product build"
 #endif
 
 __host__ __device__ inline int feat16(int t, int r, int g) { return 16 * t + 4 * g + r; }
@@ -162,7 +162,7 @@ template <int NT> struct EpiResidual : EpiSave {   // raw u rows to scratch, out
   __device__ __forceinline__ float apply(int ot, int r, float v) const { return ra * xold[ot][r] + rbf * v; }
 };
 
-template <int KT, int NT, bool ACC, int RP, class Epi, bool FIRSTWAIT = true>
+template <int KT, int NT, bool ACC, int RP, class Epi>
 __device__ __forceinline__ void linear_s(__amdgpu_buffer_rsrc_t W, int &wp, const f32x4 (&in)[KT], f32x4 (&out)[NT], int v16,
                                          f32x4 (&ring)[RING], Epi epi) {
   static_assert(NT % 2 == 0, "output tiles are processed in pairs");
@@ -188,21 +188,8 @@ __device__ __forceinline__ void linear_s(__amdgpu_buffer_rsrc_t W, int &wp, cons
     ring[(RP + 2 * s + 1) % RING] = bload_w(W, v16 + 1024, wo);           // + 1 KiB: the instruction's immediate offset
     wo += 2048;
     pin_s(wo);
-    // Where an output-tile pair begins, everything older than the two requests above must have completed -- in particular the stores
-    // of the PREVIOUS pair's accumulators (Epi::tile_done: saved rows), issued straight from the MFMA result registers.  Without this
-    // wait the one-layer instance of fused_lx2 produced wrong forces in ~1 % of its tiles, different tiles on every launch, mostly in
-    // the first tiles of a launch (cold L2: the vector-memory queue backs up): the rows read back in the backward pass did not hold
-    // what the forward pass had in its registers.  Holding the stores' scalar offsets live, more wait states before or after them, and a
-    // vmcnt(0) at the forward/backward boundary did NOT cure it; completing the stores before the next pair's MFMAs are issued does
-    // (44 / 44 launches).  The wait also bounds the ring: the fragments requested up to three steps ago must have arrived here, which
-    // they have at L2 latency (41k-atom water box: 26.4 -> 26.7 ms).
-#ifndef AHIP_LIN_WAIT_MODE
-#define AHIP_LIN_WAIT_MODE 2
-#endif
-    // mode 2: at the first step of every linear (the previous linear may have ended with such stores; FIRSTWAIT = false: the caller keeps
-    // track of that itself, fused.hip) and, inside a linear, only where its epilogue stores accumulators (Epi::STORES); mode 1: at every
-    // pair; mode 0: never (A/B timing only -- unsafe)
-    if (kt == 0 && (AHIP_LIN_WAIT_MODE == 1 || (AHIP_LIN_WAIT_MODE == 2 && ((p == 0 && FIRSTWAIT) || (p > 0 && Epi::STORES))))) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    // (Rounds 2-3 waited here -- s_waitcnt vmcnt(2) where a tile pair begins -- until the previous pair's accumulator stores had completed: that
+    // hid the store-data hazard now padded inside bstore(); with the pad the waits are redundant: 57.3 -> 56.9 ms at 1 M Si, soak green.)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll

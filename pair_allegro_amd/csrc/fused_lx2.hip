@@ -187,7 +187,7 @@ __device__ __forceinline__ void mix_rows_p(float (&V)[9][2][4], __amdgpu_buffer_
     }
     const int v16 = fresh_lane() << 4;
     if constexpr (FWD) linear_s<4, 2, false, 0>(WB, wp, in, o, v16, ring, EpiSaveN<2>{SB, row0 + LM * 2, v16});
-    else linear_s<4, 2, false, 0, EpiNone, false>(WB, wp, in, o, v16, ring, EpiNone{});      // backward: no linear stores accumulators, no wait at its start (linear_s)
+    else linear_s<4, 2, false, 0>(WB, wp, in, o, v16, ring, EpiNone{});
 #pragma unroll
     for (int t = 0; t < 2; ++t) acc_put4(V[LM][t], (!FWD && LM == 0) ? o[t] + ds[t] : o[t]);
     __builtin_amdgcn_sched_barrier(0);
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
     float V[D][HT][4];       // own half of the edge tensor, forward; of its gradient, backward: parked in AGPRs (acc_park)
     {
       f32x4 w0[EWH];
-      linear_s<4, EWH, false, 0, EpiSave, false>(WB, wp, x, w0, V16(), ring, EpiSave{SB, S::R_W0, V16()});
+      linear_s<4, EWH, false, 0>(WB, wp, x, w0, V16(), ring, EpiSave{SB, S::R_W0, V16()});
 #pragma unroll
       for (int lm = 0; lm < D; ++lm)
 #pragma unroll
@@ -415,12 +415,12 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
         linear_s<8, 2, false, 0>(WB, wp, cat, z, V16(), ring, EpiSiluSaveD{SB, RL + S::O_Z1, V16()});
         x_swap<2>(X, xb, z, pr);
         zin[0] = z[0]; zin[1] = z[1]; zin[2] = pr[0]; zin[3] = pr[1];
-        linear_s<4, 2, false, 0, EpiSiluSaveD, false>(WB, wp, zin, z2, V16(), ring, EpiSiluSaveD{SB, RL + S::O_Z2, V16()});
+        linear_s<4, 2, false, 0>(WB, wp, zin, z2, V16(), ring, EpiSiluSaveD{SB, RL + S::O_Z2, V16()});
         x_swap<2>(X, xb, z2, pr);
         zin[0] = z2[0]; zin[1] = z2[1]; zin[2] = pr[0]; zin[3] = pr[1];
         const float ra = lds.res[kk][0], rbf = lds.res[kk][1] * fc;
         f32x4 xo[2] = {x[0], x[1]};
-        linear_s<4, 2, false, 0, EpiResidual<2>, false>(WB, wp, zin, xn, V16(), ring, EpiResidual<2>{{SB, RL + S::O_U, V16()}, xo, ra, rbf});
+        linear_s<4, 2, false, 0>(WB, wp, zin, xn, V16(), ring, EpiResidual<2>{{SB, RL + S::O_U, V16()}, xo, ra, rbf});
         x_swap<2>(X, xb, xn, pr);
         x[0] = xn[0]; x[1] = xn[1]; x[2] = pr[0]; x[3] = pr[1];
       }
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dzr[t][r] = deps * wo1[t][r] * dsilu1(zr[t][r]);
-      linear_s<2, 4, false, 0, EpiNone, false>(WB, wp, dzr, dx, V16(), ring, EpiNone{});
+      linear_s<2, 4, false, 0>(WB, wp, dzr, dx, V16(), ring, EpiNone{});
     }
     float dfc_part = 0.f;    // partial sums over the own channels / own latent tiles: they meet in lds.ych at the end of the tile
     float dY[D];
@@ -487,14 +487,14 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
           dfc_part += rb * hsum4(accv);
           pin(dfc_part);
         }
-        linear_s<4, 2, false, 0, EpiMulRows<2>, false>(WB, wp, du, dh, V16(), ring, EpiMulRows<2>{zt});
+        linear_s<4, 2, false, 0>(WB, wp, du, dh, V16(), ring, EpiMulRows<2>{zt});
         x_swap<2>(X, xb, dh, pr);
         din[0] = dh[0]; din[1] = dh[1]; din[2] = pr[0]; din[3] = pr[1];
-        linear_s<4, 2, false, 0, EpiMulRows<2>, false>(WB, wp, din, dh, V16(), ring, EpiMulRows<2>{rows1});
+        linear_s<4, 2, false, 0>(WB, wp, din, dh, V16(), ring, EpiMulRows<2>{rows1});
         x_swap<2>(X, xb, dh, pr);
         din[0] = dh[0]; din[1] = dh[1]; din[2] = pr[0]; din[3] = pr[1];
         f32x4 dcat[4];       // own x tiles (2), own scalar tiles (2)
-        linear_s<4, 4, false, 0, EpiNone, false>(WB, wp, din, dcat, V16(), ring, EpiNone{});
+        linear_s<4, 4, false, 0>(WB, wp, din, dcat, V16(), ring, EpiNone{});
         P[0] += dcat[0]; P[1] += dcat[1];
         ds[0] = dcat[2]; ds[1] = dcat[3];
       }
@@ -616,7 +616,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
           load_rows<2>(SB, S::R_LAYER(kk - 1) + S::O_Z2, zt, V16());
         } else load_rows<L * HT>(SB, S::R_W0 + HT, w0pre, V16());
         __builtin_amdgcn_sched_barrier(0);
-        linear_s<EWH, 4, true, 0, EpiNone, false>(WB, wp, dom, P, V16(), ring, EpiNone{});      // split by input tile: partial sums over the own channels
+        linear_s<EWH, 4, true, 0>(WB, wp, dom, P, V16(), ring, EpiNone{});      // split by input tile: partial sums over the own channels
       }
       if (kk > 0) {
         // dE/dx^{kk-1} = P + P(partner): reduce-scatter (each wave completes its own two tiles), then all-gather
@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
         for (int lm = 1; lm < D; ++lm) pin(dY[lm]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      linear_s<EWH, 4, true, 0, EpiNone, false>(WB, wp, dw0, dx, V16(), ring, EpiNone{});
+      linear_s<EWH, 4, true, 0>(WB, wp, dw0, dx, V16(), ring, EpiNone{});
       wp = wp0;                                                            // last linear of the tile (wrap-around copy follows it)
     }
     PHASEP(PP_BEMB);

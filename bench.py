@@ -485,6 +485,10 @@ def cpu_baseline_and_parity(lib, config, device_index, ncell, path):
                              f"{main_run['warmup']} warm-up + {main_run['reps']} timed evaluations, {main_run['ms_model']:.0f} ms each (model only), "
                              f"{main_run['ms_total']:.0f} ms with preprocess + scatter; "
                              f"{1e3 * main_run['ms_model'] / max(main_run['nedges'], 1):.1f} us per edge",
+                   # SURVEY 8d asks for 3 warm-up + >= 10 timed evaluations; the bounded-sample rule (10-30 s of CPU work) allows that only
+                   # while one evaluation takes under 2 s -- stated per run so nobody has to infer it from the text above
+                   "protocol": (f"{main_run['warmup']} warm-up + {main_run['reps']} timed evaluations; rule: 3 + 10 when one evaluation takes < 2 s, "
+                                f"else 1 + 3 inside a 25 s budget (this sample: {main_run['ms_model'] / 1e3:.2f} s per evaluation)"),
                    "value_glue_inclusive": round(main_run["nlocal"] / (main_run["ms_total"] * 1e-3), 1),
                    "thread_sweep": {"sample": sweep_label, "runs": sweep},
                    "runs": [{k: r[k] for k in ("sample", "nlocal", "nedges", "threads", "bind", "warmup", "reps", "ms_model", "ms_total")} for r in runs]}

@@ -88,7 +88,16 @@ def workload(config: int, ncell: int = 0):
         return dict(name=f"{len(pos)}-atom water ({m}^3 molecules, O/H), model L (l_max=2, U=64, S=64, 3 layers)",
                     cell=cell, pos=pos, mtype=(types - 1).astype(np.int32), cfg=cfg,
                     masses=[lmp_like.WATER_MASSES[s] for s in cfg["type_names"]], lammps_names=["O", "H"], lammps_types=types)
-    raise SystemExit(f"bench.py: unknown --config {config} (2, 3, 4 or 5)")
+    if config == 6:
+        # not a BASELINE config: config 5's water box with the reference test YAML's own model shape (l_max = 2, 32 tensor features, 3 layers,
+        # /root/reference/tests/test_data/test_repro_allegro.yaml:89-99) -- the shape k_fused_lx serves
+        m = ncell or 55
+        cell, pos, types = lmp_like.water(m)
+        cfg = model_file.model_L(num_tensor_features=32, avg_num_neighbors=53.6)
+        return dict(name=f"{len(pos)}-atom water ({m}^3 molecules, O/H), reference-YAML model shape (l_max=2, U=32, S=64, 3 layers)",
+                    cell=cell, pos=pos, mtype=(types - 1).astype(np.int32), cfg=cfg,
+                    masses=[lmp_like.WATER_MASSES[s] for s in cfg["type_names"]], lammps_names=["O", "H"], lammps_types=types)
+    raise SystemExit(f"bench.py: unknown --config {config} (2, 3, 4, 5 or 6)")
 
 
 def kernel_source_hash() -> str:
@@ -161,7 +170,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=4, help="BASELINE.json config: 2 (10k Si), 3 (100k Li3PO4), 4 (1M Si, the metric), 5 (500k water, model L)")
+    ap.add_argument("--config", type=int, default=4, help="BASELINE.json config: 2 (10k Si), 3 (100k Li3PO4), 4 (1M Si, the metric), 5 (500k water, model L); 6 = config 5's box with the reference YAML's model shape (U=32)")
     ap.add_argument("--ncell", type=int, default=0, help="override the replication of the chosen config (smaller boxes for quick runs)")
     ap.add_argument("--path", default="auto", choices=["auto", "fused", "generic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -350,7 +359,7 @@ def main():
             "metric": "atom_steps_per_sec", "value": round(value, 1), "unit": "atom-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE config {args.config}: {wl['name']}, r_max {cfg['r_max']} A + skin 1.0 A, NVE dt=1 fs",
+            "config": {"workload": f"{('BASELINE config ' + str(args.config)) if args.config <= 5 else 'extra config 6 (not in BASELINE.json)'}: {wl['name']}, r_max {cfg['r_max']} A + skin 1.0 A, NVE dt=1 fs",
                        "grid": "x".join(map(str, grid)), "kernel_path": used_path, "rebuilds": sim.nrebuild,
                        "rebuilds_in_timed_steps": rebuilds_timed, "rebuild_ms": round(rebuild_ms, 3),
                        "steps_per_rebuild": (round(args.steps / rebuilds_timed, 1) if rebuilds_timed else None),
@@ -384,7 +393,7 @@ def cpu_sample(config: int, ncell: int):
         cell, pos, types = lmp_like.li3po4((3, 5, 6))         # 2 880 atoms, same cell
         mapper = np.array([wl["cfg"]["type_names"].index(s) for s in wl["lammps_names"]], dtype=np.int32)
         return dict(wl, name="2880-atom Li3PO4 (3x5x6 cells)", cell=cell, pos=pos, lammps_types=types, mtype=mapper[types - 1])
-    return workload(5, 6)                                     # 648-atom water, model L (a CPU evaluation of model L costs ~20 ms per atom)
+    return workload(config if config == 6 else 5, 6)          # 648-atom water, model L / Y (a CPU evaluation of model L costs ~20 ms per atom)
 
 
 def cpu_baseline_and_parity(lib, config, device_index, ncell, path):

@@ -382,10 +382,11 @@ static void heavy_generic(ahip_model *m, const ComputeArgs &a) {
 }
 
 static void run_model(ahip_model *m, const ComputeArgs &a) {
-  AHIP_CHECK(hipMemsetAsync(a.engvir, 0, 7 * sizeof(double), a.stream));
   m->nedges = 0;
-  if (m->inum == 0) return;                                   // empty sub-domain (pair_nequip_allegro.cpp:340-341)
   const bool f64 = (m->opt_precision == "float64") || (m->hm.model_dtype == "float64");
+  // the 7 energy / virial sums start from zero: the single-pass edge build clears them in its first kernel, every other way here
+  if (m->inum == 0 || f64) AHIP_CHECK(hipMemsetAsync(a.engvir, 0, 7 * sizeof(double), a.stream));
+  if (m->inum == 0) return;                                   // empty sub-domain (pair_nequip_allegro.cpp:340-341)
   if (f64) {
     if (m->opt_path == "fused") throw UnsupportedError("the fused MFMA path computes in float32; use path=generic for float64");
     build_edges<double>(*m, a);
@@ -396,7 +397,7 @@ static void run_model(ahip_model *m, const ComputeArgs &a) {
   m->have_ett = false;
   m->nheavy = 0;
   m->heavy_thresh = (m->opt_path != "generic" && !fused_model_supported(*m, nullptr) && fusedlx_model_supported(*m, nullptr)) ? 64 : 0;
-  if (!edges_build_f32(*m, a)) { m->nheavy = 0; m->heavy_thresh = 0; build_edges<float>(*m, a); }
+  if (!edges_build_f32(*m, a)) { m->nheavy = 0; m->heavy_thresh = 0; AHIP_CHECK(hipMemsetAsync(a.engvir, 0, 7 * sizeof(double), a.stream)); build_edges<float>(*m, a); }
 #ifdef AHIP_EXPERIMENT_SWITCHES      // never in the product build: a switch that skips the model returns no forces
   static const bool edges_only = std::getenv("AHIP_EDGES_ONLY") != nullptr;     // timing experiments on the edge build alone
   if (edges_only) { m->last_path = "edges_only"; return; }

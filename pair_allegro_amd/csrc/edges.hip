@@ -35,9 +35,14 @@ static constexpr int EB_PER_WAVE = 8;    // centres per wave
 // straddles sectors, the type sits in another array).  Rewritten every step by k_pack_xt (a 60 MB stream at 1 M atoms).
 struct __attribute__((aligned(32))) AtomXT { double x, y, z; int ft, mt; };
 
+// It also clears the edge build's header + look-back status words and the caller's 7 energy / virial sums (two memset launches less per call:
+// a small system's step is a chain of short launches).
 __global__ void __launch_bounds__(256) k_pack_xt(int nall, const double *__restrict__ x, const int *__restrict__ ftype,
-                                                  const int *__restrict__ mtype, AtomXT *__restrict__ xt) {
+                                                  const int *__restrict__ mtype, AtomXT *__restrict__ xt, unsigned long long *clear, int nclear,
+                                                  double *zero7) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < nclear) clear[i] = 0ull;
+  if (i < 7) zero7[i] = 0.0;
   if (i >= nall) return;
   AtomXT a;
   a.x = x[3 * (size_t)i]; a.y = x[3 * (size_t)i + 1]; a.z = x[3 * (size_t)i + 2];
@@ -54,7 +59,7 @@ __global__ void __launch_bounds__(EB_THREADS) k_build_edges(int inum, const int 
                                                        unsigned int *ticket, unsigned long long *status, int *eoff, int *e_ii,
                                                        int *e_j, float *rvec, int *maxdeg, int *overflow,
                                                        unsigned char *e_tt, int heavy_thresh,
-                                                       int *heavy_cnt, int *heavy_list) {
+                                                       int *heavy_cnt, int *heavy_list, int *total_out) {
   __shared__ int s_cnt2[2][EB_ATOMS];          // counters of two consecutive units (no barrier between the stores of one and the
   __shared__ int s_base2[2][EB_ATOMS + 1];     // counting of the next)
   __shared__ int s_blk, s_claim2[2];           // claims double-buffered by unit parity like the counters: a wave may still be reading one while thread 0 posts the next
@@ -247,7 +252,7 @@ __global__ void __launch_bounds__(EB_THREADS) k_build_edges(int inum, const int 
   // ---- offsets + edges -------------------------------------------------------------------------------
   take_rows();                           // next unit's rows have arrived; its neighbour indices travel during the stores
   if (tid < EB_ATOMS && a_begin + tid < inum) eoff[a_begin + tid] = (int)(gbase + s_base[tid]);
-  if (tid == 0 && a_begin + EB_ATOMS >= inum) eoff[inum] = (int)(gbase + s_base[min(EB_ATOMS, inum - a_begin)]);
+  if (tid == 0 && a_begin + EB_ATOMS >= inum) { const int tot = (int)(gbase + s_base[min(EB_ATOMS, inum - a_begin)]); eoff[inum] = tot; *total_out = tot; }    // the total also next to the other counters: one read-back
 #pragma unroll
   for (int k = 0; k < EB_PER_WAVE; ++k) {
     const int la = wave * EB_PER_WAVE + k;
@@ -375,10 +380,9 @@ bool edges_build_f32(Model &m, const ComputeArgs &a) {
     if (!st.chain) AHIP_CHECK(hipEventCreateWithFlags(&st.chain, hipEventDisableTiming));
     else AHIP_CHECK(hipStreamWaitEvent(a.stream, st.chain, 0));
   }
-  // header: [0] ticket (u32), [1] maxdeg, [2] overflow, [3] number of heavy centres; status array starts at byte 64
+  // header: [0] ticket (u32), [1] maxdeg, [2] overflow, [3] number of heavy centres, [4] edge total; status array starts at byte 64
   const size_t bytes = 64 + (size_t)nunits * sizeof(unsigned long long);
   st.flags.reserve(bytes);
-  AHIP_CHECK(hipMemsetAsync(st.flags.p, 0, bytes, a.stream));
   const size_t cap = (size_t)std::max<long long>(m.nneigh, 1);            // upper bound: every list entry survives
   m.b_eoff.reserve((size_t)(inum + 2) * sizeof(int));
   m.b_eii.reserve(cap * sizeof(int));
@@ -390,11 +394,13 @@ bool edges_build_f32(Model &m, const ComputeArgs &a) {
   if (m.heavy_thresh > 0) st.heavy.reserve((size_t)std::max(inum, 1) * sizeof(int));
   const int nall = std::max(m.nall, 1);
   st.xt.reserve((size_t)nall * sizeof(AtomXT));
-  hipLaunchKernelGGL(k_pack_xt, dim3((nall + 255) / 256), dim3(256), 0, a.stream, m.nall, a.x, a.ftype, a.mtype, (AtomXT *)st.xt.p);
+  const int nclear = (int)(bytes / 8);
+  hipLaunchKernelGGL(k_pack_xt, dim3((std::max(nall, nclear) + 255) / 256), dim3(256), 0, a.stream, m.nall, a.x, a.ftype, a.mtype, (AtomXT *)st.xt.p,
+                     (unsigned long long *)st.flags.p, nclear, a.engvir);
 #define EB_LAUNCH(CH, DY) hipLaunchKernelGGL((k_build_edges<CH, DY>), dim3(nblocks), dim3(EB_THREADS), 0, a.stream, inum, m.d_ilist, m.d_nloff, m.d_nlj,       \
                      (const AtomXT *)st.xt.p, a.cutsq, a.nft, nunits, (unsigned int *)hdr, (unsigned long long *)((char *)st.flags.p + 64),   \
                      m.b_eoff.as<int>(), m.b_eii.as<int>(), m.b_ej.as<int>(), m.b_rvec.as<float>(), hdr + 1, hdr + 2,                \
-                     m.b_ett.as<unsigned char>(), m.heavy_thresh, hdr + 3, st.heavy.as<int>())
+                     m.b_ett.as<unsigned char>(), m.heavy_thresh, hdr + 3, st.heavy.as<int>(), hdr + 4)
   if (dyn) { if (one_chunk) EB_LAUNCH(1, true); else EB_LAUNCH(2, true); }
   else {
     if (one_chunk) EB_LAUNCH(1, false); else EB_LAUNCH(2, false);
@@ -407,8 +413,7 @@ bool edges_build_f32(Model &m, const ComputeArgs &a) {
   // entries (known since the list was installed) no row can overflow, the degree is bounded by the row length, and the kernels that follow
   // read the totals from device memory.
   int *h3 = st.h_back;
-  AHIP_CHECK(hipMemcpyAsync(h3, hdr, 4 * sizeof(int), hipMemcpyDeviceToHost, a.stream));
-  AHIP_CHECK(hipMemcpyAsync(h3 + 4, m.b_eoff.as<int>() + inum, sizeof(int), hipMemcpyDeviceToHost, a.stream));
+  AHIP_CHECK(hipMemcpyAsync(h3, hdr, 5 * sizeof(int), hipMemcpyDeviceToHost, a.stream));       // ticket, max degree, overflow, heavy centres, edge total
   AHIP_CHECK(hipEventRecord(st.ev_back, a.stream));
   m.d_maxdeg = hdr + 1;
   m.have_ett = true;

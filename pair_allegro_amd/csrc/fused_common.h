@@ -283,22 +283,44 @@ static __global__ void k_centre_info(int inum, const int *ilist, const int *mtyp
 // Small systems (<= PACK_SMALL_SEGS segments = 131 072 centres): the whole tile packing -- segment counts, their scan, the fill, the tile bounds
 // and the per-centre {atom, type} records -- in ONE single-workgroup launch instead of six (a 10 648-atom step is launch-bound: 0.056 -> 0.03 ms).
 static constexpr int PACK_SMALL_SEGS = 1024;
+static constexpr int PACK_CH = 32768;          // atoms per LDS chunk of k_pack_small (a multiple of SEG): 129 KB of edge offsets at a time
+// Round 4: the segment walks read the edge offsets from LDS.  A thread walking its 128 atoms straight from global memory touches one cache line
+// per lane and step (the segments are 512 B apart): 48 us for 10 648 atoms, 5 % of a step of that system and paid three times per step by the
+// overlapped multi-rank schedule.  Now the offsets of 32 768 atoms at a time are loaded coalesced into LDS (one pad word per segment: the 256
+// walkers of a chunk then hit different banks), the walks, the tiles' first edges and the tile bounds come from there.
+__device__ __forceinline__ int pack_lds_pos(int k) { return k + (k >> 7); }
 static __global__ void __launch_bounds__(PACK_SMALL_SEGS) k_pack_small(int inum, const int *eoff, int nseg, int *tile_a0, int *tile_e0, int *ntiles, int tile_slots, int maxa,
                                                                        const int *ilist, const int *mtype, int2 *centre, const int *maxdeg = nullptr) {
   __shared__ int cnt[PACK_SMALL_SEGS];
+  __shared__ int se[PACK_CH + PACK_CH / SEG + 2];
   __shared__ int total;
   const int sg = threadIdx.x;
   pack_shape(maxdeg, tile_slots, maxa);
-  int nt = 0;
+  // per-centre {atom, type} records: independent of everything below, their two dependent loads run under the first chunk's staging
+  for (int ii = sg; ii < inum; ii += PACK_SMALL_SEGS) { const int i = ilist[ii]; centre[ii] = make_int2(i, mtype[i]); }
+  const int nchunk = (inum + PACK_CH - 1) / PACK_CH;
   const int a = sg * SEG, end = min(inum, a + SEG);
-  if (sg < nseg && a < end) {
-    int cur_e = 0, cur_a = 0;
-    for (int at = a; at < end; ++at) {
-      const int deg = eoff[at + 1] - eoff[at];
-      if (cur_a == maxa || cur_e + deg > tile_slots) { ++nt; cur_e = 0; cur_a = 0; }
-      cur_e += deg; ++cur_a;
+  const int myc = a / PACK_CH, l0 = a - myc * PACK_CH;      // this thread's segment: chunk and first atom inside it
+  auto stage = [&](int c) {
+    const int c0 = c * PACK_CH, n = min(PACK_CH, inum - c0);
+    for (int k = sg; k <= n; k += PACK_SMALL_SEGS) se[pack_lds_pos(k)] = eoff[c0 + k];
+  };
+  int nt = 0;
+  for (int c = 0; c < nchunk; ++c) {
+    if (c > 0) __syncthreads();
+    stage(c);
+    __syncthreads();
+    if (sg < nseg && a < end && myc == c) {
+      int cur_e = 0, cur_a = 0, prev = se[pack_lds_pos(l0)];
+#pragma unroll 8
+      for (int k = 1; k <= end - a; ++k) {
+        const int nx = se[pack_lds_pos(l0 + k)], deg = nx - prev;
+        prev = nx;
+        if (cur_a == maxa || cur_e + deg > tile_slots) { ++nt; cur_e = 0; cur_a = 0; }
+        cur_e += deg; ++cur_a;
+      }
+      ++nt;
     }
-    ++nt;
   }
   cnt[sg] = nt;
   __syncthreads();
@@ -311,22 +333,22 @@ static __global__ void __launch_bounds__(PACK_SMALL_SEGS) k_pack_small(int inum,
   }
   const int base = cnt[sg] - nt;
   if (sg == PACK_SMALL_SEGS - 1) total = cnt[sg];
-  if (sg < nseg && a < end) {
-    int k = 0, cur_e = 0, cur_a = 0;
-    tile_a0[base] = a;
-    for (int at = a; at < end; ++at) {
-      const int deg = eoff[at + 1] - eoff[at];
-      if (cur_a == maxa || cur_e + deg > tile_slots) { ++k; cur_e = 0; cur_a = 0; tile_a0[base + k] = at; }
-      cur_e += deg; ++cur_a;
+  for (int c = 0; c < nchunk; ++c) {
+    if (nchunk > 1) { __syncthreads(); stage(c); __syncthreads(); }        // one chunk: its offsets are still staged
+    if (sg < nseg && a < end && myc == c) {
+      int k = 0, cur_e = 0, cur_a = 0, prev = se[pack_lds_pos(l0)];
+      tile_a0[base] = a; tile_e0[base] = prev;
+#pragma unroll 8
+      for (int q = 1; q <= end - a; ++q) {
+        const int nx = se[pack_lds_pos(l0 + q)], deg = nx - prev;
+        if (cur_a == maxa || cur_e + deg > tile_slots) { ++k; cur_e = 0; cur_a = 0; tile_a0[base + k] = a + q - 1; tile_e0[base + k] = prev; }
+        prev = nx;
+        cur_e += deg; ++cur_a;
+      }
     }
   }
   __syncthreads();
-  const int n = total;
-  if (sg == 0) { tile_a0[n] = inum; ntiles[0] = n; ntiles[1] = 0; }
-  __threadfence_block();
-  __syncthreads();
-  for (int t = sg; t <= n; t += PACK_SMALL_SEGS) tile_e0[t] = eoff[t < n ? tile_a0[t] : inum];
-  for (int ii = sg; ii < inum; ii += PACK_SMALL_SEGS) { const int i = ilist[ii]; centre[ii] = make_int2(i, mtype[i]); }
+  if (sg == 0) { const int n = total; tile_a0[n] = inum; tile_e0[n] = eoff[inum]; ntiles[0] = n; ntiles[1] = 0; }
 }
 // packed per-edge types when the edge list did not come from the single-pass build (edges.hip writes them itself)
 static __global__ void k_edge_types(long long E, const int *e_ii, const int *e_j, const int *ilist, const int *mtype, unsigned char *e_tt) {

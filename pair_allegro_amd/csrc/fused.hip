@@ -1090,7 +1090,7 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
     StageTimer tm(m, "tile_pack", s);
     const unsigned B = 64;
     st.centre.reserve((size_t)std::max(inum, 1) * sizeof(int2));
-    const bool small = nseg <= PACK_SMALL_SEGS;
+    const bool small = inum <= PACK_SMALL_ATOMS;
     if (small)
       hipLaunchKernelGGL(k_pack_small, dim3(1), dim3(PACK_SMALL_SEGS), 0, s, inum, m.b_eoff.as<int>(), nseg, st.tile_a0.as<int>(), st.tile_e0.as<int>(), st.ntiles.as<int>(), tile_slots, maxa,
                          m.d_ilist, a.mtype, st.centre.as<int2>(), maxdeg_sel);

@@ -283,6 +283,9 @@ static __global__ void k_centre_info(int inum, const int *ilist, const int *mtyp
 // Small systems (<= PACK_SMALL_SEGS segments = 131 072 centres): the whole tile packing -- segment counts, their scan, the fill, the tile bounds
 // and the per-centre {atom, type} records -- in ONE single-workgroup launch instead of six (a 10 648-atom step is launch-bound: 0.056 -> 0.03 ms).
 static constexpr int PACK_SMALL_SEGS = 1024;
+// One workgroup streams what one CU's L2 port delivers: up to one LDS chunk of centres the single launch wins (10 648 atoms: 29 us), beyond it the six
+// launches of the multi-workgroup path do (125 000 atoms: 0.14 ms here; 1 M atoms: 0.065 ms there).
+static constexpr int PACK_SMALL_ATOMS = 32768;
 static constexpr int PACK_CH = 32768;          // atoms per LDS chunk of k_pack_small (a multiple of SEG): 129 KB of edge offsets at a time
 // Round 4: the segment walks read the edge offsets from LDS.  A thread walking its 128 atoms straight from global memory touches one cache line
 // per lane and step (the segments are 512 B apart): 48 us for 10 648 atoms, 5 % of a step of that system and paid three times per step by the
@@ -297,13 +300,28 @@ static __global__ void __launch_bounds__(PACK_SMALL_SEGS) k_pack_small(int inum,
   const int sg = threadIdx.x;
   pack_shape(maxdeg, tile_slots, maxa);
   // per-centre {atom, type} records: independent of everything below, their two dependent loads run under the first chunk's staging
-  for (int ii = sg; ii < inum; ii += PACK_SMALL_SEGS) { const int i = ilist[ii]; centre[ii] = make_int2(i, mtype[i]); }
+  // (eight independent load chains in flight per thread: one at a time, a 125 k-atom call spent 0.17 ms in this loop alone)
+  for (int i0 = sg; i0 < inum; i0 += 8 * PACK_SMALL_SEGS) {
+    int iv[8], tv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int ii = i0 + q * PACK_SMALL_SEGS; iv[q] = ii < inum ? ilist[ii] : 0; }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) tv[q] = mtype[iv[q]];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int ii = i0 + q * PACK_SMALL_SEGS; if (ii < inum) centre[ii] = make_int2(iv[q], tv[q]); }
+  }
   const int nchunk = (inum + PACK_CH - 1) / PACK_CH;
   const int a = sg * SEG, end = min(inum, a + SEG);
   const int myc = a / PACK_CH, l0 = a - myc * PACK_CH;      // this thread's segment: chunk and first atom inside it
   auto stage = [&](int c) {
     const int c0 = c * PACK_CH, n = min(PACK_CH, inum - c0);
-    for (int k = sg; k <= n; k += PACK_SMALL_SEGS) se[pack_lds_pos(k)] = eoff[c0 + k];
+    for (int k0 = sg; k0 <= n; k0 += 8 * PACK_SMALL_SEGS) {
+      int v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const int k = k0 + q * PACK_SMALL_SEGS; v[q] = k <= n ? eoff[c0 + k] : 0; }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const int k = k0 + q * PACK_SMALL_SEGS; if (k <= n) se[pack_lds_pos(k)] = v[q]; }
+    }
   };
   int nt = 0;
   for (int c = 0; c < nchunk; ++c) {

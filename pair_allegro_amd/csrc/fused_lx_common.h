@@ -71,7 +71,7 @@ static void lx_pack_tiles(Model &m, FusedLxState &st, const ComputeArgs &a, int 
   StageTimer tm(m, "tile_pack", s);
   const unsigned B = 64;
   st.centre.reserve((size_t)std::max(inum, 1) * sizeof(int2));
-  const bool small = nseg <= PACK_SMALL_SEGS;
+  const bool small = inum <= PACK_SMALL_ATOMS;
   if (small)
     hipLaunchKernelGGL(k_pack_small, dim3(1), dim3(PACK_SMALL_SEGS), 0, s, inum, m.b_eoff.as<int>(), nseg, st.tile_a0.as<int>(), st.tile_e0.as<int>(), st.ntiles.as<int>(), slots, maxa,
                        m.d_ilist, a.mtype, st.centre.as<int2>());

@@ -430,6 +430,15 @@ static void run_model(ahip_model *m, const ComputeArgs &a) {
 
 // Page-locks a persistent host vector for as long as it keeps its storage: copies from / into pageable memory are staged by the runtime
 // and "asynchronous" in name only; the vectors of the host-pointer path only ever grow, so this registers once per growth.
+// resize_pinned: a growing resize frees the old storage, so the registration of that storage is dropped FIRST (unregistering a freed
+// range afterwards, or a new allocation landing on the still-registered old range, was possible at re-neighborings that grow nall)
+template <class T> static void unpin_if_growing(ahip::Model *m, std::vector<T> &v, size_t n) {
+#ifndef AHIP_HOST_EMU
+  if (n <= v.capacity()) return;
+  auto it = m->pinned.find((const void *)&v);
+  if (it != m->pinned.end()) { (void)hipHostUnregister(it->second.first); m->pinned.erase(it); }
+#endif
+}
 template <class T> static void pin_host(ahip::Model *m, std::vector<T> &v) {
 #ifndef AHIP_HOST_EMU
   void *p = (void *)v.data();
@@ -466,6 +475,7 @@ int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const i
     const bool want_eatom = eatom != nullptr || !m->custom_names.empty();
 
     // types: LAMMPS 1-based -> filter index (type-1) and model type (pair_nequip_allegro.cpp:576)
+    unpin_if_growing(m, m->h_ftype, (size_t)nall); unpin_if_growing(m, m->h_mtype, (size_t)nall);
     m->h_ftype.resize(nall); m->h_mtype.resize(nall);
     for (int i = 0; i < nall; ++i) {
       int t = type[i];
@@ -484,6 +494,7 @@ int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const i
     m->b_engvir.reserve(8 * sizeof(double));
     m->b_cutsq.reserve(cutsq.size() * sizeof(double));
     // positions: one host copy into a page-locked buffer, then a true DMA (LAMMPS' atom->x itself is pageable and not ours to register)
+    unpin_if_growing(m, m->h_x, (size_t)nall * 3);
     m->h_x.resize((size_t)nall * 3);
     pin_host(m, m->h_x); pin_host(m, m->h_ftype); pin_host(m, m->h_mtype);
     std::memcpy(m->h_x.data(), x, (size_t)nall * 3 * sizeof(double));
@@ -500,11 +511,13 @@ int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const i
                   m->b_engvir.as<double>(), s};
     run_model(m, a);
 
+    unpin_if_growing(m, m->h_f, (size_t)nall * 3);
     m->h_f.resize((size_t)nall * 3);
     pin_host(m, m->h_f);
     double ev[7];
     AHIP_CHECK(hipMemcpyAsync(m->h_f.data(), m->b_f.p, (size_t)nall * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     if (want_eatom) {
+      unpin_if_growing(m, m->h_eatom, (size_t)nall);
       m->h_eatom.resize(nall);
       pin_host(m, m->h_eatom);
       AHIP_CHECK(hipMemcpyAsync(m->h_eatom.data(), m->b_eatom.p, (size_t)nall * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -602,6 +615,7 @@ int ahip_compute_dev(ahip_model *m, int nlocal, int nghost, const double *x_dev,
       if (nall > 0) hipLaunchKernelGGL(k_add_n, dim3((unsigned)((3LL * nall + 255) / 256)), dim3(256), 0, s, 3LL * nall, f_dev, m->b_f.as<double>());
       if (eatom_dev && inum > 0) hipLaunchKernelGGL(k_copy_centres, dim3((unsigned)((inum + 255) / 256)), dim3(256), 0, s, inum, m->d_ilist, eatom_dev, m->b_eatom.as<double>());
       AHIP_CHECK(hipGetLastError());
+      unpin_if_growing(m, m->h_f, (size_t)nall * 3); unpin_if_growing(m, m->h_eatom, (size_t)nall); unpin_if_growing(m, m->h_mtype, (size_t)nall);
       m->h_f.resize((size_t)nall * 3); m->h_eatom.resize(nall); m->h_mtype.resize(nall);
       std::vector<int> il(inum);
       double ev[7];

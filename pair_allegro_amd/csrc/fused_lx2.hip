@@ -106,13 +106,19 @@ __device__ __forceinline__ void reduce_stage_p(const float *stg, const float *ze
 #pragma unroll
     for (int b = 0; b < NRD / RB; ++b) {
       f32x4 v[RB];
+      unsigned ad[RB];
 #pragma unroll
       for (int k = 0; k < RB; ++k) {
         const int kk = k + b * RB;
-        const unsigned ad = kk < cnt ? shb + kk * (LPI * S::STG_LD * 4) : zb;
-        asm volatile("ds_read_b128 %0, %1" : "=v"(v[k]) : "v"(ad));
+        ad[k] = kk < cnt ? shb + kk * (LPI * S::STG_LD * 4) : zb;
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));      // the sums below consume the values as they leave this statement
+      // the four reads AND their wait in ONE statement, early-clobber outputs: as separate statements the compiler was free to copy or
+      // spill a destination between a read and the wait -- i.e. to read the register before the LDS data had landed -- and only the allocation of the day kept it from doing so
+      static_assert(RB == 4, "the statement below names four reads");
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                   : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3])
+                   : "memory");
 #pragma unroll
       for (int k = 0; k < RB; ++k) acc += v[k];
     }

@@ -144,7 +144,7 @@ void ahip_model_free(ahip_model *m) {
   if (m->rcut_model_dev) (void)hipFree(m->rcut_model_dev);
   for (DevBuf *b : {&m->b_flagwork, &m->b_ilist, &m->b_nloff, &m->b_nlj, &m->b_x, &m->b_ftype, &m->b_mtype, &m->b_f, &m->b_eatom,
                     &m->b_engvir, &m->b_cutsq, &m->b_cnt, &m->b_eoff, &m->b_eii, &m->b_ej, &m->b_rvec, &m->b_ett, &m->b_partial,
-                    &m->b_ws, &m->b_misc, &m->hv_eoff, &m->hv_eii, &m->hv_ej, &m->hv_rvec, &m->hv_ilist, &m->hv_engvir})
+                    &m->b_ws, &m->b_misc, &m->hv_eoff, &m->hv_eii, &m->hv_ej, &m->hv_rvec, &m->hv_ilist, &m->hv_engvir, &m->b_tile_a0, &m->b_tile_e0, &m->b_centre, &m->b_ntiles})
     b->release();
   for (auto &t : m->slots) for (auto &e : t.ring) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
 #ifndef AHIP_HOST_EMU
@@ -397,6 +397,15 @@ static void run_model(ahip_model *m, const ComputeArgs &a) {
   m->have_ett = false;
   m->nheavy = 0;
   m->heavy_thresh = (m->opt_path != "generic" && !fused_model_supported(*m, nullptr) && fusedlx_model_supported(*m, nullptr)) ? 64 : 0;
+  // Tile packing rides on the edge build when the tile shape is known before it runs: k_fused with every list row <= 64 entries (4-wave tiles:
+  // 64 slots, 6 centres), the wide kernels always (64 slots, 4 centres).  Otherwise (shape chosen on the device, two-pass edge build) the
+  // stand-alone packing kernels run after it, as before.
+  m->pack_slots = m->pack_maxa = 0;
+  if (m->opt_path != "generic") {
+    if (fused_model_supported(*m, nullptr)) { if (m->max_list_row >= 0 && m->max_list_row <= 64) { m->pack_slots = 64; m->pack_maxa = 6; } }
+    else if (fusedlx_model_supported(*m, nullptr)) { m->pack_slots = 64; m->pack_maxa = 4; }
+  }
+  m->tiles_packed = false;
   if (!edges_build_f32(*m, a)) { m->nheavy = 0; m->heavy_thresh = 0; AHIP_CHECK(hipMemsetAsync(a.engvir, 0, 7 * sizeof(double), a.stream)); build_edges<float>(*m, a); }
 #ifdef AHIP_EXPERIMENT_SWITCHES      // never in the product build: a switch that skips the model returns no forces
   static const bool edges_only = std::getenv("AHIP_EDGES_ONLY") != nullptr;     // timing experiments on the edge build alone

@@ -59,7 +59,8 @@ __global__ void __launch_bounds__(EB_THREADS) k_build_edges(int inum, const int 
                                                        unsigned int *ticket, unsigned long long *status, int *eoff, int *e_ii,
                                                        int *e_j, float *rvec, int *maxdeg, int *overflow,
                                                        unsigned char *e_tt, int heavy_thresh,
-                                                       int *heavy_cnt, int *heavy_list, int *total_out) {
+                                                       int *heavy_cnt, int *heavy_list, int *total_out,
+                                                       int pack_slots, int pack_maxa, int *tile_a0, int *tile_e0, int *ntiles, int2 *centre) {
   __shared__ int s_cnt2[2][EB_ATOMS];          // counters of two consecutive units (no barrier between the stores of one and the
   __shared__ int s_base2[2][EB_ATOMS + 1];     // counting of the next)
   __shared__ int s_blk, s_claim2[2];           // claims double-buffered by unit parity like the counters: a wave may still be reading one while thread 0 posts the next
@@ -178,6 +179,7 @@ __global__ void __launch_bounds__(EB_THREADS) k_build_edges(int inum, const int 
       if (lane == 0) {
         const int la = uwave * EB_PER_WAVE + k;
         s_cnt[la] = kept;
+        if (pack_slots > 0 && a_begin + la < inum) centre[a_begin + la] = make_int2(ci_i[q], mti);       // per-centre record of the fused kernels (tile packing below)
         // centres with more edges than a tile of the wide fused kernel holds: listed for the layer-at-a-time kernels
         if (heavy_thresh > 0 && kept > heavy_thresh) heavy_list[atomicAdd(heavy_cnt, 1)] = a_begin + la;
       }
@@ -204,7 +206,32 @@ __global__ void __launch_bounds__(EB_THREADS) k_build_edges(int inum, const int 
     // decoupled look-back, one WAVE wide: lane l polls predecessor b-1-l; the window closes at the nearest predecessor that has
     // published its inclusive prefix (state 2), everything nearer contributes its aggregate (state 1).  (A one-lane walk costs
     // one dependent global load per predecessor: with ~1000 blocks resident the chain was the kernel's critical path.)
-    const unsigned long long agg = (unsigned long long)__shfl(inc, EB_ATOMS - 1, 64);
+    unsigned long long agg = (unsigned long long)__shfl(inc, EB_ATOMS - 1, 64);
+    // ---- tile packing of the fused model kernels, fused into this pass (round 4) ----
+    // Greedy packing of consecutive centres into tiles of <= pack_slots edges and <= pack_maxa centres, restarted at every unit (64 centres; the
+    // stand-alone packing kernels restart every 128).  Lane k holds centre k's degree v and the prefixes ex / inc: the tile that would START at k
+    // ends before nxt[k] = the first later centre that does not fit; the actual starts are the chain 0 -> nxt[0] -> nxt[nxt[0]] ..., walked on the
+    // scalar unit (<= 64 readlanes).  The tile count travels through the look-back in the upper 26 bits of the same 62-bit value as the edge count
+    // (sums of both stay inside their fields: < 2^36 edges, < 2^26 tiles), so a unit learns its first tile index together with its first edge.
+    unsigned long long tmask = 0;
+    const int ex = inc - v;
+    const int nun = min(EB_ATOMS, inum - a_begin);
+    if (pack_slots > 0) {
+      int nx = lane + 1;
+      bool open = lane < nun;
+      for (int q = 1; q <= pack_maxa; ++q) {
+        const int jn = lane + q;
+        const int incj = __shfl(inc, min(jn, EB_ATOMS - 1), 64);
+        if (open) {
+          if (jn >= nun) { nx = nun; open = false; }
+          else if (q == pack_maxa || incj - ex > pack_slots) { nx = jn; open = false; }
+        }
+        if (!__any(open)) break;
+      }
+      int k = 0;
+      while (k < nun) { tmask |= 1ull << k; k = __builtin_amdgcn_readlane(nx, k); }
+      agg |= (unsigned long long)__popcll(tmask) << 36;
+    }
     const unsigned long long VMASK = (1ull << 62) - 1;
     unsigned long long prefix = 0;
     if (b == 0) {
@@ -243,7 +270,21 @@ __global__ void __launch_bounds__(EB_THREADS) k_build_edges(int inum, const int 
       }
       if (lane == 0) __hip_atomic_store(&status[b], pack_state(2, prefix + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (lane == 0) s_prefix = (long long)prefix;
+    if (lane == 0) s_prefix = (long long)(prefix & ((1ull << 36) - 1));
+    if (pack_slots > 0) {
+      const int tbase = (int)(prefix >> 36), gb = (int)(prefix & ((1ull << 36) - 1));
+      if ((tmask >> lane) & 1ull) {
+        const int ti = tbase + __popcll(tmask & ((1ull << lane) - 1));
+        tile_a0[ti] = a_begin + lane;
+        tile_e0[ti] = gb + ex;
+      }
+      if (lane == 0 && a_begin + EB_ATOMS >= inum) {            // last unit: closing bounds, tile total, the model kernel's tile counter
+        const int nt = tbase + __popcll(tmask);
+        tile_a0[nt] = inum;
+        tile_e0[nt] = gb + (int)(agg & ((1ull << 36) - 1));
+        ntiles[0] = nt; ntiles[1] = 0;
+      }
+    }
   }
   __syncthreads();
   const long long gbase = s_prefix;
@@ -391,6 +432,13 @@ bool edges_build_f32(Model &m, const ComputeArgs &a) {
   m.b_ett.reserve(cap);
   m.edges_T_size = 4;
   int *hdr = st.flags.as<int>();
+  m.tiles_packed = false;
+  if (m.pack_slots > 0) {                              // tile packing for the fused kernel that will run, done by this kernel (see k_build_edges)
+    m.b_tile_a0.reserve((size_t)(inum + 2) * sizeof(int));
+    m.b_tile_e0.reserve((size_t)(inum + 2) * sizeof(int));
+    m.b_centre.reserve((size_t)std::max(inum, 1) * sizeof(int2));
+    m.b_ntiles.reserve(64);
+  }
   if (m.heavy_thresh > 0) st.heavy.reserve((size_t)std::max(inum, 1) * sizeof(int));
   const int nall = std::max(m.nall, 1);
   st.xt.reserve((size_t)nall * sizeof(AtomXT));
@@ -400,7 +448,8 @@ bool edges_build_f32(Model &m, const ComputeArgs &a) {
 #define EB_LAUNCH(CH, DY) hipLaunchKernelGGL((k_build_edges<CH, DY>), dim3(nblocks), dim3(EB_THREADS), 0, a.stream, inum, m.d_ilist, m.d_nloff, m.d_nlj,       \
                      (const AtomXT *)st.xt.p, a.cutsq, a.nft, nunits, (unsigned int *)hdr, (unsigned long long *)((char *)st.flags.p + 64),   \
                      m.b_eoff.as<int>(), m.b_eii.as<int>(), m.b_ej.as<int>(), m.b_rvec.as<float>(), hdr + 1, hdr + 2,                \
-                     m.b_ett.as<unsigned char>(), m.heavy_thresh, hdr + 3, st.heavy.as<int>(), hdr + 4)
+                     m.b_ett.as<unsigned char>(), m.heavy_thresh, hdr + 3, st.heavy.as<int>(), hdr + 4,                              \
+                     m.pack_slots, m.pack_maxa, m.b_tile_a0.as<int>(), m.b_tile_e0.as<int>(), m.b_ntiles.as<int>(), m.b_centre.as<int2>())
   if (dyn) { if (one_chunk) EB_LAUNCH(1, true); else EB_LAUNCH(2, true); }
   else {
     if (one_chunk) EB_LAUNCH(1, false); else EB_LAUNCH(2, false);
@@ -416,6 +465,7 @@ bool edges_build_f32(Model &m, const ComputeArgs &a) {
   AHIP_CHECK(hipMemcpyAsync(h3, hdr, 5 * sizeof(int), hipMemcpyDeviceToHost, a.stream));       // ticket, max degree, overflow, heavy centres, edge total
   AHIP_CHECK(hipEventRecord(st.ev_back, a.stream));
   m.d_maxdeg = hdr + 1;
+  m.tiles_packed = m.pack_slots > 0;
   m.have_ett = true;
   m.counts_pending = true;
   if (m.max_list_row < 0) {                         // row lengths unknown (cannot happen through the C-ABI, which measures them at every list hand-over): check the overflow flag now

@@ -144,6 +144,10 @@ struct Model {
   bool counts_pending = false;               // nedges / last_max_deg / nheavy are not valid yet: call edges_counts()
   long long nedges_hint = 0;                 // edge total of the last read-back that was waited for, else an estimate (heuristics only)
   const int *d_maxdeg = nullptr;             // device word holding the largest degree of the current edge list (single-pass build)
+  // tile packing done by the single-pass edge build (edges.hip): requested shape (0 = none), whether the current edge list carries it, its arrays
+  int pack_slots = 0, pack_maxa = 0;
+  bool tiles_packed = false;
+  DevBuf b_tile_a0, b_tile_e0, b_centre, b_ntiles;
   const int *d_ntiles_last = nullptr;        // device word with the tile count of the last fused launch; last_tile_slots: its edge slots per tile (0: chosen on the device from the largest degree)
   int last_tile_slots = 0;
 

@@ -1086,7 +1086,9 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
   st.seg_base.reserve((size_t)(nseg + 2) * sizeof(int));
   st.tile_a0.reserve((size_t)(inum + nseg + 2) * sizeof(int));
   st.tile_e0.reserve((size_t)(inum + nseg + 2) * sizeof(int));
-  {
+  static_assert(Lds<4>::MAXA == 6, "allegro_hip.hip requests the 4-wave tile shape as 64 slots / 6 centres");
+  const bool prepacked = m.tiles_packed && nw == 4 && m.pack_slots == tile_slots && m.pack_maxa == maxa;      // the edge build packed the tiles (edges.hip)
+  if (!prepacked) {
     StageTimer tm(m, "tile_pack", s);
     const unsigned B = 64;
     st.centre.reserve((size_t)std::max(inum, 1) * sizeof(int2));
@@ -1113,11 +1115,13 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
   }
   FusedArgs A = st.args;
   A.eoff = m.b_eoff.as<int>(); A.e_ii = m.b_eii.as<int>(); A.e_j = m.b_ej.as<int>();
-  A.e_tt = m.b_ett.as<unsigned char>(); A.centre = st.centre.as<int2>(); A.rvec = m.b_rvec.as<float>(); A.rcut = m.rcut_model_dev;
-  A.tile_a0 = st.tile_a0.as<int>(); A.tile_e0 = st.tile_e0.as<int>(); A.ntiles = st.ntiles.as<int>();
-  A.tile_counter = (unsigned int *)(st.ntiles.as<int>() + 1);
+  A.e_tt = m.b_ett.as<unsigned char>(); A.rvec = m.b_rvec.as<float>(); A.rcut = m.rcut_model_dev;
+  int *const ntl = prepacked ? m.b_ntiles.as<int>() : st.ntiles.as<int>();
+  A.centre = prepacked ? m.b_centre.as<int2>() : st.centre.as<int2>();
+  A.tile_a0 = prepacked ? m.b_tile_a0.as<int>() : st.tile_a0.as<int>(); A.tile_e0 = prepacked ? m.b_tile_e0.as<int>() : st.tile_e0.as<int>(); A.ntiles = ntl;
+  A.tile_counter = (unsigned int *)(ntl + 1);
   A.maxdeg_sel = maxdeg_sel;
-  m.d_ntiles_last = st.ntiles.as<int>(); m.last_tile_slots = nw == 0 ? 0 : 16 * nw;
+  m.d_ntiles_last = ntl; m.last_tile_slots = nw == 0 ? 0 : 16 * nw;
   A.f = a.f; A.eatom = a.eatom; A.partial = st.partial.as<double>();
   // edge total for the claim size below: the value itself when it is on the host, else the last one that was, else the list's size
   // scaled by the volume ratio of cutoff and list spheres at a skin of 1 A

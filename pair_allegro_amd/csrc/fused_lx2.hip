@@ -890,10 +890,8 @@ bool fusedlx2_run(Model &m, const ComputeArgs &a, std::string *why) {
   FusedLxArgs A = st.args;
   A.wg_scratch = NW * A.wave_scratch;
   A.eoff = m.b_eoff.as<int>(); A.e_ii = m.b_eii.as<int>(); A.e_j = m.b_ej.as<int>();
-  A.e_tt = m.b_ett.as<unsigned char>(); A.centre = st.centre.as<int2>(); A.rvec = m.b_rvec.as<float>(); A.rcut = m.rcut_model_dev;
-  A.tile_a0 = st.tile_a0.as<int>(); A.tile_e0 = st.tile_e0.as<int>(); A.ntiles = st.ntiles.as<int>();
-  A.tile_counter = (unsigned int *)(st.ntiles.as<int>() + 1);
-  m.d_ntiles_last = st.ntiles.as<int>(); m.last_tile_slots = SLOTS;
+  A.e_tt = m.b_ett.as<unsigned char>(); A.rvec = m.b_rvec.as<float>(); A.rcut = m.rcut_model_dev;
+  lx_tile_args(m, st, A, SLOTS, S::MAXA);
   A.tchunk = (lx_nedges_estimate(m) / SLOTS > (long long)grid * 256) ? TCHUNK : 1;
   A.f = a.f; A.eatom = a.eatom; A.partial = st.partial.as<double>();
   (void)inum;

@@ -60,7 +60,18 @@ static long long lx_nedges_estimate(const Model &m) {
 }
 // Tile packing shared by the wide fused kernels: consecutive centres into tiles of <= slots edges and <= maxa centres
 // (k_pack_tiles, fused_common.h), per-centre {atom, type}, per-edge packed types, first edge of every tile.
+// the tile arrays the kernel reads: the edge build's (it packed them itself, edges.hip) or this state's
+static bool lx_prepacked(const Model &m, int slots, int maxa) { return m.tiles_packed && m.pack_slots == slots && m.pack_maxa == maxa; }
+static void lx_tile_args(Model &m, FusedLxState &st, FusedLxArgs &A, int slots, int maxa) {
+  const bool pre = lx_prepacked(m, slots, maxa);
+  int *const ntl = pre ? m.b_ntiles.as<int>() : st.ntiles.as<int>();
+  A.centre = pre ? m.b_centre.as<int2>() : st.centre.as<int2>();
+  A.tile_a0 = pre ? m.b_tile_a0.as<int>() : st.tile_a0.as<int>(); A.tile_e0 = pre ? m.b_tile_e0.as<int>() : st.tile_e0.as<int>(); A.ntiles = ntl;
+  A.tile_counter = (unsigned int *)(ntl + 1);
+  m.d_ntiles_last = ntl; m.last_tile_slots = slots;
+}
 static void lx_pack_tiles(Model &m, FusedLxState &st, const ComputeArgs &a, int slots, int maxa) {
+  if (lx_prepacked(m, slots, maxa)) return;
   hipStream_t s = a.stream;
   const int inum = m.inum;
   const int nseg = (inum + SEG - 1) / SEG;

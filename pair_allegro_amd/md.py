@@ -393,13 +393,20 @@ class Simulation:
                 mask = (xs < self.lo[d] + self.rc) if step < 0 else (xs >= self.hi[d] - self.rc)
                 sw.send_idx = torch.nonzero(mask, as_tuple=False).squeeze(1)
                 sw.nsend = int(sw.send_idx.shape[0])
-                sw.nrecv = self._exchange_counts(sw.nsend, sendrank, recvrank)
-                buf = x[sw.send_idx].clone()
-                buf[:, d] += shift
-                rx = self._sendrecv(buf, sendrank, recvrank, sw.nrecv)
-                rm = self._sendrecv(mt[sw.send_idx].to(torch.float64).unsqueeze(1), sendrank, recvrank, sw.nrecv)
+                if sendrank == self.rank and recvrank == self.rank:      # one rank along this dimension: the ghosts are my own images
+                    sw.nrecv = sw.nsend
+                    rx = x[sw.send_idx]                                  # (advanced indexing: a copy)
+                    if shift != 0.0:
+                        rx[:, d] += shift
+                    rmt = mt[sw.send_idx]
+                else:
+                    sw.nrecv = self._exchange_counts(sw.nsend, sendrank, recvrank)
+                    buf = x[sw.send_idx].clone()
+                    buf[:, d] += shift
+                    rx = self._sendrecv(buf, sendrank, recvrank, sw.nrecv)
+                    rmt = self._sendrecv(mt[sw.send_idx].to(torch.float64).unsqueeze(1), sendrank, recvrank, sw.nrecv).squeeze(1).to(torch.int32)
                 sw.first_recv = nprev + sum(t.shape[0] for t in new_x)
-                new_x.append(rx); new_mt.append(rm.squeeze(1).to(torch.int32))
+                new_x.append(rx); new_mt.append(rmt)
                 self.swaps.append(sw)
             x = torch.cat([x] + new_x); mt = torch.cat([mt] + new_mt)
         self.x, self.mtype = x.contiguous(), mt.contiguous()

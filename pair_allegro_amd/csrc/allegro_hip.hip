@@ -210,6 +210,9 @@ int ahip_set_option(ahip_model *m, const char *key, const char *value) {
     } else if (k == "edge_schedule") {
       if (v != "auto" && v != "static" && v != "dynamic") throw ArgError("option edge_schedule: expected auto|static|dynamic");
       m->opt_edge_schedule = v;
+    } else if (k == "tile_pack") {
+      if (v != "auto" && v != "separate") throw ArgError("option tile_pack: expected auto|separate");
+      m->opt_tile_pack = v;
     } else if (k == "timing") {
       m->timing = (v == "1" || v == "on" || v == "true");
     } else throw ArgError("unknown option '" + k + "'");
@@ -401,7 +404,7 @@ static void run_model(ahip_model *m, const ComputeArgs &a) {
   // 64 slots, 6 centres), the wide kernels always (64 slots, 4 centres).  Otherwise (shape chosen on the device, two-pass edge build) the
   // stand-alone packing kernels run after it, as before.
   m->pack_slots = m->pack_maxa = 0;
-  if (m->opt_path != "generic") {
+  if (m->opt_path != "generic" && m->opt_tile_pack != "separate") {
     if (fused_model_supported(*m, nullptr)) { if (m->max_list_row >= 0 && m->max_list_row <= 64) { m->pack_slots = 64; m->pack_maxa = 6; } }
     else if (fusedlx_model_supported(*m, nullptr)) { m->pack_slots = 64; m->pack_maxa = 4; }
   }

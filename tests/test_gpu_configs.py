@@ -210,6 +210,40 @@ def test_fused_per_edge_type_cutoffs(hip_lib, model_dir):
     assert len(res["edges"][0]) < len(glue.brute_force_edges(g["cell"], g["pos"], 5.0)[0])
 
 
+@pytest.mark.parametrize("shape", ["S", "Y"])
+def test_tile_packing_inside_the_edge_build_equals_the_stand_alone_packing(hip_lib, model_dir, shape):
+    """Round 4: the single-pass edge build packs the tiles itself when the tile shape is known up front (its look-back carries the tile count next
+    to the edge count; units of 64 centres).  Same forces / energies as with the stand-alone packing kernels (option tile_pack=separate; segments of
+    128 centres: other tile boundaries, i.e. another float32 summation order), on a box with an isolated atom (no edges) and, for the wide kernel,
+    centres with more than 64 edges (tiles of their own, evaluated by the layer-at-a-time kernels)."""
+    if shape == "S":
+        cell, pos, types = lmp_like.diamond_si(6)                    # 1 728 atoms, 28 edges each
+        cell = cell.copy(); cell[2, 2] += 12.0                       # a vacuum gap: surface atoms with fewer edges ...
+        pos = np.vstack([pos, [[0.5 * cell[0, 0], 0.5 * cell[1, 1], cell[2, 2] - 6.0]]])      # ... and one atom with none
+        types = np.append(types, 1).astype(np.int32)
+        cfg = model_file.model_S(num_layers=2)
+        names = ["Si"]
+    else:
+        cell, pos, types = lmp_like.water(7)                         # 1 029 atoms ...
+        cell, pos = 0.95 * cell, 0.95 * pos                          # ... compressed by 5 % in every direction: O / H centres with 50..75 edges
+        cfg = model_file.model_L(num_tensor_features=32, avg_num_neighbors=53.6)
+        names = ["O", "H"]
+    path, w = _export(model_dir, f"pack_{shape}", cfg)
+    a = util.run_pair(hip_lib, path, cell, pos, types, names, options={"path": "fused"})
+    b = util.run_pair(hip_lib, path, cell, pos, types, names, options={"path": "fused", "tile_pack": "separate"})
+    assert a["info"]["path"] == "fused_f32" and b["info"]["path"] == "fused_f32"
+    if shape == "Y":
+        assert a["info"]["max_degree"] > 64                         # heavy centres exist in this box
+    fs = np.abs(b["forces"]).max()
+    assert np.abs(a["forces"] - b["forces"]).max() < 2e-6 * max(fs, 1.0)
+    np.testing.assert_allclose(a["eatom"], b["eatom"], atol=5e-6)
+    np.testing.assert_allclose(a["pe"], b["pe"], rtol=1e-6)
+    np.testing.assert_allclose(a["virial"], b["virial"], atol=1e-4)
+    assert np.array_equal(a["edges"][0], b["edges"][0]) and np.array_equal(a["edges"][1], b["edges"][1])
+    ref = util.oracle_run(dict(cfg, model_dtype="float64"), w, cell, pos, types, names)
+    assert np.abs(a["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
+
+
 @pytest.mark.parametrize("path_opt", ["fused", "generic"])
 def test_forces_are_added_to_a_nonzero_f(hip_lib, model_dir, path_opt):
     """f[i] += forces[i] for locals AND ghosts (pair_nequip_allegro.cpp:370-377): a pre-filled f keeps its contents."""

@@ -24,7 +24,8 @@
 //            terms, f32 accumulate; option fused_arith).
 //
 // Supported model shape (others run the generic path): l_max = 1, 32 tensor features, 64 scalars,
-// MLP 2 x 64, read-out 1 x 32, 8 Bessels, <= 3 layers, <= 16 types.  Reference graph:
+// MLP 2 x 64, read-out 1 x 32, <= 3 layers, <= 16 types; any number of Bessel functions and any cutoff-polynomial order (the radial basis only
+// enters through the tabulated two-body embedding; fused_tb=mlp needs 8).  Reference graph:
 // the TorchScript model executed at /root/reference/pair_nequip_allegro.cpp:409-430.
 #include <hip/hip_runtime.h>
 
@@ -916,7 +917,13 @@ bool fused_model_supported(const Model &m, std::string *why) {
   if (h.l_max != 1) return no("fused kernels need l_max = 1");
   if (h.U != 32 || h.S != 64 || h.mlp_width != 64 || h.readout_width != 32) return no("fused kernels need U=32, S=64, MLP width 64, read-out width 32");
   if (h.mlp_depth != 2 || h.readout_depth != 1) return no("fused kernels need MLP depth 2 and read-out depth 1");
-  if (h.num_bessels != 8) return no("fused kernels need 8 Bessel functions");
+  // the radial basis only enters through the two-body embedding: tabulated (default) any number of Bessel functions will do, evaluated in the kernel
+  // (fused_tb=mlp) its first linear is laid out for 8
+  {
+    const char *tb = std::getenv("AHIP_FUSED_TB");
+    const bool in_kernel = (tb ? std::string(tb) : m.opt_fused_tb) == "mlp";
+    if (h.num_bessels < 1 || (in_kernel && h.num_bessels != 8)) return no("fused_tb=mlp needs 8 Bessel functions (the tabulated two-body embedding takes any number)");
+  }
   if (h.num_layers < 1 || h.num_layers > MAXNL) return no("fused kernels need 1..3 layers");
   if (h.num_types > 16) return no("fused kernels support at most 16 model types (4-bit packed edge types)");
   return true;

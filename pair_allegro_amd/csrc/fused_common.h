@@ -413,8 +413,8 @@ static std::vector<double> transpose(const double *W, int K, int N) {
 // stored as cubic-Hermite coefficients [pair][NK intervals][tile 4][coef 4][16]; the kernels gather 16 x 16 B per lane.
 static void append_two_body_table(std::vector<float> &w, const HostModel &h, const std::vector<double> &rcut_model_host, int NKin) {
   const int T = h.num_types;
-  const HostTensor &w0 = h.get("tb.w0");          // [2T+8][64]
-  const double *wc = w0.data.data() + (size_t)2 * T * 64;       // Bessel block [8][64]
+  const HostTensor &w0 = h.get("tb.w0");          // [2T+B][64]
+  const double *wc = w0.data.data() + (size_t)2 * T * 64;       // Bessel block [B][64], B = num_bessels: any count (the kernels never see the basis, only the table)
   auto T_ = [&](const std::string &name) -> const double * { return h.get(name).data.data(); };
   struct { const std::vector<double> &rcut_model_host; } m{rcut_model_host};
   const int NK = NKin;
@@ -439,7 +439,7 @@ static void append_two_body_table(std::vector<float> &w, const HostModel &h, con
         }
         double z1[64], dz1[64], h1[64], dh1[64], z2[64], dz2[64], h2[64], dh2[64];
         for (int n = 0; n < 64; ++n) { z1[n] = w0.data[(size_t)ti * 64 + n] + w0.data[(size_t)(T + tj) * 64 + n]; dz1[n] = 0; }
-        for (int b = 1; b <= 8; ++b) {
+        for (int b = 1; b <= h.num_bessels; ++b) {
           const double a = b * PI / rc;
           double sv, ds;                                // s = sin(a d)/d and ds/dd, series near 0
           if (a * d < 1e-4) { sv = a * (1.0 - a * a * d * d / 6.0); ds = -a * a * a * d / 3.0; }

@@ -662,7 +662,7 @@ bool fusedlx_model_supported(const Model &m, std::string *why) {
   if (h.U != 32 && h.U != 64) return no("wide fused kernels need 32 or 64 tensor features");
   if (h.S != 64 || h.mlp_width != 64 || h.readout_width != 32) return no("fused kernels need S=64, MLP width 64, read-out width 32");
   if (h.mlp_depth != 2 || h.readout_depth != 1) return no("fused kernels need MLP depth 2 and read-out depth 1");
-  if (h.num_bessels != 8) return no("fused kernels need 8 Bessel functions");
+  if (h.num_bessels < 1) return no("no radial basis");      // any number of Bessel functions: the two-body embedding is always tabulated here
   if (h.num_layers < 1 || h.num_layers > LX_MAXNL) return no("fused kernels need 1..3 layers");
   if (h.num_types > 16) return no("fused kernels support at most 16 model types (4-bit packed edge types)");
   return true;

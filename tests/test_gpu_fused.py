@@ -35,9 +35,9 @@ def test_fused_golden_si64(hip_lib, model_dir, tag):
     pc.check_edges_vs_brute_force(res, g)
 
 
-def _model_S_case(model_dir, name, type_names, symbols, cell, pos, nl=2, seed=1):
+def _model_S_case(model_dir, name, type_names, symbols, cell, pos, nl=2, seed=1, **over):
     cfg = model_file.model_S(type_names=list(type_names), num_layers=nl, seed=seed,
-                             avg_num_neighbors=float(len(util.glue.brute_force_edges(cell, pos, 5.0)[0])) / len(pos))
+                             avg_num_neighbors=float(len(util.glue.brute_force_edges(cell, pos, 5.0)[0])) / len(pos), **over)
     w = model_file.init_weights(cfg)
     path = f"{model_dir}/{name}.nequip.pth"
     allegro_torch.export_nequip_pth(path, cfg, w)
@@ -59,6 +59,22 @@ def test_fused_vs_oracle_two_types(hip_lib, model_dir, nl):
     util.assert_close_to(fused, ref, 5e-4, what=f"fused vs f64 oracle nl={nl}")
     assert np.abs(fused["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
     np.testing.assert_allclose(fused["forces"], gen["forces"], atol=2e-5)
+
+
+@pytest.mark.parametrize("nb,p", [(5, 6), (12, 4)])
+def test_fused_any_radial_basis_with_the_two_body_table(hip_lib, model_dir, nb, p):
+    """`num_bessels` and `polynomial_cutoff_p` are free hyper-parameters of the reference's YAML
+    (/root/reference/tests/test_data/test_repro_allegro.yaml:83-86).  The fused kernels see the radial basis only through the tabulated two-body
+    embedding, which the host builds from the model's own Bessel block: 5 or 12 functions, p = 4 or 6, stay on the fused path (round 4; before:
+    anything but 8 dropped to the layer-at-a-time kernels); fused_tb=mlp, whose first linear is laid out for 8, declines."""
+    g = util.load_golden("CuPd-cubic-big_r5")
+    path, cfg, types, names, ref = _model_S_case(model_dir, f"nb{nb}_S", ["Cu", "Pd"], g["symbols"], g["cell"], g["pos"], num_bessels=nb, poly_p=p)
+    res = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused"})
+    assert res["info"]["path"] == "fused_f32"
+    util.assert_close_to(res, ref, 5e-4, what=f"{nb} Bessel functions, p = {p}")
+    assert np.abs(res["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
+    with pytest.raises(Exception, match="8 Bessel"):               # the Pair mirror re-raises the library's error as its LammpsError
+        util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused", "fused_tb": "mlp"})
 
 
 @pytest.mark.parametrize("ntypes", [8, 16])

@@ -41,6 +41,19 @@ def _case(model_dir, name, cfg, cell, pos, symbols):
     return path, types, names, ref
 
 
+@pytest.mark.parametrize("U,nb,p", [(32, 6, 6), (64, 10, 5)])
+def test_wide_kernels_take_any_radial_basis(hip_lib, model_dir, U, nb, p):
+    """`num_bessels` / `polynomial_cutoff_p` other than the YAML's 8 / 6 (test_repro_allegro.yaml:83-86) stay on the wide fused kernels: the radial
+    basis only enters through the tabulated two-body embedding, built by the host from the model's own Bessel block (round 4)."""
+    g = util.load_golden("Cu2AgO4_r5")
+    cfg = model_file.model_L(type_names=["Cu", "Ag", "O"], num_tensor_features=U, num_bessels=nb, poly_p=p, avg_num_neighbors=30.0)
+    path, types, names, ref = _case(model_dir, f"L_nb{nb}_U{U}", cfg, g["cell"], g["pos"], g["symbols"])
+    res = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused"})
+    assert res["info"]["path"] == "fused_f32"
+    util.assert_close_to(res, ref, 5e-4, what=f"U={U}, {nb} Bessel functions, p={p}")
+    assert np.abs(res["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
+
+
 @pytest.mark.parametrize("U", [32, 64])
 @pytest.mark.parametrize("nl", [1, 2, 3])
 def test_model_L_layers_and_widths(hip_lib, model_dir, nl, U):

@@ -211,7 +211,7 @@ int ahip_set_option(ahip_model *m, const char *key, const char *value) {
       if (v != "auto" && v != "static" && v != "dynamic") throw ArgError("option edge_schedule: expected auto|static|dynamic");
       m->opt_edge_schedule = v;
     } else if (k == "tile_pack") {
-      if (v != "auto" && v != "separate") throw ArgError("option tile_pack: expected auto|separate");
+      if (v != "auto" && v != "separate" && v != "fused") throw ArgError("option tile_pack: expected auto|separate|fused");
       m->opt_tile_pack = v;
     } else if (k == "timing") {
       m->timing = (v == "1" || v == "on" || v == "true");
@@ -404,7 +404,10 @@ static void run_model(ahip_model *m, const ComputeArgs &a) {
   // 64 slots, 6 centres), the wide kernels always (64 slots, 4 centres).  Otherwise (shape chosen on the device, two-pass edge build) the
   // stand-alone packing kernels run after it, as before.
   m->pack_slots = m->pack_maxa = 0;
-  if (m->opt_path != "generic" && m->opt_tile_pack != "separate") {
+  // ... and up to 262 144 centres per call: the packing runs on the scanning wave of every unit, i.e. serially inside the edge build, and costs there what
+  // the stand-alone kernels cost beside it once they have a chip to spread over (1 M atoms: 0.062 vs 0.064 ms); below that the six launches they need are
+  // the cost (10 648 atoms: 0.026 ms, 125 000: 0.056 ms, three times per step in the overlapped multi-rank schedule)
+  if (m->opt_path != "generic" && m->opt_tile_pack != "separate" && (m->inum <= 262144 || m->opt_tile_pack == "fused")) {
     if (fused_model_supported(*m, nullptr)) { if (m->max_list_row >= 0 && m->max_list_row <= 64) { m->pack_slots = 64; m->pack_maxa = 6; } }
     else if (fusedlx_model_supported(*m, nullptr)) { m->pack_slots = 64; m->pack_maxa = 4; }
   }

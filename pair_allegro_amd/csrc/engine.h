@@ -104,7 +104,7 @@ struct Model {
   long long chunk_edges = 2000000;
   int reserve_wgs = 0;                      // workgroup slots the persistent fused kernels leave free (for kernels of other streams)
   bool timing = false;
-  std::string opt_tile_pack = "auto";       // auto | separate: tile packing inside the single-pass edge build where the tile shape is known up front, or always by the stand-alone kernels (A/B, tests)
+  std::string opt_tile_pack = "auto";       // auto | separate | fused (auto = fused up to 262 144 centres per call): tile packing inside the single-pass edge build where the tile shape is known up front, or always by the stand-alone kernels (A/B, tests)
   std::string opt_edge_schedule = "auto";   // auto | static | dynamic: unit schedule of the single-pass edge build (edges.hip)
   bool cutoff_strict = false;               // edge kept iff rsq < cut^2 (the KOKKOS reference path) instead of rsq <= cut^2 (the host path)
 

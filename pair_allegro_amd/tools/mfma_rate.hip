@@ -67,6 +67,69 @@ __global__ void __launch_bounds__(256, OCC) k_rate_b(const float *W, int wbytes,
   if (sum == 12345.678f) out[0] = (long long)pad[lane];
 }
 
+// Round 4 probe (VERDICT r03 #6a): bf16x3 linears in which every weight fragment serves TWO 16-slot edge groups of the wave (two B operands,
+// two accumulator pairs): the fragment stream per edge halves, i.e. the 64 B/clk/CU register-return path that bounds k_rate_b carries half the
+// bytes per MFMA.  Same fragment order and ring as linear_b; inputs / outputs of both groups in registers (a microbenchmark: the full kernel would
+// have to park one group's other state in LDS).  NTERM = 3.
+template <int KS, int NT>
+__device__ __forceinline__ void linear_b2(__amdgpu_buffer_rsrc_t W, int &wp, const Bop (&in0)[KS], const Bop (&in1)[KS], f32x4 (&out0)[NT], f32x4 (&out1)[NT],
+                                          Bop (&ob0)[NT / 2], Bop (&ob1)[NT / 2], int v16, u32x4 (&ring)[RINGB]) {
+  constexpr int NF = 6, NPROD = 6, NP = NT / 2, NSTEP = NP * KS, NS = NF * NSTEP, RB = RINGB;
+  f32x4 a0 = {0, 0, 0, 0}, a1 = a0, b0 = a0, b1 = a0;
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    const int p = s / KS, ks = s % KS;
+    if (ks == 0) { a0 = a1 = b0 = b1 = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    u32x4 a[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      a[i] = ring[(NF * s + i) % RB];
+      ring[(NF * s + i) % RB] = __builtin_bit_cast(u32x4, bload(W, v16, (wp + (NF * s + i + RB) * 256) * 4));
+    }
+#pragma unroll
+    for (int m = 0; m < NPROD; ++m) {
+      const int wt = m == 0 ? 2 : (m == 1 || m == 3) ? 1 : 0;
+      const int xt = (m == 0 || m == 3 || m == 5) ? 0 : (m == 1 || m == 4) ? 1 : 2;
+      const u32x4 x0 = xt == 0 ? in0[ks].hi : xt == 1 ? in0[ks].mid : in0[ks].lo;
+      const u32x4 x1 = xt == 0 ? in1[ks].hi : xt == 1 ? in1[ks].mid : in1[ks].lo;
+      a0 = mfma_b(a[2 * wt], x0, a0);
+      b0 = mfma_b(a[2 * wt], x1, b0);
+      a1 = mfma_b(a[2 * wt + 1], x0, a1);
+      b1 = mfma_b(a[2 * wt + 1], x1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ks == KS - 1) {
+      out0[2 * p] = a0; out0[2 * p + 1] = a1; out1[2 * p] = b0; out1[2 * p + 1] = b1;
+      ob0[p] = split_pair(a0, a1); ob1[p] = split_pair(b0, b1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  wp += NS * 256;
+}
+template <int OCC>
+__global__ void __launch_bounds__(256, OCC) k_rate_b2(const float *W, int wbytes, float *scr, long long *out, int iters) {
+  const int lane = threadIdx.x & 63, v16 = lane * 16;
+  __shared__ float pad[OCC == 2 ? 20000 : 40000];
+  pad[threadIdx.x] = 0.f;
+  __amdgpu_buffer_rsrc_t WB = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, wbytes, 0x00020000);
+  f32x4 x[4], z[4], y0[4], y1[4];
+  u32x4 ring[RINGB];
+  for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r) { x[t][r] = 0.001f * (float)((lane * 7 + t * 4 + r) % 13); z[t][r] = 0.002f * (float)((lane * 5 + t * 4 + r) % 11); }
+  Bop xa[2], xb[2], ya[2], yb[2];
+  xa[0] = split_pair(x[0], x[1]); xa[1] = split_pair(x[2], x[3]);
+  xb[0] = split_pair(z[0], z[1]); xb[1] = split_pair(z[2], z[3]);
+  int wp = 0;
+  ring_prime_b(WB, wp, v16, ring);
+  for (int it = 0; it < iters; ++it) {
+    wp = 0;
+    linear_b2<2, 4>(WB, wp, xa, xb, y0, y1, ya, yb, v16, ring);
+    linear_b2<2, 4>(WB, wp, ya, yb, x, z, xa, xb, v16, ring);
+  }
+  float sum = 0.f;
+  for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r) sum += x[t][r] + z[t][r];
+  if (sum == 12345.678f) out[0] = (long long)pad[lane];
+}
+
 // bf16x3 64x64 linears with the weight fragments SHARED by the 4 waves of a workgroup through LDS (each wave fetches a quarter of
 // the next linear's 24 fragments while the current ones are consumed; one barrier per linear).  Feasibility probe for the next
 // kernel generation: per-wave register rings are bound by the 64 B/clk/CU return path (see k_rate_b).
@@ -237,6 +300,20 @@ int main() {
       };
       runl("bf16x3 LDS-shared weights, 1 wave/SIMD", 256, k_rate_b_lds<1>);
       runl("bf16x3 LDS-shared weights, 2 waves/SIMD", 512, k_rate_b_lds<2>);
+      {   // two edge groups per fragment: 2 x 16 edges per wave, i.e. twice the flops of runb per iteration
+        auto runb2 = [&](const char *name, int grid, auto kern) {
+          for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, dWb, eb * 1024, scrb, out, itb);
+            hipEventRecord(e1, 0); hipDeviceSynchronize();
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            const double fl = (double)grid * 4 * itb * 2.0 * 64 * 64 * 32 * 2;
+            if (rep) std::printf("%-48s %7.3f ms  %6.1f f32-equivalent TFLOP/s, %5.0f cycles per 64x64 linear of 32 edges per wave at 2.3 GHz\n", name, ms, fl / (ms * 1e-3) * 1e-12, ms * 1e-3 * 2.3e9 / (itb * 2.0));
+          }
+        };
+        runb2("bf16x3 two edge groups per fragment, 1 wave/SIMD", 256, k_rate_b2<1>);
+        runb2("bf16x3 two edge groups per fragment, 2 waves/SIMD", 512, k_rate_b2<2>);
+      }
       runb("bf16x3 no epilogue + split, 1 wave/SIMD", 256, k_rate_b<0, 1>);
       runb("bf16x3 no epilogue + split, 2 waves/SIMD", 512, k_rate_b<0, 2>);
       runb("bf16x3 silu+save+split, 1 wave/SIMD", 256, k_rate_b<1, 1>);

@@ -165,3 +165,32 @@ def test_model_file_roundtrip_and_per_edge_type_cutoff(emu_lib, tmp_path):
     res = util.run_pair(emu_lib, path, cell, pos, types, ["B", "A"])
     ref = util.oracle_run(cfg, w, cell, pos, types, ["B", "A"])
     util.assert_close_to(res, ref, 1e-8, what="per-edge-type cutoff")
+
+
+def test_stage_timings_accumulate_between_reads(emu_lib, model_dir):
+    """Round 4: `timing=1` records an event pair per stage and call and nobody waits for them inside ahip_compute*; `ahip_get_timings` returns, per stage, the SUM over the
+    calls since the previous read and `ahip_get_timing_counts` the number of launches behind it (bench.py reads them once behind its timed region; read after every call
+    they are that call's timings, as before)."""
+    import util
+    from pair_allegro_amd import capi, lmp_like
+    g = util.load_golden("Si64_r5")
+    path, cfg, w = util.golden_model(g, model_dir, "float64")
+    types, names = util.lammps_types(g)
+    rs = lmp_like.build_rank_system(g["cell"], g["pos"], types, cfg["r_max"] + 1.0)
+    m = capi.Model(path, 0, emu_lib)
+    m.set_option("timing", "1")
+    m.neigh_update_csr(rs.nall, rs.ilist, rs.offsets, rs.flat)
+    mapper = np.zeros(1, np.int32); cm = np.full((1, 1), cfg["r_max"])
+    def one():
+        f = np.zeros_like(rs.x); e = np.zeros(rs.nall)
+        m.compute(rs.nlocal, rs.nghost, rs.x, rs.type, mapper, cm, f, e)
+    one()
+    t1, c1 = m.timings_and_counts()
+    assert "model_generic" in t1 and c1["model_generic"] == 1 and t1["model_generic"] > 0
+    assert m.timings() == {}                                   # nothing recorded since the last read
+    for _ in range(3):
+        one()
+    t3, c3 = m.timings_and_counts()
+    assert c3["model_generic"] == 3 and set(t3) == set(t1)
+    assert t3["model_generic"] > 1.5 * t1["model_generic"] * 0.5          # a sum over three calls, not the last call's value (loose: host timers)
+    m.close()

@@ -242,13 +242,38 @@ def main():
               f"comm_init_ms={ci['init_ms']} nlocal={sim.nlocal} nghost={sim.nall - sim.nlocal}", file=sys.stderr, flush=True)
     if os.environ.get("AHIP_BENCH_TEST_KILL_RANK", "") == str(rank):        # tests only (tests/test_gpu_md.py): a rank that dies after start-up
         os._exit(17)
-    for _ in range(args.warmup):
-        sim.step()
-
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # Exchange schedule with more than one rank: overlapped (three centre ranges per step, the exchange beside the interior ones) or serial
+    # (exchange, one call, exchange).  Which one wins depends on what the exchange costs on the machine at hand against the fixed cost of two more
+    # range calls (0.2 ms at 125 k atoms per rank, 1.4 ms at 1 M: profiles/r04_f_final.md), so unless a flag says otherwise both are timed for
+    # a few steps (minimum step time of each, maximum over ranks) before the warm-up and the faster one runs the benchmark.
+    autotune = None
+    if world > 1 and not args.no_overlap and not args.force_overlap and sim.overlap:
+        def min_step_ms(n):
+            best = float("inf")
+            for _ in range(n):
+                barrier()
+                t = time.perf_counter()
+                sim.step()
+                torch.cuda.synchronize()
+                best = min(best, 1e3 * (time.perf_counter() - t))
+            tt = torch.tensor([best], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        sim.step()                                   # first-launch costs out of the way
+        t_ov = min_step_ms(3)
+        sim.set_overlap(False)
+        sim.step()
+        t_se = min_step_ms(3)
+        use_overlap = t_ov <= t_se                   # identical on every rank (all-reduced times)
+        sim.set_overlap(use_overlap)
+        autotune = {"overlapped_ms": round(t_ov, 3), "serial_ms": round(t_se, 3), "chosen": "overlapped" if use_overlap else "serial"}
+    for _ in range(args.warmup):
+        sim.step()
 
     nrebuild0 = sim.nrebuild
     # Stage timings: the library records HIP events on its launch stream around every stage of every call and nobody waits for them
@@ -364,7 +389,7 @@ def main():
                        "rebuilds_in_timed_steps": rebuilds_timed, "rebuild_ms": round(rebuild_ms, 3),
                        "steps_per_rebuild": (round(args.steps / rebuilds_timed, 1) if rebuilds_timed else None),
                        "rebuild_share_of_step_at_1_per_50": round(rebuild_ms / 50.0 / ms_per_step, 5),
-                       "comm": "overlapped" if sim.overlap else "serial",
+                       "comm": "overlapped" if sim.overlap else "serial", "comm_autotune": autotune,
                        "comm_transport": (("library/" + sim.comm.transport + ("/single-rank gather-scatter" if world == 1 else "")) if getattr(sim, "comm", None) is not None else "torch.distributed"),
                        "stage_ms_rank0": {k: round(v, 3) for k, v in stage_avg.items()},
                        "stage_ms": {k: round(v / args.steps, 3) for k, v in stage_max.items()},          # max over ranks, per step

@@ -444,8 +444,24 @@ class Simulation:
         self.n_int = int(interior.sum().item())
         self.n_half = self.n_int // 2
 
+    def set_overlap(self, flag: bool) -> None:
+        """Switch between the overlapped three-range schedule and the serial one (exchange, all centres in one call, exchange) at run time.
+        The interior-first atom order of the last re-neighboring serves both; switching overlap ON after a re-neighboring done without it
+        re-neighbors once.  The persistent kernels keep workgroup slots free for the exchange kernels only while there is something to overlap."""
+        flag = bool(flag) and hasattr(self.backend, "compute_range")
+        if flag == self.overlap:
+            return
+        self.overlap = flag
+        if flag and self.comm_stream is None and self.dev.type == "cuda":
+            self.comm_stream = torch.cuda.Stream(self.dev)
+        if self.dev.type == "cuda" and self.nranks > 1 and hasattr(self.backend, "model"):
+            self.backend.model.set_option("reserve_wgs", 8 if flag else 0)
+        if flag and not getattr(self, "_ordered", False):
+            self.rebuild()
+
     def rebuild(self) -> None:
         self._migrate()
+        self._ordered = bool(self.overlap)
         if self.overlap:
             self._order_interior_first()
         self._borders()

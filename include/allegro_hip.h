@@ -217,6 +217,10 @@ int ahip_reneighbor_flag_dev(ahip_model *m, int n, const double *x_dev, const do
  *   mode 1: v += 0.5*dt*f*ftm2v/mass[type]                  (final_integrate)  */
 int ahip_nve_dev(ahip_model *m, int mode, int n, double *x_dev, double *v_dev, const double *f_dev,
                  const int *mtype_dev, const double *mass_by_mtype, double dt, double ftm2v, void *stream);
+/* mode 0 for the nlocal owned atoms AND f[0 .. nall) = 0 behind it (the array the next force evaluation accumulates into, pair_nequip_allegro.cpp:370-377
+ * adds to whatever f holds): one launch instead of an integrate and a zero-fill per step of the stand-alone driver. */
+int ahip_nve_first_dev(ahip_model *m, int nlocal, int nall, double *x_dev, double *v_dev, double *f_dev, const int *mtype_dev,
+                       const double *mass_by_mtype, double dt, double ftm2v, void *stream);
 
 /* ---- ghost exchange of a spatially decomposed system (csrc/comm.hip) ---------------------------
  * Replaces what the reference gets from LAMMPS: ghost positions through Comm::forward_comm before compute(), and the forces the

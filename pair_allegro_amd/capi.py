@@ -23,7 +23,7 @@ SYMBOLS = [
     "ahip_set_option", "ahip_get_timing_counts", "ahip_last_tile_occupancy", "ahip_neigh_update", "ahip_neigh_update_csr", "ahip_neigh_update_dev",
     "ahip_compute", "ahip_compute_dev", "ahip_output_register", "ahip_output_get", "ahip_get_edges", "ahip_debug_dump_edges", "ahip_get_timings",
     "ahip_compute_dev_range", "ahip_last_list_size", "ahip_neigh_update_dev_table", "ahip_map_types_dev", "ahip_reneighbor_flag_dev",
-    "ahip_last_path", "ahip_last_max_degree", "ahip_debug_fused_linear", "ahip_debug_fused_edges", "ahip_build_neighbors_dev", "ahip_nve_dev",
+    "ahip_last_path", "ahip_last_max_degree", "ahip_debug_fused_linear", "ahip_debug_fused_edges", "ahip_build_neighbors_dev", "ahip_nve_dev", "ahip_nve_first_dev",
     "ahip_model_allow_tf32", "ahip_comm_unique_id", "ahip_comm_create_rccl", "ahip_comm_create_hosted", "ahip_comm_rccl_version", "ahip_comm_free", "ahip_comm_set_plan", "ahip_comm_set_plan_local",
     "ahip_comm_forward", "ahip_comm_reverse", "ahip_comm_allreduce", "ahip_comm_selftest", "ahip_fill_zero_dev",
 ]
@@ -259,6 +259,14 @@ class Model:
         mass = np.ascontiguousarray(mass_by_mtype, dtype=np.float64)
         self.L.check(self.L.lib.ahip_nve_dev(self.h, mode, n, x_ptr, v_ptr, f_ptr, mtype_ptr, _p(mass, C.c_double),
                                               dt, ftm2v, stream or None))
+
+    def nve_first_dev(self, nlocal: int, nall: int, x_ptr: int, v_ptr: int, f_ptr: int, mtype_ptr: int, mass_by_mtype,
+                      dt: float, ftm2v: float, stream: int = 0) -> None:
+        mass = np.ascontiguousarray(mass_by_mtype, dtype=np.float64)
+        self.L.lib.ahip_nve_first_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.POINTER(C.c_double), C.c_double, C.c_double, C.c_void_p]
+        self.L.check(self.L.lib.ahip_nve_first_dev(self.h, nlocal, nall, x_ptr, v_ptr, f_ptr, mtype_ptr, _p(mass, C.c_double),
+                                                    dt, ftm2v, stream or None))
 
     # ---- introspection -----------------------------------------------------------------------
     def nedges(self) -> int:

@@ -817,8 +817,19 @@ int ahip_reneighbor_flag_dev(ahip_model *m, int n, const double *x_dev, const do
     require_model(m);
     if (n < 0 || !flag_dev || (n > 0 && (!x_dev || !xhold_dev || !v_dev))) throw ArgError("ahip_reneighbor_flag_dev: bad argument");
     AHIP_CHECK(hipSetDevice(m->device));
-    m->b_flagwork.reserve(64);
+    if (!m->b_flagwork.p) { m->b_flagwork.reserve(64); AHIP_CHECK(hipMemsetAsync(m->b_flagwork.p, 0, 64, (hipStream_t)stream)); }      // the two maxima start from zero; the flag kernel resets them after every use
     AHIP_CHECK(prim_reneighbor_flag(x_dev, xhold_dev, v_dev, n, dt, half_skin, m->b_flagwork.as<unsigned int>(), flag_dev, (hipStream_t)stream));
+  });
+}
+
+int ahip_nve_first_dev(ahip_model *m, int nlocal, int nall, double *x_dev, double *v_dev, double *f_dev, const int *mtype_dev,
+                       const double *mass_by_mtype, double dt, double ftm2v, void *stream) {
+  return guarded([&] {
+    require_model(m);
+    if (nlocal < 0 || nall < nlocal || (nall > 0 && !f_dev) || (nlocal > 0 && (!x_dev || !v_dev || !mtype_dev || !mass_by_mtype)))
+      throw ArgError("ahip_nve_first_dev: bad argument");
+    AHIP_CHECK(hipSetDevice(m->device));
+    nve_first_step(nlocal, nall, x_dev, v_dev, f_dev, mtype_dev, mass_by_mtype, m->hm.num_types, dt, ftm2v, (hipStream_t)stream);
   });
 }
 

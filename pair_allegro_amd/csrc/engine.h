@@ -267,6 +267,8 @@ void neigh_from_table(Model &m, int inum, int nall, const int *ilist_dev, const 
                       long long stride_atom, long long stride_slot, int mask, hipStream_t s);
 void map_types(Model &m, int n, const int *type_dev, int ntypes, const int *mapper_host, int *out_dev, hipStream_t s);
 void neigh_free(Model &m);
+void nve_first_step(int n, int nall, double *x, double *v, double *f, const int *mtype, const double *mass_host, int ntypes, double dt, double ftm2v,
+                    hipStream_t s);
 void nve_step(int mode, int n, double *x, double *v, const double *f, const int *mtype, const double *mass_dev_or_host,
               int ntypes, double dt, double ftm2v, hipStream_t s);
 

@@ -280,6 +280,30 @@ __global__ void k_nve(int mode, int n, double *x, double *v, const double *f, co
   if (mode == 0) x[t] += dt * vv;
 }
 
+// first half step + the zero-fill of the force array the coming evaluation accumulates into (rows [0, nall): locals after their force has been
+// used, ghosts outright): one launch instead of two in every step of the stand-alone driver
+__global__ void k_nve_first(int n, int nall, double *x, double *v, double *f, const int *mtype, MassTab mt, double dt, double dtf) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 3LL * nall) return;
+  if (t < 3LL * n) {
+    double dtfm = dtf * mt.inv_mass[mtype[t / 3]];
+    double vv = v[t] + dtfm * f[t];
+    v[t] = vv;
+    x[t] += dt * vv;
+  }
+  f[t] = 0.0;
+}
+void nve_first_step(int n, int nall, double *x, double *v, double *f, const int *mtype, const double *mass_host, int ntypes, double dt, double ftm2v,
+                    hipStream_t s) {
+  if (ntypes > 16) throw UnsupportedError("nve: more than 16 model types");
+  MassTab mt;
+  for (int k = 0; k < 16; ++k) mt.inv_mass[k] = k < ntypes ? 1.0 / mass_host[k] : 0.0;
+  if (nall <= 0) return;
+  const unsigned B = 256;
+  hipLaunchKernelGGL(k_nve_first, dim3((unsigned)((3LL * nall + B - 1) / B)), dim3(B), 0, s, n, nall, x, v, f, mtype, mt, dt, 0.5 * dt * ftm2v);
+  AHIP_CHECK(hipGetLastError());
+}
+
 void nve_step(int mode, int n, double *x, double *v, const double *f, const int *mtype, const double *mass_host,
               int ntypes, double dt, double ftm2v, hipStream_t s) {
   if (ntypes > 16) throw UnsupportedError("nve: more than 16 model types");

@@ -181,16 +181,15 @@ __global__ void __launch_bounds__(256) k_disp_max(const double *x, const double 
   for (int off = 32; off > 0; off >>= 1) { md = fmaxf(md, __shfl_down(md, off, 64)); mv = fmaxf(mv, __shfl_down(mv, off, 64)); }
   if ((threadIdx.x & 63) == 0) { atomicMax(&work[0], __float_as_uint(md)); atomicMax(&work[1], __float_as_uint(mv)); }
 }
-__global__ void k_disp_flag(const unsigned int *work, double dt, double half_skin, int *flag) {
+__global__ void k_disp_flag(unsigned int *work, double dt, double half_skin, int *flag) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const double reach = sqrt((double)__uint_as_float(work[0])) + 2.0 * dt * sqrt((double)__uint_as_float(work[1]));
     flag[0] = reach > half_skin ? 1 : 0;
+    work[0] = 0u; work[1] = 0u;             // ready for the next step's maxima: no memset launch per step (the caller zeroes the words once)
   }
 }
 hipError_t prim_reneighbor_flag(const double *x, const double *xhold, const double *v, int n, double dt, double half_skin,
                                 unsigned int *work, int *flag, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(work, 0, 2 * sizeof(unsigned int), s);
-  if (e != hipSuccess) return e;
   if (n > 0) {
     int nb = (n + 255) / 256;
     if (nb > 1024) nb = 1024;

@@ -87,6 +87,10 @@ class HipBackend:
     def nve(self, mode: int, n: int, x, v, f, mtype, dt: float) -> None:
         self.model.nve_dev(mode, n, x.data_ptr(), v.data_ptr(), f.data_ptr(), mtype.data_ptr(), self.mass, dt, FTM2V)
 
+    def nve_first(self, n: int, x, v, f, mtype, dt: float) -> None:
+        """first half step of the owned atoms + zero-fill of ALL rows of f, in one launch (ahip_nve_first_dev)"""
+        self.model.nve_first_dev(n, f.shape[0], x.data_ptr(), v.data_ptr(), f.data_ptr(), mtype.data_ptr(), self.mass, dt, FTM2V)
+
     def fill_zero(self, t: torch.Tensor, stream: int = 0) -> None:
         self.model.L.check(self.model.L.lib.ahip_fill_zero_dev(t.data_ptr(), t.numel() * t.element_size(), stream or None))
 
@@ -467,6 +471,7 @@ class Simulation:
         self._borders()
         self._set_comm_plan()
         self.f = torch.zeros((self.nall, 3), dtype=torch.float64, device=self.dev)
+        self._f_zeroed = True
         lo = self.lo - self.rc - 1e-6
         hi = self.hi + self.rc + 1e-6
         self.backend.build_neighbors(self.x, self.nlocal, lo, hi, self.rc)
@@ -558,7 +563,9 @@ class Simulation:
     # ---- force evaluation and time step -----------------------------------------------------------
     def compute_forces(self, comm_first: bool = True) -> None:
         """forward comm -> forces of all centres -> reverse comm.  Overlapped schedule: see __init__."""
-        if hasattr(self.backend, "fill_zero"):
+        if getattr(self, "_f_zeroed", False):           # the integrator's first half step, or the re-neighboring's fresh array, left it zero
+            self._f_zeroed = False
+        elif hasattr(self.backend, "fill_zero"):
             self.backend.fill_zero(self.f, self._stream())
         else:
             self.f.zero_()
@@ -605,7 +612,11 @@ class Simulation:
 
     def step(self) -> None:
         n = self.nlocal
-        self.backend.nve(0, n, self.x, self.v, self.f, self.mtype, self.dt)         # v += dt/2 f/m ; x += dt v
+        if hasattr(self.backend, "nve_first") and hasattr(self.backend.model.L.lib, "ahip_nve_first_dev"):
+            self.backend.nve_first(n, self.x, self.v, self.f, self.mtype, self.dt)      # v += dt/2 f/m ; x += dt v ; f = 0 for the evaluation below
+            self._f_zeroed = True
+        else:
+            self.backend.nve(0, n, self.x, self.v, self.f, self.mtype, self.dt)         # v += dt/2 f/m ; x += dt v
         if self.needs_rebuild():
             self.rebuild()
             self._flag_posted = False

@@ -18,7 +18,7 @@ from pair_allegro_amd import capi, lmp_like, md, model_file
 
 pytestmark = pytest.mark.gpu
 
-LAUNCHES = 100
+LAUNCHES = int(os.environ.get("AHIP_SOAK_LAUNCHES", "100"))          # 100 in the suite; the round-4 evidence run used 2000 (profiles/r04_j_soak_2000.txt)
 _oracle_cache = {}          # the float64 oracle once per (model, system), shared by the arithmetics
 
 

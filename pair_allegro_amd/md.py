@@ -461,7 +461,9 @@ class Simulation:
         if self.dev.type == "cuda" and self.nranks > 1 and hasattr(self.backend, "model"):
             self.backend.model.set_option("reserve_wgs", 8 if flag else 0)
         if flag and not getattr(self, "_ordered", False):
-            self.rebuild()
+            self.rebuild()                               # between two steps: the new force array must hold the forces the next half kick uses
+            self._flag_posted = False
+            self.compute_forces(comm_first=False)
 
     def rebuild(self) -> None:
         self._migrate()

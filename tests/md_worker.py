@@ -9,13 +9,15 @@ import torch.distributed as dist
 from pair_allegro_amd import capi, lmp_like, md, model_file
 
 
-def run(lib, path, cell, pos, vel, cfg, grid, rank, d, nsteps, skin=1.0):
+def run(lib, path, cell, pos, vel, cfg, grid, rank, d, nsteps, skin=1.0, toggle=False):
     model = capi.Model(path, 0, lib)
     sim = md.Simulation(md.HipBackend(model, [28.0855]), np.diag(cell), cfg["r_max"], skin, pos, np.zeros(len(pos), np.int32),
                         vel, torch.device("cpu"), grid=grid, rank=rank, dist=d, dt=0.001)
     sim.setup()
     f = sim.gather_forces()
-    for _ in range(nsteps):
+    for k in range(nsteps):
+        if toggle and sim.nranks > 1 and k % 3 == 1:
+            sim.set_overlap(not sim.overlap)         # bench.py's schedule choice: switching between the two schedules must not change the trajectory
         sim.step()
     x = torch.zeros((len(pos), 3), dtype=torch.float64)
     x[sim.tag[: sim.nlocal]] = sim.x[: sim.nlocal]
@@ -51,7 +53,8 @@ def main():
         pos = pos - pos.min(axis=0) + np.array([8.5, 14.0, 14.0])
         cell = np.diag([40.0, 40.0, 40.0])
     vel = md.maxwell_boltzmann(len(pos), np.full(len(pos), 28.0855), temperature, 12345)
-    f2, x2, e2, nreb, nloc = run(lib, path, cell, pos, vel, cfg, grid, rank, dist, nsteps, skin)
+    toggle = len(sys.argv) > 7 and sys.argv[7] == "toggle"
+    f2, x2, e2, nreb, nloc = run(lib, path, cell, pos, vel, cfg, grid, rank, dist, nsteps, skin, toggle)
     nl = torch.tensor([nloc]); dist.all_reduce(nl)
     assert int(nl.item()) == len(pos), "atoms lost or duplicated in migration"
     if rank == 0:

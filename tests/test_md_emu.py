@@ -77,6 +77,16 @@ def test_gloo_rebuild_and_migration(emu_lib, model_dir, tmp_path):
     np.testing.assert_allclose(z["e2"], z["e1"], rtol=1e-9)
 
 
+def test_gloo_switching_the_exchange_schedule_keeps_the_trajectory(emu_lib, model_dir, tmp_path):
+    """`bench.py --gpus N` times the overlapped and the serial schedule and keeps the faster one (`Simulation.set_overlap`).  Hot system, small skin
+    (re-neighborings in both modes, one of them forced by switching overlap back on after a serial re-neighboring), the schedule flipped every third
+    step on 2x2x1 bricks: positions and energy equal the single-rank run."""
+    z = _run_workers(emu_lib, model_dir, tmp_path, 4, 29741, extra=(4000.0, 24, 0.3, "toggle"))
+    assert int(z["nreb"]) >= 2
+    np.testing.assert_allclose(z["x2"], z["x1"], atol=1e-8)
+    np.testing.assert_allclose(z["e2"], z["e1"], rtol=1e-9)
+
+
 def test_gloo_empty_brick_next_to_a_cluster(emu_lib, model_dir, tmp_path):
     """2x1x1 bricks, every atom in brick 0 (a cluster in a large box): rank 0 receives no ghosts but sends a slab, rank 1 owns nothing.
     The exchange plan of a rank without ghosts must still post its sends (the single-rank plan was taken whenever

@@ -182,6 +182,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # A rank that hangs (a collective whose peer died, an exchange kernel that never gets a CU) must not sit there until the launcher's own
+        # timeout: after the wall-clock budget every rank prints where its threads are and exits non-zero.
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ.get("AHIP_BENCH_BUDGET_S", "900")), exit=True)
+
     import torch
     from pair_allegro_amd import capi, md, model_file
 
@@ -406,6 +412,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist_raw.destroy_process_group()
+    if world > 1:
+        import faulthandler
+        faulthandler.cancel_dump_traceback_later()
 
 
 def cpu_sample(config: int, ncell: int):

@@ -68,6 +68,14 @@ int ahip_model_meta(const ahip_model *m, double *r_max, int *num_types, const ch
  *                                                 kernels launched on OTHER streams (ghost exchange) can run beside them (default 0)
  *   "cutoff_compare" = "le" | "lt"               edge kept iff rsq <= cut^2 (default; pair_nequip_allegro.cpp:507) or rsq < cut^2
  *                                                 (the KOKKOS path of the reference, pair_nequip_allegro_kokkos.cpp:174)
+ *   "fused_arith" = "auto" | "f32" | "bf16x3" | "tf32eq"   arithmetic of the dense contractions of the l_max = 1 fused kernel: f32-input MFMA;
+ *                                                 three-term bf16 split (float32-equivalent); two-term bf16 split (TF32-class).  auto = f32 unless
+ *                                                 the model file says allow_tf32 = 1 (pair_nequip_allegro.cpp:267-270), then tf32eq
+ *   "fused_tb"  = "table" | "mlp"                two-body embedding of the fused kernels: tabulated cubic splines (default) or the MLP itself
+ *   "edge_schedule" = "auto" | "static" | "dynamic"   unit schedule of the single-pass edge build (dynamic: safe beside other resident kernels)
+ *   "tile_pack" = "auto" | "separate" | "fused"  tile packing of the fused kernels inside the edge build or as its own kernels
+ *   "timing"    = "0" | "1"                      record per-stage HIP events (ahip_get_timings)
+ * Unknown keys and values are errors (AHIP_ERR_ARG).
  */
 int ahip_set_option(ahip_model *m, const char *key, const char *value);
 
@@ -126,9 +134,14 @@ int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const i
  * x_dev/f_dev/eatom_dev are device pointers, mtype_dev holds MODEL types (already mapped),
  * cutoff_matrix_model is a HOST [num_types^2] matrix in model-type index (NULL = r_max).
  * Forces are accumulated into f_dev; eng_vir_dev receives 7 doubles {eng, xx,yy,zz,xy,xz,yz}.
- * Asynchronous on `stream` (a hipStream_t, NULL = default) except for one 4-byte read-back of
- * the edge count (the Kokkos path has the same one, :203-206).  With outputs registered through ahip_output_register the
- * call additionally keeps host copies of them (pair_nequip_allegro_kokkos.cpp:342-344) and synchronises the stream. */
+ * Asynchronous on `stream` (a hipStream_t, NULL = default).  The reference's Kokkos path reads its edge total back in every step
+ * (:203-206); here the counters of the edge build (edge total, largest degree, centres left to the layer-at-a-time kernels) travel to
+ * page-locked memory behind the edge build and the host waits for them only when it needs a value: never on the l_max = 1 fused path with
+ * list rows of at most 128 entries (the row length measured at ahip_neigh_update* bounds every degree; tile shape and tile count are
+ * decided on the device), after the model kernel has been enqueued on the wide fused paths (number of centres with more than 64 edges),
+ * before the model on the layer-at-a-time path, and in the getters (ahip_get_edges, ahip_last_max_degree, ahip_last_tile_occupancy).
+ * With outputs registered through ahip_output_register the call additionally keeps host copies of them
+ * (pair_nequip_allegro_kokkos.cpp:342-344) and synchronises the stream. */
 int ahip_compute_dev(ahip_model *m, int nlocal, int nghost, const double *x_dev, const int *mtype_dev,
                      const double *cutoff_matrix_model, double *f_dev, double *eatom_dev,
                      double *eng_vir_dev, void *stream);

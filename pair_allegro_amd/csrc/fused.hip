@@ -179,6 +179,10 @@ __device__ __forceinline__ void linear_b(__amdgpu_buffer_rsrc_t W, int &wp, cons
   constexpr int NPROD = NTERM == 3 ? 6 : 3, MF = 2 * NPROD;      // products per accumulator, MFMAs per step
   constexpr int NP = NT / 2, NSTEP = NP * KS, NS = NF * NSTEP;
   f32x4 acc0, acc1, prev0, prev1;
+  // byte offset of the next fragments to request: ONE running scalar advanced step by step, as in linear_s (written as wp + constant the optimiser
+  // forms every offset of the tile at the top of the tile loop and spills them to VGPR lanes: 508 scalar spills in the two-layer instance)
+  int wo = (wp + RB * 256) * 4;
+  pin_s(wo);
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
     const int p = s / KS, ks = s % KS;
@@ -190,8 +194,10 @@ __device__ __forceinline__ void linear_b(__amdgpu_buffer_rsrc_t W, int &wp, cons
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
       a[i] = ring[(RP + NF * s + i) % RB];
-      ring[(RP + NF * s + i) % RB] = __builtin_bit_cast(u32x4, bload(W, v16, (wp + (NF * s + i + RB) * 256) * 4));
+      ring[(RP + NF * s + i) % RB] = __builtin_bit_cast(u32x4, bload_w(W, v16 + (i & 3) * 1024, wo + (i >> 2) * 4096));      // + k KiB: the instruction's immediate offset
     }
+    wo += NF * 1024;
+    pin_s(wo);
     // the two accumulators alternate; smallest terms first
 #pragma unroll
     for (int m = 0; m < NPROD; ++m) {
@@ -234,10 +240,13 @@ __device__ __forceinline__ void linear_b(__amdgpu_buffer_rsrc_t W, int &wp, cons
     __builtin_amdgcn_sched_barrier(0);
   }
   wp += NS * 256;
+  pin_s(wp);
 }
 template <int RB> __device__ __forceinline__ void ring_prime_b(__amdgpu_buffer_rsrc_t W, int wp, int v16, u32x4 (&ring)[RB]) {
+  int wo = wp * 4;
+  pin_s(wo);
 #pragma unroll
-  for (int j = 0; j < RB; ++j) ring[j] = __builtin_bit_cast(u32x4, bload(W, v16, (wp + j * 256) * 4));
+  for (int j = 0; j < RB; ++j) ring[j] = __builtin_bit_cast(u32x4, bload_w(W, v16 + (j & 3) * 1024, wo + (j >> 2) * 4096));
 }
 
 // Per-centre sum of the staged tile: dst[a][f] = scale * sum_{slots of a} stage[slot][f], f < 128.

@@ -280,7 +280,7 @@ static __global__ void k_centre_info(int inum, const int *ilist, const int *mtyp
   int ii = blockIdx.x * blockDim.x + threadIdx.x;
   if (ii < inum) { const int i = ilist[ii]; centre[ii] = make_int2(i, mtype[i]); }
 }
-// Small systems (<= PACK_SMALL_SEGS segments = 131 072 centres): the whole tile packing -- segment counts, their scan, the fill, the tile bounds
+// Small systems (<= PACK_SMALL_ATOMS centres, below): the whole tile packing -- segment counts, their scan, the fill, the tile bounds
 // and the per-centre {atom, type} records -- in ONE single-workgroup launch instead of six (a 10 648-atom step is launch-bound: 0.056 -> 0.03 ms).
 static constexpr int PACK_SMALL_SEGS = 1024;
 // One workgroup streams what one CU's L2 port delivers: up to one LDS chunk of centres the single launch wins (10 648 atoms: 29 us), beyond it the six

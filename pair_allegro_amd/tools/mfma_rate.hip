@@ -130,6 +130,101 @@ __global__ void __launch_bounds__(256, OCC) k_rate_b2(const float *W, int wbytes
   if (sum == 12345.678f) out[0] = (long long)pad[lane];
 }
 
+// The same with what the real kernel does around the MFMAs: SiLU + saved derivative rows (EpiSiluSaveD per group, the 16 epilogue elements of the previous
+// tile pair spread over the MFMAs of the current one), outputs split into the next linear's B operands, and BALLAST registers per lane kept live across the
+// linears (the per-edge state of two groups that a real tile carries: latent 2 x 16 is in the operands already, edge tensor 2 x 32 = 64).
+template <int KS, int NT>
+__device__ __forceinline__ void linear_b2e(__amdgpu_buffer_rsrc_t W, int &wp, const Bop (&in0)[KS], const Bop (&in1)[KS], f32x4 (&out0)[NT], f32x4 (&out1)[NT],
+                                           Bop (&ob0)[NT / 2], Bop (&ob1)[NT / 2], int v16, u32x4 (&ring)[RINGB], EpiSiluSaveD e0, EpiSiluSaveD e1) {
+  constexpr int NF = 6, NPROD = 6, NP = NT / 2, NSTEP = NP * KS, NS = NF * NSTEP, RB = RINGB;
+  f32x4 a0 = {0, 0, 0, 0}, a1 = a0, b0 = a0, b1 = a0, pa0 = a0, pa1 = a0, pb0 = a0, pb1 = a0;
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    const int p = s / KS, ks = s % KS;
+    if (ks == 0) { a0 = a1 = b0 = b1 = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    u32x4 a[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      a[i] = ring[(NF * s + i) % RB];
+      ring[(NF * s + i) % RB] = __builtin_bit_cast(u32x4, bload(W, v16, (wp + (NF * s + i + RB) * 256) * 4));
+    }
+#pragma unroll
+    for (int m = 0; m < NPROD; ++m) {
+      const int wt = m == 0 ? 2 : (m == 1 || m == 3) ? 1 : 0;
+      const int xt = (m == 0 || m == 3 || m == 5) ? 0 : (m == 1 || m == 4) ? 1 : 2;
+      const u32x4 x0 = xt == 0 ? in0[ks].hi : xt == 1 ? in0[ks].mid : in0[ks].lo;
+      const u32x4 x1 = xt == 0 ? in1[ks].hi : xt == 1 ? in1[ks].mid : in1[ks].lo;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q == 0) a0 = mfma_b(a[2 * wt], x0, a0);
+        else if (q == 1) b0 = mfma_b(a[2 * wt], x1, b0);
+        else if (q == 2) a1 = mfma_b(a[2 * wt + 1], x0, a1);
+        else b1 = mfma_b(a[2 * wt + 1], x1, b1);
+        if (p > 0) {
+          // 16 epilogue elements of the previous pair (8 per group) over the KS * 24 MFMAs of this pair
+          const int idx = ks * 24 + 4 * m + q, tot = KS * 24;
+          const int f0 = (idx * 16 + tot - 1) / tot, f1 = ((idx + 1) * 16 + tot - 1) / tot;
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if (e >= f0 && e < f1) {
+              const int grp = e >> 3, el = e & 7;
+              if (grp == 0) {
+                if (el < 4) out0[2 * (p - 1)][el] = e0.apply(2 * (p - 1), el, pa0[el]); else out0[2 * (p - 1) + 1][el - 4] = e0.apply(2 * (p - 1) + 1, el - 4, pa1[el - 4]);
+                if (el == 7) { e0.flush(2 * (p - 1)); ob0[p - 1] = split_pair(out0[2 * (p - 1)], out0[2 * (p - 1) + 1]); }
+              } else {
+                if (el < 4) out1[2 * (p - 1)][el] = e1.apply(2 * (p - 1), el, pb0[el]); else out1[2 * (p - 1) + 1][el - 4] = e1.apply(2 * (p - 1) + 1, el - 4, pb1[el - 4]);
+                if (el == 7) { e1.flush(2 * (p - 1)); ob1[p - 1] = split_pair(out1[2 * (p - 1)], out1[2 * (p - 1) + 1]); }
+              }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (ks == KS - 1) {
+      if (p == NP - 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          out0[2 * p][r] = e0.apply(2 * p, r, a0[r]); out0[2 * p + 1][r] = e0.apply(2 * p + 1, r, a1[r]);
+          out1[2 * p][r] = e1.apply(2 * p, r, b0[r]); out1[2 * p + 1][r] = e1.apply(2 * p + 1, r, b1[r]);
+        }
+        e0.flush(2 * p); e1.flush(2 * p);
+        ob0[p] = split_pair(out0[2 * p], out0[2 * p + 1]); ob1[p] = split_pair(out1[2 * p], out1[2 * p + 1]);
+      } else { pa0 = a0; pa1 = a1; pb0 = b0; pb1 = b1; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  wp += NS * 256;
+}
+template <int OCC, int BALLAST>
+__global__ void __launch_bounds__(256, OCC) k_rate_b2e(const float *W, int wbytes, float *scr, long long *out, int iters) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, v16 = lane * 16;
+  __shared__ float pad[OCC == 2 ? 20000 : 40000];
+  pad[threadIdx.x] = 0.f;
+  __amdgpu_buffer_rsrc_t WB = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, wbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t SB = __builtin_amdgcn_make_buffer_rsrc((void *)(scr + ((size_t)blockIdx.x * 4 + wave) * 16 * ROW), 0, 16 * ROW * 4, 0x00020000);
+  f32x4 x[4], z[4], y0[4], y1[4];
+  u32x4 ring[RINGB];
+  float bal[BALLAST > 0 ? BALLAST : 1];
+  for (int i = 0; i < BALLAST; ++i) bal[i] = 0.5f * (float)(lane + i);
+  for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r) { x[t][r] = 0.001f * (float)((lane * 7 + t * 4 + r) % 13); z[t][r] = 0.002f * (float)((lane * 5 + t * 4 + r) % 11); }
+  Bop xa[2], xb[2], ya[2], yb[2];
+  xa[0] = split_pair(x[0], x[1]); xa[1] = split_pair(x[2], x[3]);
+  xb[0] = split_pair(z[0], z[1]); xb[1] = split_pair(z[2], z[3]);
+  int wp = 0;
+  ring_prime_b(WB, wp, v16, ring);
+  for (int it = 0; it < iters; ++it) {
+    wp = 0;
+#pragma unroll
+    for (int i = 0; i < BALLAST; ++i) asm volatile("" : "+v"(bal[i]));        // live here, in registers
+    linear_b2e<2, 4>(WB, wp, xa, xb, y0, y1, ya, yb, v16, ring, EpiSiluSaveD{SB, 0, v16}, EpiSiluSaveD{SB, 4, v16});
+    linear_b2e<2, 4>(WB, wp, ya, yb, x, z, xa, xb, v16, ring, EpiSiluSaveD{SB, 8, v16}, EpiSiluSaveD{SB, 12, v16});
+  }
+  float sum = 0.f;
+  for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r) sum += x[t][r] + z[t][r];
+  for (int i = 0; i < BALLAST; ++i) sum += bal[i];
+  if (sum == 12345.678f) out[0] = (long long)pad[lane];
+}
+
 // bf16x3 64x64 linears with the weight fragments SHARED by the 4 waves of a workgroup through LDS (each wave fetches a quarter of
 // the next linear's 24 fragments while the current ones are consumed; one barrier per linear).  Feasibility probe for the next
 // kernel generation: per-wave register rings are bound by the 64 B/clk/CU return path (see k_rate_b).
@@ -313,6 +408,10 @@ int main() {
         };
         runb2("bf16x3 two edge groups per fragment, 1 wave/SIMD", 256, k_rate_b2<1>);
         runb2("bf16x3 two edge groups per fragment, 2 waves/SIMD", 512, k_rate_b2<2>);
+        runb2("two groups + silu+save+split, 1 wave/SIMD", 256, k_rate_b2e<1, 0>);
+        runb2("two groups + silu+save+split, 2 waves/SIMD", 512, k_rate_b2e<2, 0>);
+        runb2("two groups + silu+save+split + 64 live regs, 2 waves/SIMD", 512, k_rate_b2e<2, 64>);
+        runb2("two groups + silu+save+split + 96 live regs, 2 waves/SIMD", 512, k_rate_b2e<2, 96>);
       }
       runb("bf16x3 no epilogue + split, 1 wave/SIMD", 256, k_rate_b<0, 1>);
       runb("bf16x3 no epilogue + split, 2 waves/SIMD", 512, k_rate_b<0, 2>);

@@ -14,6 +14,12 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "liballegro_hip.so")
+# Pageable host memory handed to hipMemcpy is pinned on the fly by the HIP runtime for copies above 1 MiB and that pinning is cached by address; after the
+# heap has returned and re-acquired pages (any long-lived process) the cache can be stale and the copy engine faults on a host address (round 4: 4 of 10 runs
+# of the GPU test suite died that way inside a weight upload).  The library stages its own pageable copies through page-locked memory (csrc/engine.h:
+# copy_h2d / copy_d2h); this raises the runtime's threshold for the pinned path (MiB) so that copies issued by OTHER code of the process -- torch moving
+# numpy arrays to the device -- take the staged path as well.  Only effective when set before the first HIP call; an explicit setting wins.
+os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1048576")
 
 AHIP_OK, AHIP_ERR_ARG, AHIP_ERR_FILE, AHIP_ERR_DEVICE, AHIP_ERR_STATE, AHIP_ERR_UNSUPPORTED = range(6)
 

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "engine.h"
@@ -219,6 +220,39 @@ int ahip_set_option(ahip_model *m, const char *key, const char *value) {
   });
 }
 
+namespace ahip {
+namespace {
+struct Staging {
+  std::mutex mu;
+  void *p = nullptr;
+  static constexpr size_t BYTES = 8u << 20;
+  void *get() {
+    if (!p) AHIP_CHECK(hipHostMalloc(&p, BYTES, hipHostMallocDefault));
+    return p;
+  }
+};
+Staging g_staging;      // process-wide, never freed (the runtime may be gone when static destructors run)
+}  // namespace
+void copy_h2d(void *dst_dev, const void *src_host, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_staging.mu);
+  char *st = (char *)g_staging.get();
+  for (size_t o = 0; o < bytes; o += Staging::BYTES) {
+    const size_t n = std::min(Staging::BYTES, bytes - o);
+    std::memcpy(st, (const char *)src_host + o, n);
+    AHIP_CHECK(hipMemcpy((char *)dst_dev + o, st, n, hipMemcpyHostToDevice));
+  }
+}
+void copy_d2h(void *dst_host, const void *src_dev, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_staging.mu);
+  char *st = (char *)g_staging.get();
+  for (size_t o = 0; o < bytes; o += Staging::BYTES) {
+    const size_t n = std::min(Staging::BYTES, bytes - o);
+    AHIP_CHECK(hipMemcpy(st, (const char *)src_dev + o, n, hipMemcpyDeviceToHost));
+    std::memcpy((char *)dst_host + o, st, n);
+  }
+}
+}  // namespace ahip
+
 // ------------------------------------------------------------------------------------ neighbor list
 static void install_list_host(ahip_model *m, int inum, int nall) {
   AHIP_CHECK(hipSetDevice(m->device));
@@ -226,9 +260,9 @@ static void install_list_host(ahip_model *m, int inum, int nall) {
   m->b_ilist.reserve(std::max<size_t>(inum, 1) * sizeof(int));
   m->b_nloff.reserve(((size_t)inum + 1) * sizeof(int));
   m->b_nlj.reserve(std::max<size_t>(nn, 1) * sizeof(int));
-  AHIP_CHECK(hipMemcpy(m->b_ilist.p, m->h_ilist.data(), (size_t)inum * sizeof(int), hipMemcpyHostToDevice));
-  AHIP_CHECK(hipMemcpy(m->b_nloff.p, m->h_off32.data(), ((size_t)inum + 1) * sizeof(int), hipMemcpyHostToDevice));
-  AHIP_CHECK(hipMemcpy(m->b_nlj.p, m->h_flat_j.data(), nn * sizeof(int), hipMemcpyHostToDevice));
+  copy_h2d(m->b_ilist.p, m->h_ilist.data(), (size_t)inum * sizeof(int));
+  copy_h2d(m->b_nloff.p, m->h_off32.data(), ((size_t)inum + 1) * sizeof(int));
+  copy_h2d(m->b_nlj.p, m->h_flat_j.data(), nn * sizeof(int));
   m->d_ilist = m->b_ilist.as<int>();
   m->d_nloff = m->b_nloff.as<int>();
   m->d_nlj = m->b_nlj.as<int>();
@@ -693,19 +727,19 @@ int ahip_get_edges(ahip_model *m, long long *nedges, long long *edge_index, doub
     AHIP_CHECK(hipSetDevice(m->device));
     AHIP_CHECK(hipDeviceSynchronize());
     std::vector<int> eii(E), ej(E), il(m->inum);
-    AHIP_CHECK(hipMemcpy(eii.data(), m->b_eii.p, E * sizeof(int), hipMemcpyDeviceToHost));
-    AHIP_CHECK(hipMemcpy(ej.data(), m->b_ej.p, E * sizeof(int), hipMemcpyDeviceToHost));
-    AHIP_CHECK(hipMemcpy(il.data(), m->d_ilist, (size_t)m->inum * sizeof(int), hipMemcpyDeviceToHost));
+    copy_d2h(eii.data(), m->b_eii.p, E * sizeof(int));
+    copy_d2h(ej.data(), m->b_ej.p, E * sizeof(int));
+    copy_d2h(il.data(), m->d_ilist, (size_t)m->inum * sizeof(int));
     if (edge_index)
       for (size_t e = 0; e < E; ++e) { edge_index[e] = il[eii[e]]; edge_index[E + e] = ej[e]; }
     if (rij) {
       if (m->edges_T_size == 8) {
         std::vector<double> r(E * 3);
-        AHIP_CHECK(hipMemcpy(r.data(), m->b_rvec.p, E * 3 * sizeof(double), hipMemcpyDeviceToHost));
+        copy_d2h(r.data(), m->b_rvec.p, E * 3 * sizeof(double));
         for (size_t e = 0; e < E; ++e) rij[e] = std::sqrt(r[3 * e] * r[3 * e] + r[3 * e + 1] * r[3 * e + 1] + r[3 * e + 2] * r[3 * e + 2]);
       } else {
         std::vector<float> r(E * 3);
-        AHIP_CHECK(hipMemcpy(r.data(), m->b_rvec.p, E * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        copy_d2h(r.data(), m->b_rvec.p, E * 3 * sizeof(float));
         for (size_t e = 0; e < E; ++e) {
           double a = r[3 * e], b = r[3 * e + 1], c = r[3 * e + 2];
           rij[e] = std::sqrt(a * a + b * b + c * c);

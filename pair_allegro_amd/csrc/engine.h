@@ -237,6 +237,13 @@ void fusedlx2_free(Model &m);
 // row is too long for the register-resident version and the caller must run the two-pass kernels.
 bool edges_build_f32(Model &m, const ComputeArgs &a);
 // waits for the counters of the last edges_build_f32 if they are still in flight (m.counts_pending) and installs them in m
+// Synchronous copies between PAGEABLE host memory and the device, staged through the library's own page-locked buffer.  Handed a pageable pointer, the
+// HIP runtime pins the range on the fly for copies above 1 MiB and caches that pinning by address; in a long-lived process the heap hands pages back to the
+// system and gets them back later (malloc trimming), the cached pinning then points at nothing, and the copy engine faults on a HOST address -- seen as an
+// intermittent "Memory access fault by GPU ... on address 0x5555..." during the weight upload of the n-th model of a process (round 4, tests -m gpu:
+// 4 of 10 full runs).  Page-locked memory of our own never takes that path.
+void copy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+void copy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 void edges_counts(Model &m);
 // longest row of a device-resident CSR list (list hand-over only: one small kernel + a 4-byte read-back)
 int edges_max_row(Model &m, int inum, const int *offsets_dev);

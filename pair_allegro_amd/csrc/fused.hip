@@ -1049,7 +1049,7 @@ static void fused_prepare(Model &m) {
   A.o_shift = mark(); for (int t = 0; t < T; ++t) w.push_back((float)h.get("shift").data[t]);
   mark();
   st.wbuf.reserve(w.size() * sizeof(float));
-  AHIP_CHECK(hipMemcpy(st.wbuf.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+  copy_h2d(st.wbuf.p, w.data(), w.size() * sizeof(float));       // staged: see engine.h
   A.wbase = st.wbuf.as<float>();
   A.wbytes = (int)(w.size() * sizeof(float));
   A.T = T; A.NL = NL; A.p = h.poly_p;
@@ -1295,7 +1295,8 @@ extern "C" int ahip_debug_fused_edges(ahip_model *mh, float *out, long long nedg
   FusedState &st = *(FusedState *)m->fused_state;
   if (!st.dbg_on || !st.dbg.p || nedges != m->nedges) return AHIP_ERR_STATE;
   if (hipDeviceSynchronize() != hipSuccess) return AHIP_ERR_DEVICE;
-  return hipMemcpy(out, st.dbg.p, (size_t)nedges * 8 * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess ? 0 : AHIP_ERR_DEVICE;
+  try { copy_d2h(out, st.dbg.p, (size_t)nedges * 8 * sizeof(float)); } catch (...) { return AHIP_ERR_DEVICE; }
+  return 0;
 }
 
 extern "C" int ahip_debug_fused_linear(int K, int N, const double *W, const float *in, float *out) {

@@ -741,7 +741,7 @@ template <int L, int UT> static void fusedlx_prepare_t(Model &m, FusedLxState &s
   A.o_shift = mark(); for (int t = 0; t < T; ++t) w.push_back((float)h.get("shift").data[t]);
   mark();
   st.wbuf.reserve(w.size() * sizeof(float));
-  AHIP_CHECK(hipMemcpy(st.wbuf.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+  copy_h2d(st.wbuf.p, w.data(), w.size() * sizeof(float));       // staged: see engine.h
   A.wbase = st.wbuf.as<float>();
   A.wbytes = (int)(w.size() * sizeof(float));
   A.T = T; A.NL = NL; A.p = h.poly_p;

@@ -29,7 +29,7 @@ template <typename T> static void upload_weights(Model &m) {
     for (size_t i = 0; i < src.size(); ++i) tmp[i] = (T)src[i];
     void *p = nullptr;
     AHIP_CHECK(hipMalloc(&p, std::max<size_t>(tmp.size(), 1) * sizeof(T)));
-    AHIP_CHECK(hipMemcpy(p, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice));
+    copy_h2d(p, tmp.data(), tmp.size() * sizeof(T));
     dw.owned.push_back(p);
     dw.w[name] = (T *)p;
   };
@@ -292,8 +292,8 @@ template <typename T> static void generic_run(Model &m, const ComputeArgs &a) {
     m.h_eoff.assign({0});
   } else {
     m.h_eoff.resize((size_t)inum + 1);
-    AHIP_CHECK(hipMemcpyAsync(m.h_eoff.data(), m.b_eoff.p, ((size_t)inum + 1) * sizeof(int), hipMemcpyDeviceToHost, a.stream));
     AHIP_CHECK(hipStreamSynchronize(a.stream));
+    copy_d2h(m.h_eoff.data(), m.b_eoff.p, ((size_t)inum + 1) * sizeof(int));
     int c = 0;
     while (c < inum) {
       int c1 = c + 1;                                         // at least one centre per chunk

@@ -194,3 +194,24 @@ def test_stage_timings_accumulate_between_reads(emu_lib, model_dir):
     assert c3["model_generic"] == 3 and set(t3) == set(t1)
     assert t3["model_generic"] > 1.5 * t1["model_generic"] * 0.5          # a sum over three calls, not the last call's value (loose: host timers)
     m.close()
+
+
+def test_host_list_larger_than_the_staging_buffer_arrives_intact(emu_lib, si_model):
+    """Pageable host arrays reach the device in chunks through the library's page-locked staging buffer (csrc/engine.h: copy_h2d, 8 MiB): a row whose only
+    in-range neighbour sits behind the first chunk boundary must still produce its edge (and nothing else)."""
+    path, cfg = si_model
+    m = capi.Model(path, 0, emu_lib)
+    n_far = 2_300_000                                     # 9.2 MB of int32 indices: two chunks
+    x = np.array([[0.0, 0.0, 0.0], [1.5, 0.0, 0.0], [100.0, 0.0, 0.0]])
+    row = np.full(n_far + 1, 2, dtype=np.int32)
+    row[-1] = 1
+    m.neigh_update_csr(3, np.array([0], dtype=np.int32), np.array([0, len(row)], dtype=np.int64), row)
+    f = np.zeros_like(x)
+    eatom = np.zeros(3)
+    m.compute(1, 2, x, np.ones(3, dtype=np.int32), np.array([0], dtype=np.int32), np.full((1, 1), cfg["r_max"]), f, eatom)
+    ei, r = m.get_edges()
+    assert ei.shape == (2, 1) and ei[0, 0] == 0 and ei[1, 0] == 1
+    np.testing.assert_allclose(r, [1.5], rtol=1e-12)
+    np.testing.assert_allclose(f[0], -f[1], atol=1e-12)       # the pair force; the far atom feels nothing
+    assert not f[2].any()
+    m.close()

@@ -19,7 +19,7 @@ DEFAULT_LIB = os.path.join(_HERE, "liballegro_hip.so")
 # of the GPU test suite died that way inside a weight upload).  The library stages its own pageable copies through page-locked memory (csrc/engine.h:
 # copy_h2d / copy_d2h); this raises the runtime's threshold for the pinned path (MiB) so that copies issued by OTHER code of the process -- torch moving
 # numpy arrays to the device -- take the staged path as well.  Only effective when set before the first HIP call; an explicit setting wins.
-os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1048576")
+os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "4095")       # MiB; the largest value that also survives a 32-bit MiB -> bytes conversion
 
 AHIP_OK, AHIP_ERR_ARG, AHIP_ERR_FILE, AHIP_ERR_DEVICE, AHIP_ERR_STATE, AHIP_ERR_UNSUPPORTED = range(6)
 

@@ -33,6 +33,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# harness-side HIP runtime default (pageable copies issued by torch take the runtime's staged path; the library stages its own): capi.harness_pinned_copy_default
+os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "4095")
 
 SI_MASS = 28.0855
 

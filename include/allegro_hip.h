@@ -96,7 +96,10 @@ int ahip_neigh_update_csr(ahip_model *m, int inum, int nall, const int *ilist,
                           const long long *offsets, const int *neigh, int neighmask);
 /* Same, CSR arrays already on the device (int32 offsets [inum+1]); no copy is made of `neigh`
  * -- the caller keeps it alive until the next update.  Synchronises the device once (the longest row is measured here: it bounds
- * every centre's degree until the next hand-over, which is what lets ahip_compute_dev* run without any device -> host read-back). */
+ * every centre's degree until the next hand-over, which is what lets ahip_compute_dev* run without any device -> host read-back).
+ * The CSR arrays MUST NOT change between hand-overs: a row that has grown past the measured bound is detected (the edge build's overflow word is
+ * inspected, without waiting, by the following calls and by every accessor) and reported as AHIP_ERR_STATE by a LATER call -- the forces of the
+ * evaluation that met it are invalid. */
 int ahip_neigh_update_dev(ahip_model *m, int inum, int nall, const int *ilist_dev,
                           const int *offsets_dev, const int *neigh_dev, long long nneigh_total);
 

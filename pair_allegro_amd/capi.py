@@ -14,12 +14,16 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "liballegro_hip.so")
-# Pageable host memory handed to hipMemcpy is pinned on the fly by the HIP runtime for copies above 1 MiB and that pinning is cached by address; after the
-# heap has returned and re-acquired pages (any long-lived process) the cache can be stale and the copy engine faults on a host address (round 4: 4 of 10 runs
-# of the GPU test suite died that way inside a weight upload).  The library stages its own pageable copies through page-locked memory (csrc/engine.h:
-# copy_h2d / copy_d2h); this raises the runtime's threshold for the pinned path (MiB) so that copies issued by OTHER code of the process -- torch moving
-# numpy arrays to the device -- take the staged path as well.  Only effective when set before the first HIP call; an explicit setting wins.
-os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "4095")       # MiB; the largest value that also survives a 32-bit MiB -> bytes conversion
+
+
+def harness_pinned_copy_default() -> None:
+    """For Python HARNESSES (tests/conftest.py, bench.py, the md workers), not for the library: torch moving large numpy arrays to the device goes
+    through the HIP runtime's pin-on-the-fly path for pageable copies above 1 MiB, whose address-keyed cache went stale in long-lived processes
+    (round 4: 4 of 10 whole-suite runs died in it).  Raising the runtime's threshold (MiB) sends those copies down its staged path.  The
+    library does not depend on this -- every pageable copy of its own is staged through page-locked memory (csrc/engine.h: copy_h2d / copy_d2h) --
+    and importing the binding no longer changes process-wide runtime behaviour.  Only effective before the first HIP call."""
+    os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "4095")       # the largest value that also survives a 32-bit MiB -> bytes conversion
+
 
 AHIP_OK, AHIP_ERR_ARG, AHIP_ERR_FILE, AHIP_ERR_DEVICE, AHIP_ERR_STATE, AHIP_ERR_UNSUPPORTED = range(6)
 

@@ -668,12 +668,12 @@ int ahip_compute_dev(ahip_model *m, int nlocal, int nghost, const double *x_dev,
       m->h_f.resize((size_t)nall * 3); m->h_eatom.resize(nall); m->h_mtype.resize(nall);
       std::vector<int> il(inum);
       double ev[7];
-      AHIP_CHECK(hipMemcpyAsync(m->h_f.data(), m->b_f.p, (size_t)nall * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-      AHIP_CHECK(hipMemcpyAsync(m->h_eatom.data(), m->b_eatom.p, (size_t)nall * sizeof(double), hipMemcpyDeviceToHost, s));
-      AHIP_CHECK(hipMemcpyAsync(m->h_mtype.data(), mtype_dev, (size_t)nall * sizeof(int), hipMemcpyDeviceToHost, s));
-      if (inum > 0) AHIP_CHECK(hipMemcpyAsync(il.data(), m->d_ilist, (size_t)inum * sizeof(int), hipMemcpyDeviceToHost, s));
-      AHIP_CHECK(hipMemcpyAsync(ev, eng_vir_dev, 7 * sizeof(double), hipMemcpyDeviceToHost, s));
       AHIP_CHECK(hipStreamSynchronize(s));
+      copy_d2h(m->h_f.data(), m->b_f.p, (size_t)nall * 3 * sizeof(double));          // pageable vectors: staged (engine.h)
+      copy_d2h(m->h_eatom.data(), m->b_eatom.p, (size_t)nall * sizeof(double));
+      copy_d2h(m->h_mtype.data(), mtype_dev, (size_t)nall * sizeof(int));
+      if (inum > 0) copy_d2h(il.data(), m->d_ilist, (size_t)inum * sizeof(int));
+      copy_d2h(ev, eng_vir_dev, 7 * sizeof(double));
       std::vector<double> ae(nall);
       const HostTensor &shift = m->hm.get("shift");
       for (int i = 0; i < nall; ++i) ae[i] = shift.data[m->h_mtype[i]];        // ghosts: no centre edges -> shift only
@@ -797,6 +797,7 @@ extern "C" int ahip_last_tile_occupancy(ahip_model *m, long long *slots_used, lo
     *slots_used = 0; *slots_total = 0;
     if (!m->d_ntiles_last || m->last_path.rfind("fused", 0) != 0) return;
     AHIP_CHECK(hipSetDevice(m->device));
+    AHIP_CHECK(hipDeviceSynchronize());        // the tile count may come from the stand-alone packing kernels on a non-blocking stream: a null-stream copy does not wait for those
     edges_counts(*m);
     int nt = 0;
     AHIP_CHECK(hipMemcpy(&nt, m->d_ntiles_last, sizeof(int), hipMemcpyDeviceToHost));

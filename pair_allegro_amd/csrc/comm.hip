@@ -377,8 +377,8 @@ extern "C" int ahip_comm_selftest(ahip_comm *h, int n, void *stream) {
   for (int i = 0; i < n; ++i) a[i] = 1000.0 * c->rank + i;
   DevBuf da, db, dr;
   da.reserve((size_t)n * 8); db.reserve((size_t)n * 8); dr.reserve(64);
-  AHIP_CHECK(hipMemcpyAsync(da.p, a.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
-  AHIP_CHECK(hipMemcpyAsync(db.p, b.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+  copy_h2d(da.p, a.data(), (size_t)n * 8);          // pageable vectors: staged (engine.h), whatever n the caller picks
+  copy_h2d(db.p, b.data(), (size_t)n * 8);
   const int next = (c->rank + 1) % c->nranks, prev = (c->rank + c->nranks - 1) % c->nranks;
   Xfer X{*c, s, {}};
   X.send(da.p, (long long)n * 8, next);
@@ -389,10 +389,10 @@ extern "C" int ahip_comm_selftest(ahip_comm *h, int n, void *stream) {
   AHIP_CHECK(hipMemcpyAsync(dr.p, red, 16, hipMemcpyHostToDevice, s));
   AHIP_CHECK(hipMemcpyAsync((char *)dr.p + 32, &imax, 4, hipMemcpyHostToDevice, s));
   if (ahip_comm_allreduce(h, dr.p, 2, 0, s) != 0 || ahip_comm_allreduce(h, (char *)dr.p + 32, 1, 1, s) != 0) return AHIP_ERR_DEVICE;
-  AHIP_CHECK(hipMemcpyAsync(b.data(), db.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
   AHIP_CHECK(hipMemcpyAsync(red, dr.p, 16, hipMemcpyDeviceToHost, s));
   AHIP_CHECK(hipMemcpyAsync(&imax, (char *)dr.p + 32, 4, hipMemcpyDeviceToHost, s));
   AHIP_CHECK(hipStreamSynchronize(s));
+  copy_d2h(b.data(), db.p, (size_t)n * 8);
   da.release(); db.release(); dr.release();
   bool ok = true;
   for (int i = 0; i < n; ++i) ok = ok && b[i] == 1000.0 * prev + i;

@@ -14,6 +14,7 @@
 // Rows longer than 128 entries raise the overflow flag and the caller re-runs the two-pass kernels.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
 #include <mutex>
 
 #include "engine.h"
@@ -315,7 +316,25 @@ __global__ void __launch_bounds__(EB_THREADS) k_build_edges(int inum, const int 
   if (tid == 0 && run_max > 0) atomicMax(maxdeg, run_max);
 }
 
-struct EdgeState { DevBuf flags, heavy, hoff, xt; int ncu = 0, occ[2] = {1, 1}; int *h_back = nullptr; hipEvent_t ev_back = nullptr, chain = nullptr; };     // h_back: pinned read-back words; ev_back: recorded behind their copy
+// h_back: pinned read-back words of the last BACK_N calls (8 ints each; [1] largest degree, [2] row-overflow flag, [3] heavy centres, [4] edge total), ev_back[k]:
+// recorded behind the copy of slot k.  A ring, so that the overflow flag of EVERY call is looked at -- for free: by the time a later call (or edges_counts)
+// comes by, the word has landed -- although no call waits for its own copy (the flag used to be read only when the row bound was unknown).
+static constexpr int BACK_N = 8;
+struct EdgeState {
+  DevBuf flags, heavy, hoff, xt; int ncu = 0, occ[2] = {1, 1};
+  int *h_back = nullptr; hipEvent_t ev_back[BACK_N] = {}, chain = nullptr; bool unchecked[BACK_N] = {}; int cur = 0;
+};
+// Looks at slot k's overflow word once its copy has completed (wait: block until it has).  A set flag means a list row was longer than the bound measured at the
+// list's hand-over: the single-pass build read only the first 64 / 128 entries of that row, the forces of that call are wrong.
+static void back_check(EdgeState &st, int k, bool wait) {
+  if (!st.unchecked[k]) return;
+  if (wait) AHIP_CHECK(hipEventSynchronize(st.ev_back[k]));
+  else if (hipEventQuery(st.ev_back[k]) != hipSuccess) return;
+  st.unchecked[k] = false;
+  if (st.h_back[8 * k + 2] != 0)
+    throw StateError("neighbor list row longer than the bound measured at its hand-over (ahip_neigh_update*): the CSR arrays handed to the library must not change "
+                     "between hand-overs; the forces of the last evaluation are invalid");
+}
 
 // ---- compact copy of the edges of the listed ("heavy") centres: the edge list the layer-at-a-time kernels run on ----
 static __global__ void k_heavy_offsets(int nh, const int *heavy, const int *eoff, int *hoff) {
@@ -353,6 +372,7 @@ int edges_max_row(Model &m, int inum, const int *offsets_dev) {
   int *out = m.b_misc.as<int>();
   AHIP_CHECK(hipMemsetAsync(out, 0, sizeof(int), nullptr));
   hipLaunchKernelGGL(k_max_row, dim3((inum + 255) / 256), dim3(256), 0, nullptr, inum, offsets_dev, out);
+  AHIP_CHECK(hipGetLastError());            // a launch that did not happen would leave the bound at 0, i.e. "every row fits"
   int h = 0;
   AHIP_CHECK(hipMemcpy(&h, out, sizeof(int), hipMemcpyDeviceToHost));
   return h;
@@ -361,8 +381,9 @@ int edges_max_row(Model &m, int inum, const int *offsets_dev) {
 void edges_counts(Model &m) {
   if (!m.counts_pending) return;
   EdgeState &st = *(EdgeState *)m.edge_state;
-  AHIP_CHECK(hipEventSynchronize(st.ev_back));       // the copy sits right behind the edge build in its stream: this does not wait for the model kernel
-  const int *h3 = st.h_back;
+  AHIP_CHECK(hipEventSynchronize(st.ev_back[st.cur]));       // the copy sits right behind the edge build in its stream: this does not wait for the model kernel
+  const int *h3 = st.h_back + 8 * st.cur;
+  back_check(st, st.cur, false);
   m.nedges = h3[4];
   m.nedges_hint = m.nedges;
   m.last_max_deg = h3[1];
@@ -400,10 +421,12 @@ bool edges_build_f32(Model &m, const ComputeArgs &a) {
     st.ncu = (hipGetDeviceProperties(&prop, m.device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&st.occ[0], k_build_edges<1, false>, EB_THREADS, 0) != hipSuccess || st.occ[0] < 1) st.occ[0] = 1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&st.occ[1], k_build_edges<2, false>, EB_THREADS, 0) != hipSuccess || st.occ[1] < 1) st.occ[1] = 1;
-    AHIP_CHECK(hipHostMalloc((void **)&st.h_back, 8 * sizeof(int), hipHostMallocDefault));
-    AHIP_CHECK(hipEventCreateWithFlags(&st.ev_back, hipEventDisableTiming));
+    AHIP_CHECK(hipHostMalloc((void **)&st.h_back, BACK_N * 8 * sizeof(int), hipHostMallocDefault));
+    std::memset(st.h_back, 0, BACK_N * 8 * sizeof(int));
+    for (int k = 0; k < BACK_N; ++k) AHIP_CHECK(hipEventCreateWithFlags(&st.ev_back[k], hipEventDisableTiming));
   }
   m.counts_pending = false;
+  for (int k = 0; k < BACK_N; ++k) back_check(st, k, false);          // earlier calls whose words have landed: no wait
   // a row of more than 128 entries cannot go through the register-resident single pass: known from the list, no launch needed to find out
   if (m.max_list_row > 128) return false;
   const bool one_chunk = m.max_list_row >= 0 && m.max_list_row <= 64;
@@ -461,16 +484,21 @@ bool edges_build_f32(Model &m, const ComputeArgs &a) {
   // (pair_nequip_allegro_kokkos.cpp:203-206); here nobody waits for the copy unless a value is needed on the host: with every row <= 128
   // entries (known since the list was installed) no row can overflow, the degree is bounded by the row length, and the kernels that follow
   // read the totals from device memory.
-  int *h3 = st.h_back;
+  st.cur = (st.cur + 1) % BACK_N;
+  back_check(st, st.cur, true);                     // the slot of BACK_N calls ago: long complete
+  int *h3 = st.h_back + 8 * st.cur;
   AHIP_CHECK(hipMemcpyAsync(h3, hdr, 5 * sizeof(int), hipMemcpyDeviceToHost, a.stream));       // ticket, max degree, overflow, heavy centres, edge total
-  AHIP_CHECK(hipEventRecord(st.ev_back, a.stream));
+  AHIP_CHECK(hipEventRecord(st.ev_back[st.cur], a.stream));
+  st.unchecked[st.cur] = true;
   m.d_maxdeg = hdr + 1;
   m.tiles_packed = m.pack_slots > 0;
   m.have_ett = true;
   m.counts_pending = true;
   if (m.max_list_row < 0) {                         // row lengths unknown (cannot happen through the C-ABI, which measures them at every list hand-over): check the overflow flag now
+    AHIP_CHECK(hipEventSynchronize(st.ev_back[st.cur]));
+    st.unchecked[st.cur] = false;                   // handled here: the caller falls back to the two-pass build
+    if (h3[2] != 0) { m.counts_pending = false; m.have_ett = false; return false; }
     edges_counts(m);
-    if (h3[2] != 0) { m.have_ett = false; return false; }
   }
   return true;
 }
@@ -483,7 +511,7 @@ void edges_free(Model &m) {
   st->heavy.release();
   st->hoff.release();
   if (st->h_back) (void)hipHostFree(st->h_back);
-  if (st->ev_back) (void)hipEventDestroy(st->ev_back);
+  for (int k = 0; k < BACK_N; ++k) if (st->ev_back[k]) (void)hipEventDestroy(st->ev_back[k]);
   if (st->chain) (void)hipEventDestroy(st->chain);
   delete st;
   m.edge_state = nullptr;

@@ -22,8 +22,9 @@ static constexpr int RING = AHIP_RING;   // weight fragments in flight per wave
 static constexpr int TCHUNK = 4;         // tiles per claim of the dynamic tile schedule
 
 // Switches that exist for timing experiments only and compute WRONG results (or drop a hazard pad) are refused outside an experiment build.
-#if (defined(ABL_NOROWS) || defined(ABL_NOW) || defined(AHIP_NO_STORE_PAD)) && !defined(AHIP_EXPERIMENT_SWITCHES)
-#error "ABL_NOROWS / ABL_NOW / AHIP_NO_STORE_PAD are timing-experiment switches (wrong results): add -DAHIP_EXPERIMENT_SWITCHES, never in the product build"
+#if (defined(ABL_NOROWS) || defined(ABL_NOW) || defined(AHIP_NO_STORE_PAD) || defined(ABL_NO_ENVSTAGE) || defined(ABL_NO_FTP) || defined(ABL_NO_LAT) || defined(ABL_NO_MIX) || \
+     defined(ABL_NOSYNC) || defined(ABL_NOREDUCE)) && !defined(AHIP_EXPERIMENT_SWITCHES)
+#error "ABL_* / AHIP_NO_STORE_PAD are timing-experiment switches (wrong results): add -DAHIP_EXPERIMENT_SWITCHES, never in the product build"
 #endif
 
 __host__ __device__ inline int feat16(int t, int r, int g) { return 16 * t + 4 * g + r; }

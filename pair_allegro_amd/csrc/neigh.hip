@@ -102,8 +102,8 @@ __global__ void k_iota(int n, int *p) {
 static void check_list_total(const int *cnt_dev, int n, int maxrow, hipStream_t s) {
   if ((long long)n * (long long)maxrow <= 2147483647LL) return;
   std::vector<int> h((size_t)n);
-  AHIP_CHECK(hipMemcpyAsync(h.data(), cnt_dev, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
   AHIP_CHECK(hipStreamSynchronize(s));
+  copy_d2h(h.data(), cnt_dev, (size_t)n * sizeof(int));          // pageable vector: staged (engine.h)
   long long tot = 0;
   for (int v : h) tot += v;
   if (tot > 2147483647LL) throw ArgError("neighbor list: more than 2^31 - 1 entries (row offsets are 32-bit, like the reference's)");

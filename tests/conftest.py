@@ -7,6 +7,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# harness-side runtime default (not the library's business): see capi.harness_pinned_copy_default
+os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "4095")
 
 
 def pytest_configure(config):

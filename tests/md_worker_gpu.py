@@ -3,6 +3,7 @@ gloo by md.HostStagedDist): the real HIP kernels under the real multi-rank sched
 import os
 import sys
 
+os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "4095")   # harness default, before torch initialises HIP (capi.harness_pinned_copy_default)
 import numpy as np
 import torch
 import torch.distributed as dist

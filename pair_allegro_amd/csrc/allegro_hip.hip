@@ -191,7 +191,7 @@ int ahip_set_option(ahip_model *m, const char *key, const char *value) {
       if (v != "model" && v != "float64") throw ArgError("option precision: expected model|float64");
       m->opt_precision = v;
     } else if (k == "fused_arith") {
-      if (v != "bf16x3" && v != "f32" && v != "tf32eq" && v != "auto") throw ArgError("option fused_arith: expected auto|f32|bf16x3|tf32eq");
+      if (v != "bf16x3" && v != "f32" && v != "tf32eq" && v != "f16x2" && v != "auto") throw ArgError("option fused_arith: expected auto|f32|f16x2|bf16x3|tf32eq");
       if (v != m->opt_fused_arith) { m->opt_fused_arith = v; fused_free(*m); }     // weight stream is rebuilt on the next compute
     } else if (k == "fused_tb") {
       if (v != "table" && v != "mlp") throw ArgError("option fused_tb: expected table|mlp");
@@ -469,7 +469,8 @@ static void run_model(ahip_model *m, const ComputeArgs &a) {
     if (m->heavy_thresh > 0) edges_counts(*m);
     if (m->nheavy > 0) heavy_generic(m, a);
     // "fused_tf32eq": the two-term bf16 split the model file licensed with allow_tf32 = 1 (fused.hip); everything else is float32-exact
-    m->last_path = m->last_fused_arith == 2 ? "fused_tf32eq" : "fused_f32";
+    // "fused_f16x2" / "fused_bf16x3": float32-equivalent splits on the f16 / bf16 matrix cores (fused_h.h, fused.hip); "fused_f32": exact fmaf chains
+    m->last_path = m->last_fused_arith == 2 ? "fused_tf32eq" : m->last_fused_arith == 3 ? "fused_f16x2" : m->last_fused_arith == 1 ? "fused_bf16x3" : "fused_f32";
     return;
   }
   edges_counts(*m);
@@ -573,6 +574,7 @@ int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const i
     }
     AHIP_CHECK(hipMemcpyAsync(ev, m->b_engvir.p, 7 * sizeof(double), hipMemcpyDeviceToHost, s));
     AHIP_CHECK(hipStreamSynchronize(s));
+    fused_poll_alarm(*m);              // the kernel has finished here: a float16-range alarm of THIS evaluation is reported by this call, before f is touched
     // scatter: f[i] += forces[i] for locals AND ghosts (pair_nequip_allegro.cpp:370-377)
     for (size_t k = 0; k < (size_t)nall * 3; ++k) f[k] += m->h_f[k];
     if (eatom)

@@ -224,6 +224,8 @@ bool fused_model_supported(const Model &m, std::string *why);
 // Returns false (and sets *why) if this particular list cannot be handled (e.g. too many edges per atom).
 bool fused_run(Model &m, const ComputeArgs &a, std::string *why);
 void fused_free(Model &m);
+// throws StateError when the f16x2 instances of k_fused have raised their range alarm (fused.hip); device-resident callers meet it at their next evaluation
+void fused_poll_alarm(Model &m);
 // the same three for the wide shapes (l_max = 2; fused_lx.hip)
 bool fusedlx_model_supported(const Model &m, std::string *why);
 bool fusedlx_run(Model &m, const ComputeArgs &a, std::string *why);

@@ -20,8 +20,9 @@
 //            an LDS staging tile [slots][128 features] and a deterministic per-atom reduction.
 //  * activations needed by the backward pass are stored as raw register images in a per-wave
 //            private scratch (written and re-read by the same wave within the same tile: Infinity-Cache traffic).
-//  * arithmetic of the linears: f32-input MFMA (default) or bf16x3 (exact 3-way bf16 split, six bf16-MFMA
-//            terms, f32 accumulate; option fused_arith).
+//  * arithmetic of the linears (option fused_arith): f32-input MFMA; f16x2 (two float16 terms per operand, three f16-MFMA
+//            products, f32 accumulate: fused_h.h); bf16x3 (exact 3-way bf16 split, six bf16-MFMA terms); tf32eq (two bf16 terms,
+//            only for model files that set allow_tf32).
 //
 // Supported model shape (others run the generic path): l_max = 1, 32 tensor features, 64 scalars,
 // MLP 2 x 64, read-out 1 x 32, <= 3 layers, <= 16 types; any number of Bessel functions and any cutoff-polynomial order (the radial basis only
@@ -34,6 +35,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "../../include/allegro_hip.h"
 #include "engine.h"
@@ -41,6 +43,7 @@
 // (1 M-atom Si: 58.3 -> 56.8 ms; 2 fragments: slower than 4)
 #define AHIP_RING 4
 #include "fused_common.h"
+#include "fused_h.h"
 #include "prims.h"
 
 // This file is compiled in two parts (Makefile; same options, halves the build time): AHIP_FUSED_PART 0 = the host side + the f32-input MFMA
@@ -91,6 +94,8 @@ struct FusedArgs {
   double *f, *eatom, *partial;            // partial [gridDim.x][7]
   long long *prof;                        // [PH_N] or unused
   float *dbg;                             // [E][8] per-edge diagnostics or null
+  float bscale, ibscale;                  // f16x2 arithmetic: the backward pass runs scaled by this power of two (fused_h.h), undone on the edge gradient
+  int *err;                               // host-mapped word: set when an edge gradient comes out non-finite (float16 range exceeded)
 };
 
 template <int NW> struct __attribute__((aligned(16))) Lds {
@@ -274,14 +279,30 @@ enum { PH_GEOM = 0, PH_TB, PH_EMB, PH_ENV, PH_TP, PH_MIX, PH_LAT, PH_OUT, PH_BLA
 
 // One weight-fragment ring per arithmetic (see linear_s / linear_b); lin<> dispatches a linear of the tile sequence to
 // the f32-input MFMA form or to the bf16x3 form (inputs are split into their three bf16 terms right here).
-// AR: arithmetic of the tile's linears: 0 = f32-input MFMA, 1 = bf16x3 (three-term split, float32-equivalent), 2 = tf32eq (two-term split)
+// AR: arithmetic of the tile's linears: 0 = f32-input MFMA, 1 = bf16x3 (three-term split, float32-equivalent), 2 = tf32eq (two-term bf16 split),
+// 3 = f16x2 (two float16 terms, float32-equivalent inside float16's exponent range: fused_h.h)
 template <int AR> struct RingT {
   f32x4 f[AR != 0 ? 1 : RING];
-  u32x4 b[AR == 0 ? 1 : (AR == 1 ? RINGB : RINGB2)];
+  u32x4 b[AR == 0 ? 1 : (AR == 1 ? RINGB : AR == 2 ? RINGB2 : RINGH)];
 };
 template <int AR, int KT, int NT, bool ACC, int RPI, class Epi>
 __device__ __forceinline__ void lin(__amdgpu_buffer_rsrc_t W, int &wp, const f32x4 (&in)[KT], f32x4 (&out)[NT], int v16, RingT<AR> &ring, Epi epi) {
-  if constexpr (AR != 0) {
+  if constexpr (AR == 3) {
+    static_assert(KT % 2 == 0, "K-steps are pairs of 16-feature tiles");
+    Hop b[1][KT / 2], unused[1][NT / 2];
+#pragma unroll
+    for (int ks = 0; ks < KT / 2; ++ks) b[0][ks] = split_pair_h(in[2 * ks], in[2 * ks + 1]);
+#ifdef AHIP_H_PKSILU        // A/B: the SiLU epilogue on register pairs (packed f32 operations)
+    if constexpr (std::is_same<Epi, EpiSiluSaveD>::value) {
+      EpiSiluSaveD2 ep[1] = {EpiSiluSaveD2{epi.S, epi.row0, epi.v16}};
+      linear_h<1, KT / 2, NT, ACC, false, (4 * RPI) % RINGH, EpiSiluSaveD2>(W, wp, b, reinterpret_cast<f32x4 (&)[1][NT]>(out), unused, v16, ring.b, ep);
+    } else
+#endif
+    {
+      Epi ep[1] = {epi};
+      linear_h<1, KT / 2, NT, ACC, false, (4 * RPI) % RINGH, Epi>(W, wp, b, reinterpret_cast<f32x4 (&)[1][NT]>(out), unused, v16, ring.b, ep);
+    }
+  } else if constexpr (AR != 0) {
     static_assert(KT % 2 == 0, "K-steps are pairs of 16-feature tiles");
     constexpr int NTERM = AR == 1 ? 3 : 2;
     Bop b[KT / 2], unused[NT / 2];
@@ -562,7 +583,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     asm volatile("" : "+v"(eps));            // computed here, not sunk to its use at the end of the tile (keeps the read-out rows alive until then)
 
     // =========================== backward ===========================
-    const float deps = valid ? lds.scale[ti] * A.cenv : 0.f;
+    // f16x2: the backward pass is linear in this upstream gradient and runs scaled by a power of two that brings it to O(1) (float16 has no exponent range to spare)
+    const float deps = valid ? lds.scale[ti] * A.cenv * (AR == 3 ? A.bscale : 1.f) : 0.f;
     f32x4 dx[4];
     f32x4 dzr[2];
 #pragma unroll
@@ -771,9 +793,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     PHASE(PH_BTB);
     // ---------------- geometry backward, outputs ----------------
     {
-      const float dfc_tot = gsum(dfc_part);
-      const float dd = dfc_tot * (dfc_dx / rc) + gsum(dd_part);
-      const float y1 = gsum(dY1), y2 = gsum(dY2), y3 = gsum(dY3);
+      const float ibs = AR == 3 ? A.ibscale : 1.f;
+      const float dfc_tot = gsum(dfc_part) * ibs;
+      const float dd = dfc_tot * (dfc_dx / rc) + gsum(dd_part) * ibs;
+      const float y1 = gsum(dY1) * ibs, y2 = gsum(dY2) * ibs, y3 = gsum(dY3) * ibs;
       const float Gx = C_S3 * y3, Gy = C_S3 * y1, Gz = C_S3 * y2;
       const float gn = Gx * nx + Gy * ny + Gz * nz;
       const float gx = dd * nx + (Gx - gn * nx) * inv;
@@ -784,6 +807,9 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         dp[0] = gx; dp[1] = gy; dp[2] = gz; dp[3] = dd; dp[4] = dfc_tot; dp[5] = y1; dp[6] = y2; dp[7] = y3;
       }
       const float m = valid ? 1.f : 0.f;
+#if !defined(ABL_NOW) && !defined(ABL_NOROWS) && !defined(ABL_NOROWLD) && !defined(ABL_NOROWST)
+      if (AR == 3 && valid && !(fabsf(gx) + fabsf(gy) + fabsf(gz) + fabsf(eps) < 3.0e38f)) *A.err = 1;      // inf / NaN: an operand left float16's range
+#endif
       if (g == 0) {
         st[0] = m * gx; st[1] = m * gy; st[2] = m * gz; st[3] = m * eps;
         if (valid) {
@@ -853,6 +879,18 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
 
 // ---------------------------------------------------------------------------- the bf16-split instances (fused_bf.o)
 void fused_launch_bf16(int nw, bool prof, int arith, bool tbt, int grid, hipStream_t s, const FusedArgs &A);
+void fused_launch_f16(int nw, bool prof, int grid, hipStream_t s, const FusedArgs &A);
+#if AHIP_FUSED_PART == 2
+// the f16x2 instances (fused_h.o): two-body table only
+void fused_launch_f16(int nw, bool prof, int grid, hipStream_t s, const FusedArgs &A) {
+#define AHIP_LAUNCH_NL(NWV, PROFV, NLV) hipLaunchKernelGGL((k_fused<NWV, PROFV, 3, true, NLV>), dim3(grid), dim3(NWV * 64), 0, s, A)
+#define AHIP_LAUNCH(NWV, PROFV) do { if (A.NL == 1) AHIP_LAUNCH_NL(NWV, PROFV, 1); else if (A.NL == 2) AHIP_LAUNCH_NL(NWV, PROFV, 2); else AHIP_LAUNCH_NL(NWV, PROFV, 3); } while (0)
+  if (prof) { if (nw == 4) AHIP_LAUNCH(4, true); else AHIP_LAUNCH(8, true); }
+  else { if (nw == 4) AHIP_LAUNCH(4, false); else AHIP_LAUNCH(8, false); }
+#undef AHIP_LAUNCH
+#undef AHIP_LAUNCH_NL
+}
+#endif
 #if AHIP_FUSED_PART == 1
 void fused_launch_bf16(int nw, bool prof, int arith, bool tbt, int grid, hipStream_t s, const FusedArgs &A) {
 #define AHIP_LAUNCH_NL(NWV, PROFV, B3V, TBV, NLV) hipLaunchKernelGGL((k_fused<NWV, PROFV, B3V, TBV, NLV>), dim3(grid), dim3(NWV * 64), 0, s, A)
@@ -875,7 +913,8 @@ struct FusedState {
   FusedArgs args;
   bool ready = false, prof_on = false, dbg_on = false, clk_on = false;
   bool tbt = true;             // two-body embedding from the spline table (default) or evaluated as an MLP (option fused_tb=mlp)
-  int arith = 0;               // 0: f32-input MFMA; 1: bf16x3 (option fused_arith=bf16x3 / AHIP_FUSED_ARITH=b3); 2: tf32eq (two-term bf16 split; fused_arith=auto picks it when the model file says allow_tf32 = 1)
+  int arith = 0;               // 0: f32-input MFMA; 1: bf16x3 (option fused_arith=bf16x3 / AHIP_FUSED_ARITH=b3); 2: tf32eq (two-term bf16 split; fused_arith=auto picks it when the model file says allow_tf32 = 1); 3: f16x2 (fused_h.h)
+  int *h_err = nullptr;        // page-locked, device-mapped: raised by the f16x2 instances when an edge gradient comes out non-finite
   DevBuf prof, dbg;
   int ncu = 256;
   int force_nw = 0;            // AHIP_FUSED_NW=4|8 pins the workgroup shape (A/B measurements)
@@ -886,11 +925,6 @@ struct FusedState {
 // column 16 (2 p + half) + i.  Terms by truncation (exact three-way split of the f32 weight).
 static inline unsigned bf16_trunc_bits(float f) { unsigned u; std::memcpy(&u, &f, 4); return u >> 16; }
 static inline float bf16_bits_to_f(unsigned h) { unsigned u = h << 16; float f; std::memcpy(&f, &u, 4); return f; }
-static void frag_dims_b(int K, int N, int &KS, int &NT) {
-  KS = (K + 31) / 32;
-  NT = (N + 15) / 16;
-  NT += NT & 1;
-}
 static int append_frag_b(std::vector<float> &out, const double *W, int K, int N, int ldw, int nterm = 3) {
   int KS, NT;
   frag_dims_b(K, N, KS, NT);
@@ -960,19 +994,25 @@ static void fused_prepare(Model &m) {
   {
     const char *ar = std::getenv("AHIP_FUSED_ARITH");
     std::string arith = ar ? ar : m.opt_fused_arith;
-    st.arith = (arith == "b3" || arith == "bf16x3") ? 1 : (arith == "tf32eq" || (arith == "auto" && h.allow_tf32)) ? 2 : 0;
+    st.arith = (arith == "b3" || arith == "bf16x3") ? 1 : (arith == "tf32eq" || (arith == "auto" && h.allow_tf32)) ? 2 : (arith == "f16x2" || arith == "auto") ? 3 : 0;
   }
   {
     const char *tb = std::getenv("AHIP_FUSED_TB");
     std::string mode = tb ? tb : m.opt_fused_tb;
     st.tbt = mode != "mlp";
   }
-  const bool b3 = st.arith != 0, tbt = st.tbt;
+  if (st.arith == 3 && !st.tbt) st.arith = 0;        // the f16x2 instances exist with the tabulated two-body embedding only
+  const bool b3 = st.arith == 1 || st.arith == 2, tbt = st.tbt;
   const int nterm = st.arith == 1 ? 3 : 2;
-  auto fwd = [&](const double *W, int K, int N) { if (b3) append_frag_b(w, W, K, N, N, nterm); else append_frag(w, W, K, N, N); };
+  bool h_range_ok = true;
+  auto fwd = [&](const double *W, int K, int N) {
+    if (st.arith == 3) h_range_ok = append_frag_h(w, W, K, N, N) && h_range_ok;
+    else if (b3) append_frag_b(w, W, K, N, N, nterm); else append_frag(w, W, K, N, N);
+  };
   auto bwd = [&](const double *W, int K, int N) {
     auto t = transpose(W, K, N);
-    if (b3) append_frag_b(w, t.data(), N, K, K, nterm); else append_frag(w, t.data(), N, K, K);
+    if (st.arith == 3) h_range_ok = append_frag_h(w, t.data(), N, K, K) && h_range_ok;
+    else if (b3) append_frag_b(w, t.data(), N, K, K, nterm); else append_frag(w, t.data(), N, K, K);
   };
   auto T_ = [&](const std::string &name) -> const double * { return h.get(name).data.data(); };
   const double *wc = w0.data.data() + (size_t)2 * T * 64;       // Bessel block [8][64]
@@ -1026,7 +1066,7 @@ static void fused_prepare(Model &m) {
     bwd(wc, 8, 64);
   }
   {   // wrap-around copy: the last linear of a tile prefetches the first fragments of the next tile
-    const size_t n = (size_t)(st.arith == 1 ? RINGB : st.arith == 2 ? RINGB2 : RING) * 256;
+    const size_t n = (size_t)(st.arith == 1 ? RINGB : st.arith == 2 ? RINGB2 : st.arith == 3 ? RINGH : RING) * 256;
     for (size_t i = 0; i < n; ++i) w.push_back(w[stream0 + i]);
   }
   // two-body embedding table (see k_fused): per type pair, cubic Hermite in d on [0, r_c(pair)] from the float64 MLP
@@ -1054,6 +1094,21 @@ static void fused_prepare(Model &m) {
   A.wbytes = (int)(w.size() * sizeof(float));
   A.T = T; A.NL = NL; A.p = h.poly_p;
   A.cenv = (float)(1.0 / std::sqrt(h.avg_num_neighbors));
+  A.bscale = A.ibscale = 1.f;
+  if (st.arith == 3) {
+    if (!h_range_ok) throw UnsupportedError("fused_arith=f16x2: a weight of this model exceeds float16's range; use fused_arith=f32");
+    // the upstream gradient of the backward pass is scale[type] / sqrt(avg_num_neighbors): a power of two brings it to O(1)
+    double smax = 0.0;
+    for (int t = 0; t < T; ++t) smax = std::max(smax, std::fabs(h.get("scale").data[t]));
+    int ex = smax > 0.0 ? -(int)std::lround(std::log2(smax * (double)A.cenv)) : 0;
+    ex = std::max(-24, std::min(24, ex));
+    A.bscale = (float)std::ldexp(1.0, ex); A.ibscale = (float)std::ldexp(1.0, -ex);
+    if (!st.h_err) {
+      AHIP_CHECK(hipHostMalloc((void **)&st.h_err, 64, hipHostMallocMapped));
+      *st.h_err = 0;
+    }
+    AHIP_CHECK(hipHostGetDevicePointer((void **)&A.err, st.h_err, 0));
+  }
   hipDeviceProp_t prop;
   AHIP_CHECK(hipGetDeviceProperties(&prop, m.device));
   st.ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1081,6 +1136,7 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
   if (m.edges_T_size != 4) { if (why) *why = "edge vectors are not float32"; return false; }
   fused_prepare(m);
   FusedState &st = *(FusedState *)m.fused_state;
+  fused_poll_alarm(m);       // raised by an EARLIER evaluation (nobody waits for the kernel): its forces were not finite
   if (st.prof_on || st.clk_on || st.dbg_on) edges_counts(m);      // instrumented runs size their buffers / reports from the counts
   int nw = 0;                                   // 0: decided on the device
   if (!m.counts_pending) {
@@ -1166,6 +1222,7 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
       // (10 648 Si atoms: 4 659 tiles on 512 workgroups = 12 instead of 10 tile times with claims of 4)
       A.tchunk = (nedges_est / (16 * shape) > (long long)g * 256) ? TCHUNK : 1;
       if (const char *tc = std::getenv("AHIP_TCHUNK")) A.tchunk = std::max(1, std::atoi(tc));       // experiments
+      if (st.arith == 3) { fused_launch_f16(shape, st.prof_on, g, s, A); continue; }                        // fused_h.o
       if (st.arith != 0) { fused_launch_bf16(shape, st.prof_on, st.arith, st.tbt, g, s, A); continue; }     // fused_bf.o
 #define AHIP_LAUNCH_NL(NWV, PROFV, TBV, NLV) hipLaunchKernelGGL((k_fused<NWV, PROFV, 0, TBV, NLV>), dim3(g), dim3(NWV * 64), 0, s, A)
 #define AHIP_LAUNCH(NWV, PROFV, TBV) do { if (A.NL == 1) AHIP_LAUNCH_NL(NWV, PROFV, TBV, 1); else if (A.NL == 2) AHIP_LAUNCH_NL(NWV, PROFV, TBV, 2); else AHIP_LAUNCH_NL(NWV, PROFV, TBV, 3); } while (0)
@@ -1219,10 +1276,21 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
   return true;
 }
 
+void fused_poll_alarm(Model &m) {
+  if (!m.fused_state) return;
+  FusedState &st = *(FusedState *)m.fused_state;
+  if (st.h_err && *(volatile int *)st.h_err != 0) {
+    *st.h_err = 0;
+    throw StateError("fused_arith=f16x2: an edge gradient was not finite (an activation left float16's range, or the input was not finite): the forces of that "
+                     "evaluation are invalid; set option fused_arith=f32 for this model");
+  }
+}
+
 void fused_free(Model &m) {
   if (!m.fused_state) return;
   FusedState *st = (FusedState *)m.fused_state;
   for (DevBuf *b : {&st->wbuf, &st->scratch, &st->seg_count, &st->seg_base, &st->tile_a0, &st->tile_e0, &st->centre, &st->ntiles, &st->partial, &st->prof, &st->dbg}) b->release();
+  if (st->h_err) (void)hipHostFree(st->h_err);
   delete st;
   m.fused_state = nullptr;
 }
@@ -1282,6 +1350,35 @@ __global__ void __launch_bounds__(128) k_selftest_linear_b(const float *Wf, int 
     }
 }
 
+template <int KS, int NT>
+__global__ void __launch_bounds__(128) k_selftest_linear_h(const float *Wf, int wbytes, const float *in, int K, float *out, int N) {
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, row = (threadIdx.x >> 6) * 16 + j;
+  f32x4 a[2 * KS], o[1][NT];
+#pragma unroll
+  for (int t = 0; t < 2 * KS; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int k = feat16(t, r, g);
+      a[t][r] = k < K ? in[row * K + k] : 0.f;
+    }
+  Hop b[1][KS], ob[1][NT / 2];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) b[0][ks] = split_pair_h(a[2 * ks], a[2 * ks + 1]);
+  __amdgpu_buffer_rsrc_t WB = __builtin_amdgcn_make_buffer_rsrc((void *)Wf, 0, wbytes, 0x00020000);
+  u32x4 ring[RINGH];
+  int wp = 0;
+  ring_prime_b(WB, wp, lane * 16, ring);
+  EpiNone ep[1];
+  linear_h<1, KS, NT, false, false, 0, EpiNone>(WB, wp, b, o, ob, lane * 16, ring, ep);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int n = feat16(t, r, g);
+      if (n < N) out[row * N + n] = o[0][t][r];
+    }
+}
+
 #endif   // AHIP_FUSED_PART == 0
 }  // namespace ahip
 
@@ -1303,12 +1400,14 @@ extern "C" int ahip_debug_fused_linear(int K, int N, const double *W, const floa
   try {
     const char *ar = std::getenv("AHIP_FUSED_ARITH");
     const int nterm = (ar && std::string(ar) == "tf32eq") ? 2 : 3;
-    const bool b3 = ar && (std::string(ar) == "b3" || std::string(ar) == "bf16x3" || std::string(ar) == "tf32eq");
+    const bool h2 = ar && std::string(ar) == "f16x2";
+    const bool b3 = h2 || (ar && (std::string(ar) == "b3" || std::string(ar) == "bf16x3" || std::string(ar) == "tf32eq"));
     std::vector<float> frag;
     int KT, NT;
-    if (b3) { append_frag_b(frag, W, K, N, N, nterm); frag_dims_b(K, N, KT, NT); }
+    if (h2) { append_frag_h(frag, W, K, N, N); frag_dims_b(K, N, KT, NT); }
+    else if (b3) { append_frag_b(frag, W, K, N, N, nterm); frag_dims_b(K, N, KT, NT); }
     else { append_frag(frag, W, K, N, N); frag_dims(K, N, KT, NT); }
-    frag.resize(frag.size() + (size_t)(RINGB2 + 2) * 256, 0.f);      // the ring prefetches past the end
+    frag.resize(frag.size() + (size_t)(RINGB + 2) * 256, 0.f);      // the ring prefetches past the end
     float *dW = nullptr, *din = nullptr, *dout = nullptr;
     AHIP_CHECK(hipMalloc((void **)&dW, frag.size() * sizeof(float)));
     AHIP_CHECK(hipMalloc((void **)&din, (size_t)32 * K * sizeof(float)));
@@ -1317,7 +1416,8 @@ extern "C" int ahip_debug_fused_linear(int K, int N, const double *W, const floa
     AHIP_CHECK(hipMemcpy(din, in, (size_t)32 * K * sizeof(float), hipMemcpyHostToDevice));
     bool ok = true;
     const int wbytes = (int)(frag.size() * sizeof(float));
-#define CASEB(ks, nt) do { if (nterm == 3) hipLaunchKernelGGL((k_selftest_linear_b<ks, nt, 3>), dim3(1), dim3(128), 0, 0, dW, wbytes, din, K, dout, N); \
+#define CASEB(ks, nt) do { if (h2) hipLaunchKernelGGL((k_selftest_linear_h<ks, nt>), dim3(1), dim3(128), 0, 0, dW, wbytes, din, K, dout, N); \
+                           else if (nterm == 3) hipLaunchKernelGGL((k_selftest_linear_b<ks, nt, 3>), dim3(1), dim3(128), 0, 0, dW, wbytes, din, K, dout, N); \
                            else hipLaunchKernelGGL((k_selftest_linear_b<ks, nt, 2>), dim3(1), dim3(128), 0, 0, dW, wbytes, din, K, dout, N); } while (0)
     if (b3) {
       if (KT == 1 && NT == 2) CASEB(1, 2);

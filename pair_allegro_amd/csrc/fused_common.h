@@ -23,7 +23,7 @@ static constexpr int TCHUNK = 4;         // tiles per claim of the dynamic tile 
 
 // Switches that exist for timing experiments only and compute WRONG results (or drop a hazard pad) are refused outside an experiment build.
 #if (defined(ABL_NOROWS) || defined(ABL_NOW) || defined(AHIP_NO_STORE_PAD) || defined(ABL_NO_ENVSTAGE) || defined(ABL_NO_FTP) || defined(ABL_NO_LAT) || defined(ABL_NO_MIX) || \
-     defined(ABL_NOSYNC) || defined(ABL_NOREDUCE)) && !defined(AHIP_EXPERIMENT_SWITCHES)
+     defined(ABL_NOSYNC) || defined(ABL_NOREDUCE) || defined(ABL_NOROWST) || defined(ABL_NOROWLD)) && !defined(AHIP_EXPERIMENT_SWITCHES)
 #error "ABL_* / AHIP_NO_STORE_PAD are timing-experiment switches (wrong results): add -DAHIP_EXPERIMENT_SWITCHES, never in the product build"
 #endif
 
@@ -47,9 +47,13 @@ __device__ __forceinline__ void pin_s(int &v) { asm volatile("" : "+s"(v)); }
 __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t, int voff, int soff) { const float q = __builtin_bit_cast(float, (voff + soff) | 0x3f000000); return f32x4{q, q, q, q}; }
 __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t, int, int, f32x4 v) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); }
 #else
+#ifdef ABL_NOROWLD   // timing experiment only (results are wrong): saved rows are stored but never loaded
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t, int voff, int soff) { const float q = __builtin_bit_cast(float, (voff + soff) | 0x3f000000); return f32x4{q, q, q, q}; }
+#else
 __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AHIP_ROW_AUX));
 }
+#endif
 // HAZARD (gfx950, found in round 4 by editing the assembly of a failing build one instruction class / region at a time, tools/asm_variant.sh):
 // a buffer_store_dwordx4 reads its 16 bytes of data AFTER it has issued; a VALU or MFMA instruction that overwrites one of the four data registers
 // in the next issue slot gets there first and the store writes the NEW value.  LLVM knows this hazard ("VMEM store of more than 8 bytes
@@ -60,12 +64,16 @@ __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, int voff, int s
 // rounds 2-3: "accumulator stores must have completed", "the bf16 instances break under two compiler options").  The s_nop below READS the
 // data registers (so nothing may overwrite them before it) and supplies the two wait states the hazard needs on gfx940+.
 // tools/store_hazard.hip reproduces it in 40 lines.
+#ifdef ABL_NOROWST    // timing experiment only (results are wrong): saved rows are loaded but never stored
+__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t, int, int, f32x4 v) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); }
+#else
 __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, int voff, int soff, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, AHIP_ROW_AUX);
 #ifndef AHIP_NO_STORE_PAD          // experiment switch (tools/store_hazard.hip, A/B timing): builds the unsafe form
   asm volatile("s_nop 1" ::"v"(v));
 #endif
 }
+#endif
 #endif
 #ifdef ABL_NOW       // timing experiment only (results are wrong): no weight-fragment traffic
 __device__ __forceinline__ f32x4 bload_w(__amdgpu_buffer_rsrc_t, int voff, int soff) { const float q = __builtin_bit_cast(float, ((voff + soff) & 0xffff) | 0x3c000000); return f32x4{q, q, q, q}; }

@@ -17,6 +17,8 @@
 // linear_h<G, ...>: G = 1 or 2 edge groups (16 slots each) of the wave share every weight fragment (two B operands, two accumulator sets per
 // fragment): the fragment stream through the 64 B/clk/CU register-return path per edge halves with G = 2.
 #pragma once
+#include <cstring>
+
 #include "fused_common.h"
 
 namespace ahip {
@@ -119,9 +121,15 @@ __device__ __forceinline__ void linear_h(__amdgpu_buffer_rsrc_t W, int &wp, cons
       for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
+#ifdef AHIP_H_ORDER          // A/B: cross / main / cross, so that the two MFMAs on one cross accumulator are 4 G instead of 2 G issues apart
+          if (m == 0) ac[g][hh] = mfma_h(a[2 + hh], in[g][ks].hi, ac[g][hh]);
+          else if (m == 2) ac[g][hh] = mfma_h(a[hh], in[g][ks].lo, ac[g][hh]);
+          else ah[g][hh] = mfma_h(a[hh], in[g][ks].hi, ah[g][hh]);
+#else
           if (m == 0) ac[g][hh] = mfma_h(a[2 + hh], in[g][ks].hi, ac[g][hh]);
           else if (m == 1) ac[g][hh] = mfma_h(a[hh], in[g][ks].lo, ac[g][hh]);
           else ah[g][hh] = mfma_h(a[hh], in[g][ks].hi, ah[g][hh]);
+#endif
           if (p > 0) {
             // the 4 G register pairs of the previous tile pair, spread over this pair's MFMAs
             const int idx = ks * MF + (m * 2 + hh) * G + g, tot = KS * MF, NE = 4 * G;
@@ -166,4 +174,43 @@ __device__ __forceinline__ void linear_h(__amdgpu_buffer_rsrc_t W, int &wp, cons
   pin_s(wp);
 }
 
+// ---- host side ----
+// K-steps (pairs of 16-feature input tiles) and output tiles (padded to even) of a [K][N] linear on the 16x16x32 matrix instructions
+static void frag_dims_b(int K, int N, int &KS, int &NT) {
+  KS = (K + 31) / 32;
+  NT = (N + 15) / 16;
+  NT += NT & 1;
+}
+// f16x2 fragments of W [K][N] (fused_h.h): per (tile pair p, K-step ks) four 1 KiB entries hi0 hi1 lo0 lo1 in append_frag_b's lane layout;
+// hi = f16(w), lo' = f16((w - hi) * 2^11), both round-to-nearest-even.  Returns false when a weight exceeds float16's range.
+static bool append_frag_h(std::vector<float> &out, const double *W, int K, int N, int ldw) {
+  int KS, NT;
+  frag_dims_b(K, N, KS, NT);
+  bool ok = true;
+  for (int p = 0; p < NT / 2; ++p)
+    for (int ks = 0; ks < KS; ++ks)
+      for (int term = 0; term < 2; ++term)
+        for (int half = 0; half < 2; ++half)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int w = 0; w < 4; ++w) {
+              unsigned word = 0;
+              for (int e = 0; e < 2; ++e) {
+                const int sl = 2 * w + e, g = lane >> 4;
+                const int k = sl < 4 ? 16 * (2 * ks) + 4 * g + sl : 16 * (2 * ks + 1) + 4 * g + (sl - 4);
+                const int n = 16 * (2 * p + half) + (lane & 15);
+                const float v = (k < K && n < N) ? (float)W[(size_t)k * ldw + n] : 0.f;
+                if (!(std::fabs(v) < 32768.f)) ok = false;
+                const _Float16 hi = (_Float16)v;
+                const _Float16 lo = (_Float16)((v - (float)hi) * H_LO_SCALE);
+                const _Float16 t = term == 0 ? hi : lo;
+                unsigned short bits;
+                std::memcpy(&bits, &t, 2);
+                word |= (unsigned)bits << (16 * e);
+              }
+              float f;
+              std::memcpy(&f, &word, 4);
+              out.push_back(f);
+            }
+  return ok;
+}
 }  // namespace ahip

@@ -29,35 +29,6 @@ __global__ void k_denorm(float *out) {
   if (lane == 0) { out[0] = c[0]; out[1] = d[0]; out[2] = e[0]; }
 }
 
-// host: f16x2 fragments of W [K][N], layout of append_frag_b with two terms
-static void append_frag_h(std::vector<float> &out, const double *W, int K, int N, int ldw) {
-  int KS, NT;
-  frag_dims_b(K, N, KS, NT);
-  for (int p = 0; p < NT / 2; ++p)
-    for (int ks = 0; ks < KS; ++ks)
-      for (int term = 0; term < 2; ++term)
-        for (int half = 0; half < 2; ++half)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int w = 0; w < 4; ++w) {
-              unsigned word = 0;
-              for (int e = 0; e < 2; ++e) {
-                const int sl = 2 * w + e, g = lane >> 4;
-                const int k = sl < 4 ? 16 * (2 * ks) + 4 * g + sl : 16 * (2 * ks + 1) + 4 * g + (sl - 4);
-                const int n = 16 * (2 * p + half) + (lane & 15);
-                const float v = (k < K && n < N) ? (float)W[(size_t)k * ldw + n] : 0.f;
-                const _Float16 hi = (_Float16)v;
-                const _Float16 lo = (_Float16)((v - (float)hi) * 2048.f);
-                unsigned short bits;
-                const _Float16 t = term == 0 ? hi : lo;
-                std::memcpy(&bits, &t, 2);
-                word |= (unsigned)bits << (16 * e);
-              }
-              float f;
-              std::memcpy(&f, &word, 4);
-              out.push_back(f);
-            }
-}
-
 // out[32][N] = in[32][K] @ W: two waves, 16 rows each, through linear_h<1>
 template <int KS, int NT>
 __global__ void __launch_bounds__(128) k_lin_h(const float *Wf, int wbytes, const float *in, int K, float *out, int N) {

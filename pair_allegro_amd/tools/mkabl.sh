@@ -8,15 +8,16 @@ obj=$1; shift
 cd "$(dirname "$0")/../csrc" || exit 1
 COMMON="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -fno-slp-vectorize -Wno-unused-function"
 case $obj in
+  fused_h)   SPEC="-DAHIP_FUSED_PART=2 -mllvm -amdgpu-use-amdgpu-trackers=1 -mllvm -disable-machine-licm -mllvm -disable-postra-machine-licm"; SRC=fused.hip ;;
   fused)     SPEC="-DAHIP_FUSED_PART=0 -mllvm -amdgpu-use-amdgpu-trackers=1 -mllvm -disable-machine-licm -mllvm -disable-postra-machine-licm" ;;
   fused_lx2|fused_lx) SPEC="-mllvm -pragma-unroll-threshold=1000000" ;;
   *) echo "unknown object $obj"; exit 1 ;;
 esac
-ALL="allegro_hip.o prims.o neigh.o edges.o gemm.o fused.o fused_bf.o fused_lx.o fused_lx2.o comm.o model_io.o"
+ALL="allegro_hip.o prims.o neigh.o edges.o gemm.o fused.o fused_bf.o fused_h.o fused_lx.o fused_lx2.o comm.o model_io.o"
 for v in "$@"; do
   name=${v%%:*}; flags=${v#*:}
   (
-    /opt/rocm/bin/hipcc $COMMON $SPEC $flags -c $obj.hip -o /tmp/abl_${name}_$obj.o 2> /tmp/abl_${name}.err || { echo "build $name failed"; head -5 /tmp/abl_${name}.err; exit 1; }
+    /opt/rocm/bin/hipcc $COMMON $SPEC $flags -c ${SRC:-$obj.hip} -o /tmp/abl_${name}_$obj.o 2> /tmp/abl_${name}.err || { echo "build $name failed"; head -5 /tmp/abl_${name}.err; exit 1; }
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../abl_$name.so ${ALL/$obj.o//tmp/abl_${name}_$obj.o} -ldl && echo "built $name"
   ) &
 done

@@ -34,7 +34,7 @@ def test_config3_li3po4_parity_vs_oracle(hip_lib, model_dir):
     names = lmp_like.LI3PO4_LAMMPS_NAMES
     ref = util.oracle_run(dict(cfg, model_dtype="float64"), w, cell, pos, types, names)
     res = util.run_pair(hip_lib, path, cell, pos, types, names)
-    assert res["info"]["path"] == "fused_f32"
+    assert res["info"]["path"] in pc.FUSED_F32EQ
     util.assert_close_to(res, ref, 5e-4, what="Li3PO4 fused vs f64 oracle")
     assert np.abs(res["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
     # 2x2x1 ranks (the config's grid): ghosts of all four LAMMPS types cross the brick faces
@@ -92,7 +92,7 @@ def test_config3_full_size_properties_100k(hip_lib, model_dir):
     cfg = model_file.model_S(type_names=["Li", "P", "O"], avg_num_neighbors=48.6)
     mapper = np.array([0, 1, 2, 2], dtype=np.int32)
     masses = [lmp_like.LI3PO4_MASSES[s] for s in cfg["type_names"]]
-    _full_size_properties(hip_lib, model_dir, cfg, cell, pos, mapper[types - 1], masses, ("fused_f32",), check_overlap=True)
+    _full_size_properties(hip_lib, model_dir, cfg, cell, pos, mapper[types - 1], masses, pc.FUSED_F32EQ, check_overlap=True)
 
 
 # ------------------------------------------------------------------------------------------------ config 5
@@ -112,7 +112,7 @@ def test_config5_water_parity_vs_oracle(hip_lib, model_dir):
     symbols = ["O" if t == 1 else "H" for t in types]
     path, cfg, w, types2, names, ref = _model_L_case(model_dir, "water_L", ["O", "H"], cell, pos, symbols)
     res = util.run_pair(hip_lib, path, cell, pos, types2, names)
-    assert res["info"]["path"] == "fused_f32"
+    assert res["info"]["path"] in pc.FUSED_F32EQ
     util.assert_close_to(res, ref, 5e-4, what="water model L vs f64 oracle")
     assert np.abs(res["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
 
@@ -122,7 +122,7 @@ def test_config5_full_size_properties_500k(hip_lib, model_dir):
     cell, pos, types = lmp_like.water(55)
     cfg = model_file.model_L(avg_num_neighbors=53.6)
     masses = [lmp_like.WATER_MASSES[s] for s in cfg["type_names"]]
-    _full_size_properties(hip_lib, model_dir, cfg, cell, pos, (types - 1).astype(np.int32), masses, ("fused_f32",),
+    _full_size_properties(hip_lib, model_dir, cfg, cell, pos, (types - 1).astype(np.int32), masses, pc.FUSED_F32EQ,
                           check_overlap=False)
 
 
@@ -203,7 +203,7 @@ def test_fused_per_edge_type_cutoffs(hip_lib, model_dir):
     ref = util.oracle_run(dict(cfg, model_dtype="float64"), w, g["cell"], g["pos"], types, names)
     for tb in ("table", "mlp"):
         res = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused", "fused_tb": tb})
-        assert res["info"]["path"] == "fused_f32"
+        assert res["info"]["path"] in pc.FUSED_F32EQ
         util.assert_close_to(res, ref, 5e-4, what=f"per-edge-type cutoffs, fused ({tb})")
         assert np.abs(res["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
     # fewer edges than with the single r_max: the filter really used the matrix
@@ -231,7 +231,7 @@ def test_tile_packing_inside_the_edge_build_equals_the_stand_alone_packing(hip_l
     path, w = _export(model_dir, f"pack_{shape}", cfg)
     a = util.run_pair(hip_lib, path, cell, pos, types, names, options={"path": "fused"})
     b = util.run_pair(hip_lib, path, cell, pos, types, names, options={"path": "fused", "tile_pack": "separate"})
-    assert a["info"]["path"] == "fused_f32" and b["info"]["path"] == "fused_f32"
+    assert a["info"]["path"] in pc.FUSED_F32EQ and b["info"]["path"] in pc.FUSED_F32EQ
     if shape == "Y":
         assert a["info"]["max_degree"] > 64                         # heavy centres exist in this box
     fs = np.abs(b["forces"]).max()
@@ -301,7 +301,7 @@ def test_device_call_with_a_changing_cutoff_matrix(hip_lib, model_dir):
     m = capi.Model(path, 0, hip_lib)
     m.neigh_update_csr(rs.nall, rs.ilist, rs.offsets, rs.flat)
     seq = [run(m, c) for c in (wide, narrow, wide, over, None)]
-    assert m.last_path == "fused_f32"
+    assert m.last_path in pc.FUSED_F32EQ
     m.close()
     fw, fn = fresh(wide), fresh(narrow)
     assert fn[2] < fw[2]

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import util
+import parity_cases as pc  # noqa: E402
 from oracle import allegro_torch
 from pair_allegro_amd import cg, model_file
 
@@ -37,7 +38,7 @@ def test_rotation_translation_permutation(hip_lib, model_dir, kind, path_opt):
     types = np.array([names.index(s) + 1 for s in g["symbols"]], dtype=np.int32)
     pos, cell = np.asarray(g["pos"]), np.asarray(g["cell"])
     a = util.run_pair(hip_lib, path, cell, pos, types, names, options={"path": path_opt})
-    assert a["info"]["path"] == ("fused_f32" if path_opt == "fused" else "generic_f32")
+    assert a["info"]["path"] in (pc.FUSED_F32EQ if path_opt == "fused" else ("generic_f32",))
     rng = np.random.default_rng(5)
     centre = pos.mean(axis=0)
     fmax = np.abs(a["forces"]).max()

@@ -11,11 +11,11 @@ from pair_allegro_amd import cg, lmp_like, model_file
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("arith", ["f32", "bf16x3", "tf32eq"])
+@pytest.mark.parametrize("arith", ["f32", "f16x2", "bf16x3", "tf32eq"])
 @pytest.mark.parametrize("K,N", [(8, 64), (32, 32), (32, 64), (64, 32), (64, 64), (96, 64), (64, 96), (64, 8)])
 def test_mfma_linear_primitive(hip_lib, K, N, arith, monkeypatch):
-    """The streamed register-chain linear, on the f32-input MFMA and on the bf16x3 split (six bf16 MFMA terms):
-    both must reproduce x @ W to float32 accuracy."""
+    """The streamed register-chain linear, on the f32-input MFMA, on the f16x2 split (two float16 terms per operand, three f16 MFMA products) and on
+    the bf16x3 split (six bf16 MFMA terms): all must reproduce x @ W to float32 accuracy."""
     monkeypatch.setenv("AHIP_FUSED_ARITH", arith)
     rng = np.random.RandomState(K * 100 + N)
     W = rng.normal(size=(K, N))                    # asymmetric: catches transposed fragments
@@ -31,7 +31,7 @@ def test_mfma_linear_primitive(hip_lib, K, N, arith, monkeypatch):
 def test_fused_golden_si64(hip_lib, model_dir, tag):
     """Committed float64 goldens of the model-S workloads (BASELINE config 1's 64-atom Si box, a 128-atom sample of config 3's Li3PO4)."""
     res, g = pc.check_golden(hip_lib, model_dir, tag, "float32", options={"path": "fused"})
-    assert res["info"]["path"] == "fused_f32"
+    assert res["info"]["path"] in pc.FUSED_F32EQ
     pc.check_edges_vs_brute_force(res, g)
 
 
@@ -54,7 +54,7 @@ def test_fused_vs_oracle_two_types(hip_lib, model_dir, nl):
     g = util.load_golden("CuPd-cubic-big_r5")
     path, cfg, types, names, ref = _model_S_case(model_dir, f"cupd_S_nl{nl}", ["Cu", "Pd"], g["symbols"], g["cell"], g["pos"], nl=nl)
     fused = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused"})
-    assert fused["info"]["path"] == "fused_f32"
+    assert fused["info"]["path"] in pc.FUSED_F32EQ
     gen = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "generic"})
     util.assert_close_to(fused, ref, 5e-4, what=f"fused vs f64 oracle nl={nl}")
     assert np.abs(fused["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
@@ -70,7 +70,7 @@ def test_fused_any_radial_basis_with_the_two_body_table(hip_lib, model_dir, nb, 
     g = util.load_golden("CuPd-cubic-big_r5")
     path, cfg, types, names, ref = _model_S_case(model_dir, f"nb{nb}_S", ["Cu", "Pd"], g["symbols"], g["cell"], g["pos"], num_bessels=nb, poly_p=p)
     res = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused"})
-    assert res["info"]["path"] == "fused_f32"
+    assert res["info"]["path"] in pc.FUSED_F32EQ
     util.assert_close_to(res, ref, 5e-4, what=f"{nb} Bessel functions, p = {p}")
     assert np.abs(res["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
     with pytest.raises(Exception, match="8 Bessel"):               # the Pair mirror re-raises the library's error as its LammpsError
@@ -97,7 +97,7 @@ def test_fused_many_species(hip_lib, model_dir, ntypes):
     types = np.array([names.index(s_) + 1 for s_ in symbols], dtype=np.int32)
     ref = util.oracle_run(dict(cfg, model_dtype="float64"), w, g["cell"], g["pos"], types, names)
     fused = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused"})
-    assert fused["info"]["path"] == "fused_f32"
+    assert fused["info"]["path"] in pc.FUSED_F32EQ
     util.assert_close_to(fused, ref, 5e-4, what=f"{ntypes} species, fused vs f64 oracle")
     assert np.abs(fused["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
 
@@ -126,11 +126,11 @@ def test_allow_tf32_selects_the_two_term_split(hip_lib, model_dir):
     assert err <= err_tf32 and err < 5e-4
     util.assert_close_to(res, ref, 5e-4, what="tf32eq vs f64 oracle (reference tolerance)")
     exact = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"fused_arith": "f32"})
-    assert exact["info"]["path"] == "fused_f32" and np.abs(exact["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
+    assert exact["info"]["path"] in pc.FUSED_F32EQ and np.abs(exact["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
     cfg0 = dict(cfg, allow_tf32=0)
     path0 = f"{model_dir}/notf32.nequip.pth"
     allegro_torch.export_nequip_pth(path0, cfg0, w)
-    assert util.run_pair(hip_lib, path0, g["cell"], g["pos"], types, names)["info"]["path"] == "fused_f32"
+    assert util.run_pair(hip_lib, path0, g["cell"], g["pos"], types, names)["info"]["path"] in pc.FUSED_F32EQ
 
 
 def test_fused_bf16x3_arithmetic_matches_f32(hip_lib, model_dir):
@@ -146,6 +146,84 @@ def test_fused_bf16x3_arithmetic_matches_f32(hip_lib, model_dir):
     assert eb3 < max(2.0 * e32, 1e-5), (eb3, e32)
     np.testing.assert_allclose(b3["forces"], f32["forces"], atol=1e-5)
     np.testing.assert_allclose(b3["pe"], f32["pe"], rtol=2e-6)
+
+
+def test_fused_f16x2_arithmetic_is_float32_equivalent(hip_lib, model_dir):
+    """fused_arith=f16x2 (csrc/fused_h.h: two float16 terms per operand, the remainder scaled by 2^11; three f16-MFMA products, f32 accumulate; the
+    backward pass scaled by a power of two) sits at the same distance from the float64 oracle as the f32-input MFMA kernel -- forces, per-atom
+    energies, virial -- on the 256-atom CuPd box (2 types) and on a model whose energy scale is 1e-4 / 1e+4 of the usual one (the backward scale at work)."""
+    g = util.load_golden("CuPd-cubic-big_r5")
+    path, cfg, types, names, ref = _model_S_case(model_dir, "cupd_S_h2", ["Cu", "Pd"], g["symbols"], g["cell"], g["pos"])
+    f32 = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused", "fused_arith": "f32"})
+    h2 = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused", "fused_arith": "f16x2"})
+    assert f32["info"]["path"] == "fused_f32" and h2["info"]["path"] == "fused_f16x2"
+    util.assert_close_to(h2, ref, 5e-4, what="fused f16x2 vs f64 oracle")
+    e32 = np.abs(f32["forces"] - ref["forces"]).max()
+    eh2 = np.abs(h2["forces"] - ref["forces"]).max()
+    print(f"max|dF| vs f64 oracle: f32 {e32:.3e}, f16x2 {eh2:.3e}")
+    assert eh2 < max(1.5 * e32, pc.F32EQ_DF), (eh2, e32)
+    np.testing.assert_allclose(h2["forces"], f32["forces"], atol=1e-5)
+    np.testing.assert_allclose(h2["pe"], f32["pe"], rtol=2e-6)
+    for sc in (1e-4, 1e4):
+        w = model_file.init_weights(cfg)
+        w["scale"] = np.asarray(w["scale"]) * sc
+        p2 = f"{model_dir}/cupd_S_h2_scale{sc:g}.nequip.pth"
+        allegro_torch.export_nequip_pth(p2, cfg, w)
+        r64 = util.oracle_run(dict(cfg, model_dtype="float64"), w, g["cell"], g["pos"], types, names)
+        a = util.run_pair(hip_lib, p2, g["cell"], g["pos"], types, names, options={"path": "fused", "fused_arith": "f32"})
+        b = util.run_pair(hip_lib, p2, g["cell"], g["pos"], types, names, options={"path": "fused", "fused_arith": "f16x2"})
+        fm = np.abs(r64["forces"]).max()
+        ea, eb = np.abs(a["forces"] - r64["forces"]).max() / fm, np.abs(b["forces"] - r64["forces"]).max() / fm
+        print(f"energy scale x{sc:g}: max|dF| / max|F| f32 {ea:.3e}, f16x2 {eb:.3e}")
+        assert eb < max(1.5 * ea, 2e-5), (sc, ea, eb)
+
+
+def test_fused_arith_auto_selection(hip_lib, model_dir):
+    """fused_arith=auto: f16x2 for a model file with allow_tf32 = 0 (float32-equivalent, named in the path), exact f32 fmaf chains on request or when the
+    two-body embedding is evaluated in the kernel (fused_tb=mlp: the f16x2 instances exist with the table only); tf32eq only for allow_tf32 = 1
+    (test_allow_tf32_selects_the_two_term_split)."""
+    g = util.load_golden("CuPd-cubic-big_r5")
+    path, cfg, types, names, ref = _model_S_case(model_dir, "cupd_S_auto", ["Cu", "Pd"], g["symbols"], g["cell"], g["pos"])
+    run = lambda opts: util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options=opts)["info"]["path"]
+    assert run({}) == pc.FUSED_S_DEFAULT == "fused_f16x2"
+    assert run({"fused_arith": "f32"}) == "fused_f32"
+    assert run({"fused_tb": "mlp"}) == "fused_f32"
+    assert run({"fused_arith": "bf16x3"}) == "fused_bf16x3"
+    assert run({"path": "generic"}) == "generic_f32"
+
+
+def test_f16x2_range_alarm(hip_lib, model_dir):
+    """float16 has no exponent range to spare: when an operand leaves it the edge gradient comes out non-finite, the kernel raises a flag in
+    host-mapped memory and the evaluation reports AHIP_ERR_STATE naming the remedy (fused_arith=f32): the host-pointer call, which waits for the
+    kernel anyway, in the same call and before it touches f; a device-resident caller at its next evaluation.  Here: latent weights blown up by 3e4;
+    fused_arith=f32 evaluates the same file."""
+    from pair_allegro_amd import capi
+    g = util.load_golden("CuPd-cubic-big_r5")
+    cfg = model_file.model_S(type_names=["Cu", "Pd"], avg_num_neighbors=40.0)
+    w = model_file.init_weights(cfg)
+    w["l1.lat.w0"] = np.asarray(w["l1.lat.w0"]) * 3e4
+    path = f"{model_dir}/h2_overflow.nequip.pth"
+    allegro_torch.export_nequip_pth(path, cfg, w)
+    names = ["Cu", "Pd"]
+    types = np.array([names.index(s_) + 1 for s_ in g["symbols"]], dtype=np.int32)
+    from pair_allegro_amd.pair import PairAllegro, atom_from_rank_system, list_from_rank_system
+    rs = lmp_like.build_rank_system(g["cell"], g["pos"], types, cfg["r_max"] + 1.0)
+    pair = PairAllegro(lib=hip_lib, quiet=True)
+    pair.settings([])
+    pair.coeff(["*", "*", path] + names, ntypes=2)
+    pair.model.set_option("path", "fused"); pair.model.set_option("fused_arith", "f16x2")
+    pair.init_style()
+    atom = atom_from_rank_system(rs, 2)
+    lst = list_from_rank_system(rs)
+    with pytest.raises(capi.AhipError) as ei:
+        pair.compute(atom, lst)
+    assert ei.value.code == capi.AHIP_ERR_STATE and "fused_arith=f32" in ei.value.msg
+    assert not atom.f.any()                       # reported before the scatter
+    pair.model.set_option("fused_arith", "f32")
+    atom.f[:] = 0.0
+    pair.compute(atom, lst)
+    assert pair.model.last_path == "fused_f32" and np.isfinite(atom.f).all()
+    pair.model.close()
 
 
 def test_fused_two_body_table_matches_mlp(hip_lib, model_dir):
@@ -175,7 +253,7 @@ def test_fused_two_lammps_types_share_a_model_type(hip_lib, model_dir):
     o_atoms = np.where(types == o_type)[0]
     types4[o_atoms[::2]] = len(names) + 1                    # every second oxygen becomes LAMMPS type 4, also named O
     split = util.run_pair(hip_lib, path, g["cell"], g["pos"], types4, names + ["O"], options={"path": "fused"})
-    assert split["info"]["path"] == "fused_f32"
+    assert split["info"]["path"] in pc.FUSED_F32EQ
     np.testing.assert_allclose(split["forces"], base["forces"], atol=1e-6)
     np.testing.assert_allclose(split["eatom"], base["eatom"], atol=1e-6)
     np.testing.assert_allclose(split["pe"], base["pe"], rtol=1e-7)
@@ -201,7 +279,7 @@ def test_fused_wide_tiles_65_to_128_neighbours(hip_lib, model_dir):
     types = np.ones(len(pos), dtype=np.int32)
     ref = util.oracle_run(dict(cfg, model_dtype="float64"), w, cell, pos, types, ["Cu"])
     res = util.run_pair(hip_lib, path, cell, pos, types, ["Cu"], options={"path": "fused"})
-    assert res["info"]["path"] == "fused_f32"
+    assert res["info"]["path"] in pc.FUSED_F32EQ
     assert 64 < res["info"]["max_degree"] <= 128
     util.assert_close_to(res, ref, 5e-4, what="wide-tile fused vs f64 oracle")
     assert np.abs(res["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
@@ -223,7 +301,7 @@ def test_compute_allegro_outputs_on_the_fused_path(hip_lib, model_dir):
     rs = lmp_like.build_rank_system(g["cell"], g["pos"], types, 6.0)
     atom = atom_from_rank_system(rs, len(names))
     pair.compute(atom, list_from_rank_system(rs))
-    assert pair.model.last_path == "fused_f32"
+    assert pair.model.last_path in pc.FUSED_F32EQ
     arr = cf.compute_peratom(rs.nlocal, rs.nall).copy()
     np.add.at(arr, rs.tag[rs.nlocal:] - 1, cf.pack_reverse_comm(rs.nghost, rs.nlocal).reshape(-1, 3))
     forces = np.zeros_like(ref["forces"])
@@ -275,7 +353,7 @@ def test_full_size_properties_10k(hip_lib, model_dir):
     cell, pos, types = lmp_like.diamond_si(11)
     a = util.run_pair(hip_lib, path, cell, pos, types, ["Si"], options={"path": "fused"})
     b = util.run_pair(hip_lib, path, cell, pos, types, ["Si"], options={"path": "generic"})
-    assert a["info"]["path"] == "fused_f32" and b["info"]["path"] == "generic_f32"
+    assert a["info"]["path"] in pc.FUSED_F32EQ and b["info"]["path"] == "generic_f32"
     assert np.abs(a["forces"].sum(0)).max() < 1e-6 * len(pos) ** 0.5
     np.testing.assert_allclose(a["eatom"].sum(), a["pe"], rtol=1e-10)
     assert np.abs(a["forces"] - b["forces"]).max() < 5e-5

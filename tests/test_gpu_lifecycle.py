@@ -9,6 +9,7 @@ same inputs (same kernels, so the tolerance is the float64 atomics' arrival orde
 import numpy as np
 import pytest
 
+import parity_cases as pc  # noqa: E402
 import util
 from oracle import allegro_torch
 from pair_allegro_amd import lmp_like, model_file
@@ -98,11 +99,11 @@ def test_one_pair_object_through_growing_shrinking_and_denser_systems(hip_lib, m
     w = model_file.init_weights(cfg)
     path = f"{model_dir}/lifecycle_S.nequip.pth"
     allegro_torch.export_nequip_pth(path, cfg, w)
-    seq = [("small", 3, 1.0, "fused_f32"), ("grown", 5, 1.0, "fused_f32"), ("empty", 0, 0, None), ("small again", 3, 1.0, "fused_f32"),
-           ("rows > 64", 3, 0.86, "fused_f32"), ("degree > 64", 3, 0.74, "fused_f32"), ("degrees around 64", 3, 0.748, "fused_f32"), ("degree > 128", 3, 0.55, "generic_f32"),
-           ("plain after fallback", 4, 1.0, "fused_f32"), ("degree > 64 again", 4, 0.74, "fused_f32")]
+    seq = [("small", 3, 1.0, pc.FUSED_S_DEFAULT), ("grown", 5, 1.0, pc.FUSED_S_DEFAULT), ("empty", 0, 0, None), ("small again", 3, 1.0, pc.FUSED_S_DEFAULT),
+           ("rows > 64", 3, 0.86, pc.FUSED_S_DEFAULT), ("degree > 64", 3, 0.74, pc.FUSED_S_DEFAULT), ("degrees around 64", 3, 0.748, pc.FUSED_S_DEFAULT), ("degree > 128", 3, 0.55, "generic_f32"),
+           ("plain after fallback", 4, 1.0, pc.FUSED_S_DEFAULT), ("degree > 64 again", 4, 0.74, pc.FUSED_S_DEFAULT)]
     seen = _run_sequence(hip_lib, path, cfg, ["Si"], seq, {})
-    assert seen.count("fused_f32") == 8 and seen.count("generic_f32") == 1
+    assert seen.count(pc.FUSED_S_DEFAULT) == 8 and seen.count("generic_f32") == 1
 
 
 def test_one_pair_object_with_heavy_centres_coming_and_going(hip_lib, model_dir):

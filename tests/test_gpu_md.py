@@ -7,6 +7,7 @@ import pytest
 import torch
 
 import util
+import parity_cases as pc  # noqa: E402
 from pair_allegro_amd import capi, lmp_like, md, model_file
 
 pytestmark = pytest.mark.gpu
@@ -65,7 +66,7 @@ def test_nve_energy_conservation(hip_lib, model_dir, path, overlap):
     assert t0["ke"] > 0.03 * n * 0.9           # ~ 3/2 kT per atom
     assert drift < 2e-4 * n * 0.0388, (drift, e0)   # << thermal energy (f32 forces, dt = 1 fs)
     assert abs(t["pe"] - t0["pe"]) > 1e-3      # the system actually evolved
-    assert model.last_path == ("fused_f32" if path == "fused" else "generic_f32")
+    assert model.last_path in (pc.FUSED_F32EQ if path == "fused" else ("generic_f32",))
     model.close()
 
 
@@ -80,7 +81,7 @@ def test_full_size_properties_1M(hip_lib, model_dir):
     dev = torch.device("cuda", 0)
     sim = md.Simulation(md.HipBackend(model, [MASS]), np.diag(cell), cfg["r_max"], 1.0, pos, np.zeros(n, np.int32), None, dev, overlap=False)
     sim.setup()
-    assert model.last_path == "fused_f32"
+    assert model.last_path in pc.FUSED_F32EQ
     ei, _ = model.get_edges()
     assert ei.shape[1] == 28 * n
     f = sim.f[: sim.nlocal].clone()
@@ -114,7 +115,7 @@ def test_multi_rank_on_one_gpu(hip_lib, model_dir, tmp_path, world, port):
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
     z = np.load(out)
-    assert str(z["used"]) == "fused_f32" and str(z["used1"]) == "fused_f32"
+    assert str(z["used"]) in pc.FUSED_F32EQ and str(z["used1"]) in pc.FUSED_F32EQ
     assert 0 < int(z["nint"]) < int(z["nloc"])                      # rank 0 has both interior and boundary centres
     for k in ("2", "3"):                                            # overlapped, serial
         assert np.abs(z["f" + k] - z["f1"]).max() < 2e-5            # float32 kernels, different summation order per decomposition
@@ -149,7 +150,7 @@ def test_bench_two_ranks_on_one_gpu(launcher):
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2
     assert d["metric"] == "atom_steps_per_sec" and d["value"] > 0 and d["higher_is_better"] is True
     assert abs(d["value"] - 10648 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-3 * d["value"]        # whole-job atoms / max-over-ranks time
-    assert d["config"]["grid"] == "2x1x1" and d["config"]["kernel_path"] == "fused_f32"
+    assert d["config"]["grid"] == "2x1x1" and d["config"]["kernel_path"] in pc.FUSED_F32EQ
     assert d["config"]["comm_transport"].startswith("library/")
     # the N > 1 line carries the exchange's device time and the max-over-ranks stage times
     assert d["config"]["comm_ms"] > 0 and d["config"]["stage_ms"]["model_fused"] >= d["config"]["stage_ms_rank0"]["model_fused"] - 1e-3

@@ -72,7 +72,7 @@ def _soak(hip_lib, model_dir, name, cfg, cell, pos, mtype, masses, options, expe
 
 @pytest.mark.parametrize("layers", [2, 3])
 @pytest.mark.parametrize("arith,expect,tol", [("f32", "fused_f32", pc.NORTH_STAR_DF), ("tf32eq", "fused_tf32eq", 2e-3),
-                                             ("bf16x3", "fused_f32", pc.NORTH_STAR_DF)])
+                                             ("bf16x3", "fused_bf16x3", pc.NORTH_STAR_DF), ("f16x2", "fused_f16x2", pc.F32EQ_DF)])
 def test_soak_k_fused(hip_lib, model_dir, arith, expect, tol, layers):
     """10 648-atom Si box (BASELINE configs[1] geometry), model S with 2 / 3 layers, every arithmetic of k_fused."""
     cell, pos, types = lmp_like.diamond_si(11)

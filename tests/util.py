@@ -177,3 +177,84 @@ class tf32_emulation:
         import torch
         torch.Tensor.__matmul__, torch.einsum = self._orig
         return False
+
+
+# ---- the split arithmetics of k_fused, emulated on the torch oracle (csrc/fused_h.h, csrc/fused.hip: linear_b) ----
+class split_emulation:
+    """Context manager: inside it every `a @ b` and every two-operand `torch.einsum` of an EAGER float32 module is evaluated the way the fused
+    kernel's linears evaluate it, forward and (through a custom autograd function) backward, with float32 accumulation:
+      "f16x2"  -- v = hi + 2^-11 lo', hi = f16(v), lo' = f16((v - hi) 2^11), both round-to-nearest; product = hi hi + 2^-11 (hi lo' + lo' hi)
+      "bf16x3" -- v = hi + mid + lo by truncation to bf16; the six products of weight >= 2^-16
+      "f32"    -- nothing changed (the yardstick)
+    What this pins on the CPU is the claim that the splits are float32-EQUIVALENT for the model: same distance from the float64 oracle."""
+
+    def __init__(self, mode):
+        assert mode in ("f32", "f16x2", "bf16x3")
+        self.mode = mode
+
+    @staticmethod
+    def f16_terms(t):
+        import torch
+        hi = t.to(torch.float16).to(torch.float32)
+        lo = ((t - hi) * 2048.0).to(torch.float16).to(torch.float32) / 2048.0
+        return hi, lo
+
+    @staticmethod
+    def bf16_terms(t):
+        import torch
+        tr = lambda q: (q.contiguous().view(torch.int32) & ~0xFFFF).view(torch.float32)
+        hi = tr(t); r = t - hi; mid = tr(r); lo = tr(r - mid)
+        return hi, mid, lo
+
+    def contract(self, f, a, b):
+        if self.mode == "f16x2":
+            ah, al = self.f16_terms(a); bh, bl = self.f16_terms(b)
+            return f(ah, bh) + (f(ah, bl) + f(al, bh))
+        if self.mode == "bf16x3":
+            a0, a1, a2 = self.bf16_terms(a); b0, b1, b2 = self.bf16_terms(b)
+            return ((f(a2, b0) + f(a1, b1) + f(a0, b2)) + (f(a1, b0) + f(a0, b1))) + f(a0, b0)
+        return f(a, b)
+
+    def __enter__(self):
+        import torch
+        orig_mm, orig_es = torch.Tensor.__matmul__, torch.einsum
+        self._orig = (orig_mm, orig_es)
+        me = self
+
+        class _Contract(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, eq, a, b):
+                ctx.eq = eq
+                ctx.save_for_backward(a, b)
+                return me.contract((lambda x, y: orig_es(eq, x, y)) if eq else orig_mm, a, b)
+
+            @staticmethod
+            def backward(ctx, g):
+                a, b = ctx.saved_tensors
+                g = g.contiguous()
+
+                def vjp(wrt_a):          # (gradient term, other-operand term) -> the contraction that yields the gradient w.r.t. one operand
+                    def f(gt, ot):
+                        v = (a if wrt_a else b).detach().clone().requires_grad_(True)
+                        with torch.enable_grad():
+                            out = (orig_es(ctx.eq, v, ot) if wrt_a else orig_es(ctx.eq, ot, v)) if ctx.eq else (orig_mm(v, ot) if wrt_a else orig_mm(ot, v))
+                        return torch.autograd.grad(out, v, gt)[0]
+                    return f
+                return None, me.contract(vjp(True), g, b), me.contract(vjp(False), g, a)
+
+        def mm(a, b):
+            return _Contract.apply("", a, b) if a.dtype == torch.float32 else orig_mm(a, b)
+
+        def es(eq, *ops):
+            if len(ops) == 2 and ops[0].dtype == torch.float32:
+                return _Contract.apply(eq, ops[0], ops[1])
+            return orig_es(eq, *ops)
+
+        torch.Tensor.__matmul__ = mm
+        torch.einsum = es
+        return self
+
+    def __exit__(self, *exc):
+        import torch
+        torch.Tensor.__matmul__, torch.einsum = self._orig
+        return False

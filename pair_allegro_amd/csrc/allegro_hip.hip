@@ -129,10 +129,30 @@ int ahip_model_load(const char *path, int device, ahip_model **out) {
   });
 }
 
+namespace ahip {
+int *alarm_word(Model &m) {
+  if (!m.h_alarm) {
+    AHIP_CHECK(hipHostMalloc((void **)&m.h_alarm, 64, hipHostMallocMapped));
+    *m.h_alarm = 0;
+  }
+  int *d = nullptr;
+  AHIP_CHECK(hipHostGetDevicePointer((void **)&d, m.h_alarm, 0));
+  return d;
+}
+void fused_poll_alarm(Model &m) {
+  if (m.h_alarm && *(volatile int *)m.h_alarm != 0) {
+    *m.h_alarm = 0;
+    throw StateError("fused_arith=f16x2: an edge gradient was not finite (an activation left float16's range, or the input was not finite): the forces of that "
+                     "evaluation are invalid; set option fused_arith=f32 for this model");
+  }
+}
+}  // namespace ahip
+
 void ahip_model_free(ahip_model *m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
+  if (m->h_alarm) { (void)hipHostFree(m->h_alarm); m->h_alarm = nullptr; }
   fused_free(*m);
   fusedlx_free(*m);
   fusedlx2_free(*m);
@@ -192,7 +212,7 @@ int ahip_set_option(ahip_model *m, const char *key, const char *value) {
       m->opt_precision = v;
     } else if (k == "fused_arith") {
       if (v != "bf16x3" && v != "f32" && v != "tf32eq" && v != "f16x2" && v != "auto") throw ArgError("option fused_arith: expected auto|f32|f16x2|bf16x3|tf32eq");
-      if (v != m->opt_fused_arith) { m->opt_fused_arith = v; fused_free(*m); }     // weight stream is rebuilt on the next compute
+      if (v != m->opt_fused_arith) { m->opt_fused_arith = v; fused_free(*m); fusedlx_free(*m); fusedlx2_free(*m); }     // weight streams are rebuilt on the next compute
     } else if (k == "fused_tb") {
       if (v != "table" && v != "mlp") throw ArgError("option fused_tb: expected table|mlp");
       if (v != m->opt_fused_tb) { m->opt_fused_tb = v; fused_free(*m); }

@@ -6,6 +6,9 @@
 #include <atomic>
 #include <map>
 #include <stdexcept>
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -171,6 +174,7 @@ struct Model {
   PrimScratch prim;
 
   // fused path private state (fused.hip: model S shape; fused_lx.hip: l_max = 2 shapes)
+  int *h_alarm = nullptr;                    // page-locked, device-mapped word raised by the f16x2 instances of the fused kernels (fused_h.h): see alarm_word()
   void *fused_state = nullptr;
   void *fusedlx_state = nullptr;
   void *fusedlx2_state = nullptr;            // wave-pair version of the 64-feature shape (fused_lx2.hip)
@@ -224,8 +228,24 @@ bool fused_model_supported(const Model &m, std::string *why);
 // Returns false (and sets *why) if this particular list cannot be handled (e.g. too many edges per atom).
 bool fused_run(Model &m, const ComputeArgs &a, std::string *why);
 void fused_free(Model &m);
-// throws StateError when the f16x2 instances of k_fused have raised their range alarm (fused.hip); device-resident callers meet it at their next evaluation
+// f16x2 arithmetic (fused_h.h): device address of the model's alarm word (allocated on first use); fused_poll_alarm throws StateError when a kernel has
+// raised it -- the host-pointer call polls behind its own synchronisation, device-resident callers meet it at their next evaluation
+int *alarm_word(Model &m);
 void fused_poll_alarm(Model &m);
+// arithmetic of the wide fused kernels' linears from option fused_arith: 3 = f16x2 (auto, f16x2), 0 = f32-input MFMA (f32; the bf16 splits exist in k_fused only)
+inline int lx_arith_of(const Model &m) {
+  const char *ar = std::getenv("AHIP_FUSED_ARITH");
+  const std::string a = ar ? ar : m.opt_fused_arith;
+  return (a == "auto" || a == "f16x2") ? 3 : 0;
+}
+// power of two that brings the backward pass's upstream gradient scale[type] / sqrt(avg_num_neighbors) to O(1) (f16x2 arithmetic)
+inline int backward_scale_exponent(const HostModel &h) {
+  double smax = 0.0;
+  for (int t = 0; t < h.num_types; ++t) smax = std::max(smax, std::fabs(h.get("scale").data[t]));
+  const double up = smax / std::sqrt(h.avg_num_neighbors);
+  const int ex = up > 0.0 ? -(int)std::lround(std::log2(up)) : 0;
+  return std::max(-24, std::min(24, ex));
+}
 // the same three for the wide shapes (l_max = 2; fused_lx.hip)
 bool fusedlx_model_supported(const Model &m, std::string *why);
 bool fusedlx_run(Model &m, const ComputeArgs &a, std::string *why);

@@ -914,7 +914,6 @@ struct FusedState {
   bool ready = false, prof_on = false, dbg_on = false, clk_on = false;
   bool tbt = true;             // two-body embedding from the spline table (default) or evaluated as an MLP (option fused_tb=mlp)
   int arith = 0;               // 0: f32-input MFMA; 1: bf16x3 (option fused_arith=bf16x3 / AHIP_FUSED_ARITH=b3); 2: tf32eq (two-term bf16 split; fused_arith=auto picks it when the model file says allow_tf32 = 1); 3: f16x2 (fused_h.h)
-  int *h_err = nullptr;        // page-locked, device-mapped: raised by the f16x2 instances when an edge gradient comes out non-finite
   DevBuf prof, dbg;
   int ncu = 256;
   int force_nw = 0;            // AHIP_FUSED_NW=4|8 pins the workgroup shape (A/B measurements)
@@ -1097,17 +1096,9 @@ static void fused_prepare(Model &m) {
   A.bscale = A.ibscale = 1.f;
   if (st.arith == 3) {
     if (!h_range_ok) throw UnsupportedError("fused_arith=f16x2: a weight of this model exceeds float16's range; use fused_arith=f32");
-    // the upstream gradient of the backward pass is scale[type] / sqrt(avg_num_neighbors): a power of two brings it to O(1)
-    double smax = 0.0;
-    for (int t = 0; t < T; ++t) smax = std::max(smax, std::fabs(h.get("scale").data[t]));
-    int ex = smax > 0.0 ? -(int)std::lround(std::log2(smax * (double)A.cenv)) : 0;
-    ex = std::max(-24, std::min(24, ex));
+    const int ex = backward_scale_exponent(h);       // the upstream gradient of the backward pass is scale[type] / sqrt(avg_num_neighbors)
     A.bscale = (float)std::ldexp(1.0, ex); A.ibscale = (float)std::ldexp(1.0, -ex);
-    if (!st.h_err) {
-      AHIP_CHECK(hipHostMalloc((void **)&st.h_err, 64, hipHostMallocMapped));
-      *st.h_err = 0;
-    }
-    AHIP_CHECK(hipHostGetDevicePointer((void **)&A.err, st.h_err, 0));
+    A.err = alarm_word(m);
   }
   hipDeviceProp_t prop;
   AHIP_CHECK(hipGetDeviceProperties(&prop, m.device));
@@ -1276,21 +1267,10 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
   return true;
 }
 
-void fused_poll_alarm(Model &m) {
-  if (!m.fused_state) return;
-  FusedState &st = *(FusedState *)m.fused_state;
-  if (st.h_err && *(volatile int *)st.h_err != 0) {
-    *st.h_err = 0;
-    throw StateError("fused_arith=f16x2: an edge gradient was not finite (an activation left float16's range, or the input was not finite): the forces of that "
-                     "evaluation are invalid; set option fused_arith=f32 for this model");
-  }
-}
-
 void fused_free(Model &m) {
   if (!m.fused_state) return;
   FusedState *st = (FusedState *)m.fused_state;
   for (DevBuf *b : {&st->wbuf, &st->scratch, &st->seg_count, &st->seg_base, &st->tile_a0, &st->tile_e0, &st->centre, &st->ntiles, &st->partial, &st->prof, &st->dbg}) b->release();
-  if (st->h_err) (void)hipHostFree(st->h_err);
   delete st;
   m.fused_state = nullptr;
 }

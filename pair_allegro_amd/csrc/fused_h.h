@@ -52,6 +52,14 @@ __device__ __forceinline__ Hop split_pair_h(const f32x4 &t0, const f32x4 &t1) {
   return b;
 }
 
+// first RINGH fragments of the stream at wp into the ring
+__device__ __forceinline__ void ring_prime_h(__amdgpu_buffer_rsrc_t W, int wp, int v16, u32x4 (&ring)[RINGH]) {
+  int wo = wp * 4;
+  pin_s(wo);
+#pragma unroll
+  for (int j = 0; j < RINGH; ++j) ring[j] = __builtin_bit_cast(u32x4, bload_w(W, v16 + (j & 3) * 1024, wo + (j >> 2) * 4096));
+}
+
 // Epilogue functors may process the two values of a register pair at once (apply2: packed f32 VALU operations); the others go value by value.
 template <class E> __device__ __forceinline__ auto epi_apply2(E &e, int ot, int r, f32x2 v, int) -> decltype(e.apply2(ot, r, v)) { return e.apply2(ot, r, v); }
 template <class E> __device__ __forceinline__ f32x2 epi_apply2(E &e, int ot, int r, f32x2 v, long) { return f32x2{e.apply(ot, r, v[0]), e.apply(ot, r + 1, v[1])}; }

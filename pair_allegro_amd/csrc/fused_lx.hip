@@ -109,8 +109,8 @@ __device__ __forceinline__ void reduce_stage_x(const float *stg, const int *aoff
 // saved as the next layer's V_in) or V[lm] <- V[lm] @ M_l^T (+ ds on the scalar row: backward).  With 32 tensor features a row
 // is 2 x 2 tiles = 4 weight fragments = half a ring: rows alternate the ring phase, and the last (ninth) row is zero-padded on
 // the host to 8 fragments so that the stream stays ring-aligned.
-template <int LM, int D, int UT, bool FWD>
-__device__ __forceinline__ void mix_rows(float (&V)[D][UT][4], __amdgpu_buffer_rsrc_t WB, int &wp, int v16, f32x4 (&ring)[RING],
+template <int LM, int D, int UT, bool FWD, int AR>
+__device__ __forceinline__ void mix_rows(float (&V)[D][UT][4], __amdgpu_buffer_rsrc_t WB, int &wp, int v16, LxRing<AR> &ring,
                                          __amdgpu_buffer_rsrc_t SB, int row0, const f32x4 (&ds)[UT]) {
   if constexpr (LM < D) {
     constexpr bool PADDED = (UT == 2) && (LM == D - 1) && (D % 2 == 1);
@@ -119,12 +119,12 @@ __device__ __forceinline__ void mix_rows(float (&V)[D][UT][4], __amdgpu_buffer_r
     f32x4 vi[UT], o[NTO];
 #pragma unroll
     for (int t = 0; t < UT; ++t) vi[t] = acc_get4(V[LM][t]);
-    if constexpr (FWD) linear_s<UT, NTO, false, RP>(WB, wp, vi, o, v16, ring, EpiSaveN<UT>{SB, row0 + LM * UT, v16});
-    else linear_s<UT, NTO, false, RP>(WB, wp, vi, o, v16, ring, EpiNone{});
+    if constexpr (FWD) lx_lin<AR, UT, NTO, false, RP>(WB, wp, vi, o, v16, ring, EpiSaveN<UT>{SB, row0 + LM * UT, v16});
+    else lx_lin<AR, UT, NTO, false, RP>(WB, wp, vi, o, v16, ring, EpiNone{});
 #pragma unroll
     for (int t = 0; t < UT; ++t) acc_put4(V[LM][t], (!FWD && LM == 0) ? o[t] + ds[t] : o[t]);
     __builtin_amdgcn_sched_barrier(0);
-    mix_rows<LM + 1, D, UT, FWD>(V, WB, wp, v16, ring, SB, row0, ds);
+    mix_rows<LM + 1, D, UT, FWD, AR>(V, WB, wp, v16, ring, SB, row0, ds);
   }
 }
 
@@ -134,7 +134,7 @@ enum { PX_GEOM = 0, PX_EMB, PX_ENV, PX_TP, PX_LAT, PX_MIX, PX_OUT, PX_BLAT, PX_B
 // ---------------------------------------------------------------------------- the kernel
 // NLT = number of layers: the layer loops are unrolled so that `last layer` / `first layer` are compile-time facts -- with
 // run-time branches inside them the register allocator shuffles dozens of spill slots at every join (load, wait, store).
-template <int L, int UT, int NW, int NLT, bool PROF>
+template <int L, int UT, int NW, int NLT, bool PROF, int AR>
 __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
   using S = ShapeX<L, UT, NW>;
   constexpr int NTHREADS = NW * 64, D = S::D, U = S::U, EW = S::EW, MAXA = S::MAXA, STG_LD = S::STG_LD, ENVA = S::ENVA, NP = S::NP;
@@ -161,9 +161,9 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
     for (int k = 0; k < PX_N; ++k) pacc[k] = 0;
     tprev = clock64();
   }
-  f32x4 ring[RING];
+  LxRing<AR> ring;
   int wp = A.o_stream;
-  ring_prime(WB, wp, v16, ring);
+  lx_prime<AR>(WB, wp, v16, ring);
   if (tid < MAXA) lds.eacc[tid] = 0.0;
   if (lane < 6) lds.virw[wave][lane] = 0.0;
   if (tid < A.T * A.T) lds.rc[tid] = (float)A.rcut[tid];
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
     // ---------------- two-body embedding x0(d; type pair) from the spline table ----------------
     f32x4 x[4];
     {
-      ring_prime(WB, wp, v16, ring);        // RING_DROP: not carried through the finish / geometry phases of the tile boundary either
+      lx_prime<AR>(WB, wp, v16, ring);        // RING_DROP: not carried through the finish / geometry phases of the tile boundary either
       const float tb_invh = (float)A.tb_nk / rc;
       const float sft = d * tb_invh;
       const int kq = min((int)sft, A.tb_nk - 1);
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
     float V[D][UT][4];       // the edge tensor, forward; its gradient, backward: parked in AGPRs (acc_park)
     {
       f32x4 w0[EW];
-      linear_s<4, EW, false, 0>(WB, wp, x, w0, v16, ring, EpiSave{SB, S::R_W0, v16});
+      lx_lin<AR, 4, EW, false>(WB, wp, x, w0, v16, ring, EpiSave{SB, S::R_W0, v16});
 #pragma unroll
       for (int lm = 0; lm < D; ++lm)
 #pragma unroll
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
       float *const envk = lds.env[kk];
       {
         f32x4 om[EW];
-        linear_s<4, EW, false, 0>(WB, wp, x, om, v16, ring, EpiSave{SB, RL + S::O_OM, v16});
+        lx_lin<AR, 4, EW, false>(WB, wp, x, om, v16, ring, EpiSave{SB, RL + S::O_OM, v16});
         // environment sum over the centre's edges, one K-tile at a time through the double-buffered stage
 #ifndef ABL_NO_ENVSTAGE
 #pragma unroll
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
               f32x2 vin[D], out[D];
 #pragma unroll
               for (int lm = 0; lm < D; ++lm) vin[lm] = acc_get2(V[lm][t], h);
-              if (t == UT - 1 && h == 1) ring_prime(WB, wp, v16, ring);      // see RING_DROP below
+              if (t == UT - 1 && h == 1) lx_prime<AR>(WB, wp, v16, ring);      // see RING_DROP below
               tp_fwd_x<L, false, U>(vin, en + 16 * t + 2 * h, tp + 16 * t + 2 * h, out);
 #pragma unroll
               for (int lm = 0; lm < D; ++lm) acc_put2(V[lm][t], h, out[lm]);
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
               f32x2 vin[D], out[1];
 #pragma unroll
               for (int lm = 0; lm < D; ++lm) vin[lm] = acc_get2(V[lm][t], h);
-              if (t == UT - 1 && h == 1) ring_prime(WB, wp, v16, ring);
+              if (t == UT - 1 && h == 1) lx_prime<AR>(WB, wp, v16, ring);
               tp_fwd_x<L, true, U>(vin, en + 16 * t + 2 * h, tp + 16 * t + 2 * h, out);
               set_half(sc[t], h, out[0]);
               __builtin_amdgcn_sched_barrier(0);
@@ -340,11 +340,11 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
         for (int t = 0; t < 4; ++t) cat[t] = x[t];
 #pragma unroll
         for (int t = 0; t < UT; ++t) cat[4 + t] = sc[t];
-        linear_s<4 + UT, 4, false, 0>(WB, wp, cat, z, v16, ring, EpiSiluSaveD{SB, RL + S::O_Z1, v16});
-        linear_s<4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, RL + S::O_Z2, v16});
+        lx_lin<AR, 4 + UT, 4, false>(WB, wp, cat, z, v16, ring, EpiSiluSaveD{SB, RL + S::O_Z1, v16});
+        lx_lin<AR, 4, 4, false>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, RL + S::O_Z2, v16});
         const float ra = lds.res[kk][0], rbf = lds.res[kk][1] * fc;
         f32x4 xn[4];
-        linear_s<4, 4, false, 0>(WB, wp, z2, xn, v16, ring, EpiResidual<4>{{SB, RL + S::O_U, v16}, x, ra, rbf});
+        lx_lin<AR, 4, 4, false>(WB, wp, z2, xn, v16, ring, EpiResidual<4>{{SB, RL + S::O_U, v16}, x, ra, rbf});
 #pragma unroll
         for (int t = 0; t < 4; ++t) x[t] = xn[t];
       }
@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
       PHASEX(PX_LAT);
       // channel mixing, in place per (l, m) row -> V^{kk+1}, saved as the next layer's V_in rows
 #ifndef ABL_NO_MIX
-      if (!last) mix_rows<0, D, UT, true>(V, WB, wp, v16, ring, SB, S::R_LAYER(kk + 1) + S::O_VIN, sc);
+      if (!last) mix_rows<0, D, UT, true, AR>(V, WB, wp, v16, ring, SB, S::R_LAYER(kk + 1) + S::O_VIN, sc);
 #endif
       PHASEX(PX_MIX);
     }
@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
     load_rows<4>(SB, S::R_LAYER(NL - 1) + S::O_Z2, zt, v16);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 zr[2];
-    linear_s<4, 2, false, 0>(WB, wp, x, zr, v16, ring, EpiNone{});
+    lx_lin<AR, 4, 2, false>(WB, wp, x, zr, v16, ring, EpiNone{});
     f32x4 wo1[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) wo1[t] = *(const f32x4 *)(Wb + A.o_out1 + 16 * t + 4 * g);
@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
     pin(eps);
 
     // =========================== backward ===========================
-    const float deps = valid ? lds.scale[ti] * A.cenv : 0.f;
+    const float deps = valid ? lds.scale[ti] * A.cenv * (AR == 3 ? A.bscale : 1.f) : 0.f;      // f16x2: the backward pass runs scaled by a power of two (fused_h.h)
     f32x4 dx[4];
     {
       f32x4 dzr[2];
@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dzr[t][r] = deps * wo1[t][r] * dsilu1(zr[t][r]);
-      linear_s<2, 4, false, 0>(WB, wp, dzr, dx, v16, ring, EpiNone{});
+      lx_lin<AR, 2, 4, false>(WB, wp, dzr, dx, v16, ring, EpiNone{});
     }
     float dfc_part = 0.f;
     float dY[D];
@@ -417,10 +417,10 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
           dfc_part += rb * hsum4(accv);
           pin(dfc_part);
         }
-        linear_s<4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt});
-        linear_s<4, 4, false, 0>(WB, wp, dh, du, v16, ring, EpiMulRows<4>{rows1});
+        lx_lin<AR, 4, 4, false>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt});
+        lx_lin<AR, 4, 4, false>(WB, wp, dh, du, v16, ring, EpiMulRows<4>{rows1});
         f32x4 dcat[4 + UT];
-        linear_s<4, 4 + UT, false, 0>(WB, wp, du, dcat, v16, ring, EpiNone{});
+        lx_lin<AR, 4, 4 + UT, false>(WB, wp, du, dcat, v16, ring, EpiNone{});
 #pragma unroll
         for (int t = 0; t < 4; ++t) dx[t] += dcat[t];
 #pragma unroll
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
       }
       PHASEX(PX_BLAT);
       // mix^T in place per (l, m) row: V holds dE/dV^{kk+1}, becomes dE/dV' (tensor-product output gradient)
-      if (!last) mix_rows<0, D, UT, false>(V, WB, wp, v16, ring, SB, 0, ds);
+      if (!last) mix_rows<0, D, UT, false, AR>(V, WB, wp, v16, ring, SB, 0, ds);
       PHASEX(PX_BMIX);
       // tensor-product gradient in place per K-tile; the per-edge environment gradient goes through the stage
       {
@@ -529,14 +529,14 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
           for (int lm = 1; lm < D; ++lm) pin(dY[lm]);        // see pin(): keeps the sums where they are computed
           __builtin_amdgcn_sched_barrier(0);
         }
-        ring_prime(WB, wp, v16, ring);          // RING_DROP: requested again only now -- the d omega / dY arithmetic above needs the registers
+        lx_prime<AR>(WB, wp, v16, ring);          // RING_DROP: requested again only now -- the d omega / dY arithmetic above needs the registers
         // next iteration's u / silu'(z2) rows (or the l >= 1 embedding weights for the last step) under this linear
         if (kk > 0) {
           load_rows<4>(SB, S::R_LAYER(kk - 1) + S::O_U, upre, v16);
           load_rows<4>(SB, S::R_LAYER(kk - 1) + S::O_Z2, zt, v16);
         } else load_rows<L * UT>(SB, S::R_W0 + UT, w0pre, v16);
         __builtin_amdgcn_sched_barrier(0);
-        linear_s<EW, 4, true, 0>(WB, wp, dom, dx, v16, ring, EpiNone{});
+        lx_lin<AR, EW, 4, true>(WB, wp, dom, dx, v16, ring, EpiNone{});
       }
       PHASEX(PX_BENV);
     }
@@ -563,7 +563,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
         for (int lm = 1; lm < D; ++lm) pin(dY[lm]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      linear_s<EW, 4, true, 0>(WB, wp, dw0, dx, v16, ring, EpiNone{});
+      lx_lin<AR, EW, 4, true>(WB, wp, dw0, dx, v16, ring, EpiNone{});
       wp = A.o_stream;                                                     // last linear of the tile (wrap-around copy follows it)
     }
     PHASEX(PX_BEMB);
@@ -580,11 +580,12 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
     }
     // ---------------- geometry backward, outputs ----------------
     {
-      const float dfc_tot = gsum(dfc_part);
-      const float dd = dfc_tot * (dfc_dx / rc) + gsum(dd_part);
+      const float ibs = AR == 3 ? A.ibscale : 1.f;
+      const float dfc_tot = gsum(dfc_part) * ibs;
+      const float dd = dfc_tot * (dfc_dx / rc) + gsum(dd_part) * ibs;
       float yv[D];
 #pragma unroll
-      for (int lm = 1; lm < D; ++lm) yv[lm] = gsum(dY[lm]);
+      for (int lm = 1; lm < D; ++lm) yv[lm] = gsum(dY[lm]) * ibs;
       // G = sum_lm dE/dY_lm * dY_lm/dn (n treated as a free vector), then projected onto the sphere
       float Gx = C3 * yv[3], Gy = C3 * yv[1], Gz = C3 * yv[2];
       if constexpr (L >= 2) {
@@ -597,6 +598,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
       const float gy = dd * ny + (Gy - gn * ny) * inv;
       const float gz = dd * nz + (Gz - gn * nz) * inv;
       const float m = valid ? 1.f : 0.f;
+      if (AR == 3 && valid && !(fabsf(gx) + fabsf(gy) + fabsf(gz) + fabsf(eps) < 3.0e38f)) *A.err = 1;      // inf / NaN: an operand left float16's range
       float *const st = lds.stage[0] + s * STG_LD;
       if (g == 0) {
         st[0] = m * gx; st[1] = m * gy; st[2] = m * gz; st[3] = m * eps;
@@ -677,8 +679,14 @@ template <int L, int UT> static void fusedlx_prepare_t(Model &m, FusedLxState &s
   std::memset(&A, 0, sizeof(A));
   auto mark = [&]() { while (w.size() % 64) w.push_back(0.f); return (int)w.size(); };
   auto T_ = [&](const std::string &name) -> const double * { return h.get(name).data.data(); };
-  auto fwd = [&](const double *W, int K, int N) { append_frag(w, W, K, N, N); };
-  auto bwd = [&](const double *W, int K, int N) { auto t = transpose(W, K, N); append_frag(w, t.data(), N, K, K); };
+  st.arith = lx_arith_of(m);
+  bool h_range_ok = true;
+  auto frag = [&](const double *W, int K, int N, int ldw) {
+    if (st.arith == 3) h_range_ok = append_frag_h(w, W, K, N, ldw) && h_range_ok;
+    else append_frag(w, W, K, N, ldw);
+  };
+  auto fwd = [&](const double *W, int K, int N) { frag(W, K, N, N); };
+  auto bwd = [&](const double *W, int K, int N) { auto t = transpose(W, K, N); frag(t.data(), N, K, K); };
   // one channel-mixing row; with 32 features the last row is padded to 64 output columns (8 fragments, see mix_rows)
   auto mixfrag = [&](const double *Wl, int lm, bool transposed) {
     std::vector<double> m2((size_t)U * U);
@@ -688,8 +696,8 @@ template <int L, int UT> static void fusedlx_prepare_t(Model &m, FusedLxState &s
       std::vector<double> pad((size_t)U * 2 * U, 0.0);
       for (int a = 0; a < U; ++a)
         for (int b = 0; b < U; ++b) pad[(size_t)a * 2 * U + b] = m2[(size_t)a * U + b];
-      append_frag(w, pad.data(), U, 2 * U, 2 * U);
-    } else append_frag(w, m2.data(), U, U, U);
+      frag(pad.data(), U, 2 * U, 2 * U);
+    } else frag(m2.data(), U, U, U);
   };
   // ---- the weight stream, in the order one tile consumes it (see k_fused_lx) ----
   A.o_stream = mark();
@@ -746,6 +754,13 @@ template <int L, int UT> static void fusedlx_prepare_t(Model &m, FusedLxState &s
   A.wbytes = (int)(w.size() * sizeof(float));
   A.T = T; A.NL = NL; A.p = h.poly_p;
   A.cenv = (float)(1.0 / std::sqrt(h.avg_num_neighbors));
+  A.bscale = A.ibscale = 1.f;
+  if (st.arith == 3) {
+    if (!h_range_ok) throw UnsupportedError("fused_arith=f16x2: a weight of this model exceeds float16's range; use fused_arith=f32");
+    const int ex = backward_scale_exponent(h);
+    A.bscale = (float)std::ldexp(1.0, ex); A.ibscale = (float)std::ldexp(1.0, -ex);
+    A.err = alarm_word(m);
+  }
   A.wave_scratch = (long long)S::R_TOTAL(NL) * ROW;
 }
 
@@ -784,6 +799,8 @@ bool fusedlx_run(Model &m, const ComputeArgs &a, std::string *why) {
   }
   fusedlx_prepare(m);
   FusedLxState &st = *(FusedLxState *)m.fusedlx_state;
+  fused_poll_alarm(m);       // raised by an EARLIER evaluation (nobody waits for the kernel): its forces were not finite
+  m.last_fused_arith = st.arith;
   hipStream_t s = a.stream;
   const int inum = m.inum;
   const int maxa = ShapeX<2, 4, NW>::MAXA;
@@ -800,7 +817,8 @@ bool fusedlx_run(Model &m, const ComputeArgs &a, std::string *why) {
   A.f = a.f; A.eatom = a.eatom; A.partial = st.partial.as<double>();
   {
     StageTimer tm(m, "model_fused", s);
-#define LX_LAUNCH(UTV, NLV, PROFV) hipLaunchKernelGGL((k_fused_lx<2, UTV, NW, NLV, PROFV>), dim3(grid), dim3(NW * 64), 0, s, A)
+#define LX_LAUNCH(UTV, NLV, PROFV) do { if (st.arith == 3) hipLaunchKernelGGL((k_fused_lx<2, UTV, NW, NLV, PROFV, 3>), dim3(grid), dim3(NW * 64), 0, s, A); \
+                                        else hipLaunchKernelGGL((k_fused_lx<2, UTV, NW, NLV, PROFV, 0>), dim3(grid), dim3(NW * 64), 0, s, A); } while (0)
 #define LX_LAUNCH_NL(UTV) do { if (A.NL == 3) LX_LAUNCH(UTV, 3, false); else if (A.NL == 2) LX_LAUNCH(UTV, 2, false); else LX_LAUNCH(UTV, 1, false); } while (0)
     if (st.prof_on && A.NL == 3) {
       AHIP_CHECK(hipMemsetAsync(st.prof.p, 0, 64 * sizeof(long long), s));

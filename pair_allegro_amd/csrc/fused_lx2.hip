@@ -170,8 +170,8 @@ template <int NT> __device__ __forceinline__ void x_swap(const Xch &X, int &xb, 
 //   V[lm][own] <- ([V[lm][own], V[lm][partner's]] @ M_l)[own]   (forward: the output rows are saved as the next layer's V_in)
 //   V[lm][own] <- the same with M_l^T (+ ds on the scalar row)  (backward)
 // Row lm + 1 is handed over before row lm's MFMAs are issued, so the partner's images are in LDS when the next barrier falls.
-template <int LM, bool FWD>
-__device__ __forceinline__ void mix_rows_p(float (&V)[9][2][4], __amdgpu_buffer_rsrc_t WB, int &wp, f32x4 (&ring)[RING],
+template <int LM, bool FWD, int AR>
+__device__ __forceinline__ void mix_rows_p(float (&V)[9][2][4], __amdgpu_buffer_rsrc_t WB, int &wp, LxRing<AR> &ring,
                                            __amdgpu_buffer_rsrc_t SB, int row0, const f32x4 (&ds)[2], const Xch &X, int &xb) {
   if constexpr (LM < 9) {
     f32x4 in[4], o[2];
@@ -192,12 +192,12 @@ __device__ __forceinline__ void mix_rows_p(float (&V)[9][2][4], __amdgpu_buffer_
       x_send<2>(X, xb, nx);
     }
     const int v16 = fresh_lane() << 4;
-    if constexpr (FWD) linear_s<4, 2, false, 0>(WB, wp, in, o, v16, ring, EpiSaveN<2>{SB, row0 + LM * 2, v16});
-    else linear_s<4, 2, false, 0>(WB, wp, in, o, v16, ring, EpiNone{});
+    if constexpr (FWD) lx_lin<AR, 4, 2, false>(WB, wp, in, o, v16, ring, EpiSaveN<2>{SB, row0 + LM * 2, v16});
+    else lx_lin<AR, 4, 2, false>(WB, wp, in, o, v16, ring, EpiNone{});
 #pragma unroll
     for (int t = 0; t < 2; ++t) acc_put4(V[LM][t], (!FWD && LM == 0) ? o[t] + ds[t] : o[t]);
     __builtin_amdgcn_sched_barrier(0);
-    mix_rows_p<LM + 1, FWD>(V, WB, wp, ring, SB, row0, ds, X, xb);
+    mix_rows_p<LM + 1, FWD, AR>(V, WB, wp, ring, SB, row0, ds, X, xb);
   }
 }
 
@@ -205,7 +205,7 @@ enum { PP_GEOM = 0, PP_EMB, PP_ENV, PP_TP, PP_LAT, PP_MIX, PP_OUT, PP_BLAT, PP_B
 #define PHASEP(id) do { if (PROF) { long long _t = clock64(); pacc[id] += _t - tprev; tprev = _t; } } while (0)
 
 // ---------------------------------------------------------------------------- the kernel
-template <int NLT, bool PROF>
+template <int NLT, bool PROF, int AR>
 __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
   using S = ShapeP;
   constexpr int NTHREADS = 512, D = S::D, U = S::U, HT = S::HT, EWH = S::EWH, MAXA = S::MAXA, STG_LD = S::STG_LD, ENVA = S::ENVA, NP = S::NP, L = S::L;
@@ -236,10 +236,10 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
     for (int k = 0; k < PP_N; ++k) pacc[k] = 0;
     tprev = clock64();
   }
-  f32x4 ring[RING];
+  LxRing<AR> ring;
   const int wp0 = hf ? A.o_stream_hi : A.o_stream;
   int wp = wp0;
-  ring_prime(WB, wp, V16(), ring);
+  lx_prime<AR>(WB, wp, V16(), ring);
   if (tid < MAXA) lds.eacc[tid] = 0.0;
   if (tid < 4) lds.zero16[tid] = 0.f;
   if (hf == 0 && lane < 6) lds.virw[q][lane] = 0.0;
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
     // ---------------- two-body embedding x0(d; type pair) from the spline table; local tile k = global tile (k + 2 hf) & 3 ----------------
     f32x4 x[4];
     {
-      ring_prime(WB, wp, V16(), ring);        // the ring is not carried through the finish / geometry phases of the tile boundary
+      lx_prime<AR>(WB, wp, V16(), ring);        // the ring is not carried through the finish / geometry phases of the tile boundary
       const float tb_invh = (float)A.tb_nk / rc;
       const float sft = d * tb_invh;
       const int kq = min((int)sft, A.tb_nk - 1);
@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
     float V[D][HT][4];       // own half of the edge tensor, forward; of its gradient, backward: parked in AGPRs (acc_park)
     {
       f32x4 w0[EWH];
-      linear_s<4, EWH, false, 0>(WB, wp, x, w0, V16(), ring, EpiSave{SB, S::R_W0, V16()});
+      lx_lin<AR, 4, EWH, false>(WB, wp, x, w0, V16(), ring, EpiSave{SB, S::R_W0, V16()});
 #pragma unroll
       for (int lm = 0; lm < D; ++lm)
 #pragma unroll
@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
       float *const envk = lds.env[kk];
       {
         f32x4 om[EWH];
-        linear_s<4, EWH, false, 0>(WB, wp, x, om, V16(), ring, EpiSave{SB, RL + S::O_OM, V16()});
+        lx_lin<AR, 4, EWH, false>(WB, wp, x, om, V16(), ring, EpiSave{SB, RL + S::O_OM, V16()});
         // environment sum over the centre's edges: both halves stage one own K-tile, all waves reduce both
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
               f32x2 vin[D], out[D];
 #pragma unroll
               for (int lm = 0; lm < D; ++lm) vin[lm] = acc_get2(V[lm][t], h);
-              if (t == HT - 1 && h == 1) ring_prime(WB, wp, V16(), ring);
+              if (t == HT - 1 && h == 1) lx_prime<AR>(WB, wp, V16(), ring);
               f32x2 ee[D];
 #pragma unroll
               for (int lm = 0; lm < D; ++lm) ee[lm] = *(const f32x2 *)(en + 16 * t + 2 * h + lm * U);
@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
               f32x2 vin[D], out[1];
 #pragma unroll
               for (int lm = 0; lm < D; ++lm) vin[lm] = acc_get2(V[lm][t], h);
-              if (t == HT - 1 && h == 1) ring_prime(WB, wp, V16(), ring);
+              if (t == HT - 1 && h == 1) lx_prime<AR>(WB, wp, V16(), ring);
               f32x2 ee[D];
 #pragma unroll
               for (int lm = 0; lm < D; ++lm) ee[lm] = *(const f32x2 *)(en + 16 * t + 2 * h + lm * U);
@@ -418,21 +418,21 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
         for (int t = 0; t < 4; ++t) cat[t] = x[t];
         x_swap<2>(X, xb, sc, pr);
         cat[4] = sc[0]; cat[5] = sc[1]; cat[6] = pr[0]; cat[7] = pr[1];
-        linear_s<8, 2, false, 0>(WB, wp, cat, z, V16(), ring, EpiSiluSaveD{SB, RL + S::O_Z1, V16()});
+        lx_lin<AR, 8, 2, false>(WB, wp, cat, z, V16(), ring, EpiSiluSaveD{SB, RL + S::O_Z1, V16()});
         x_swap<2>(X, xb, z, pr);
         zin[0] = z[0]; zin[1] = z[1]; zin[2] = pr[0]; zin[3] = pr[1];
-        linear_s<4, 2, false, 0>(WB, wp, zin, z2, V16(), ring, EpiSiluSaveD{SB, RL + S::O_Z2, V16()});
+        lx_lin<AR, 4, 2, false>(WB, wp, zin, z2, V16(), ring, EpiSiluSaveD{SB, RL + S::O_Z2, V16()});
         x_swap<2>(X, xb, z2, pr);
         zin[0] = z2[0]; zin[1] = z2[1]; zin[2] = pr[0]; zin[3] = pr[1];
         const float ra = lds.res[kk][0], rbf = lds.res[kk][1] * fc;
         f32x4 xo[2] = {x[0], x[1]};
-        linear_s<4, 2, false, 0>(WB, wp, zin, xn, V16(), ring, EpiResidual<2>{{SB, RL + S::O_U, V16()}, xo, ra, rbf});
+        lx_lin<AR, 4, 2, false>(WB, wp, zin, xn, V16(), ring, EpiResidual<2>{{SB, RL + S::O_U, V16()}, xo, ra, rbf});
         x_swap<2>(X, xb, xn, pr);
         x[0] = xn[0]; x[1] = xn[1]; x[2] = pr[0]; x[3] = pr[1];
       }
       PHASEP(PP_LAT);
       // channel mixing, in place per (l, m) row -> V^{kk+1}, saved as the next layer's V_in rows
-      if (!last) mix_rows_p<0, true>(V, WB, wp, ring, SB, S::R_LAYER(kk + 1) + S::O_VIN, sc, X, xb);
+      if (!last) mix_rows_p<0, true, AR>(V, WB, wp, ring, SB, S::R_LAYER(kk + 1) + S::O_VIN, sc, X, xb);
       PHASEP(PP_MIX);
     }
 
@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
     load_rows<2>(SB, S::R_LAYER(NL - 1) + S::O_Z2, zt, V16());
     __builtin_amdgcn_sched_barrier(0);
     f32x4 zr[2];
-    linear_s<4, 2, false, 0>(WB, wp, x, zr, V16(), ring, EpiNone{});
+    lx_lin<AR, 4, 2, false>(WB, wp, x, zr, V16(), ring, EpiNone{});
     f32x4 wo1[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) wo1[t] = *(const f32x4 *)(Wb + A.o_out1 + 16 * t + 4 * g);
@@ -455,7 +455,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
     pin(eps);
 
     // =========================== backward ===========================
-    const float deps = valid ? lds.scale[ti] * A.cenv : 0.f;
+    const float deps = valid ? lds.scale[ti] * A.cenv * (AR == 3 ? A.bscale : 1.f) : 0.f;      // f16x2: the backward pass runs scaled by a power of two (fused_h.h)
     f32x4 dx[4];             // dE/dx, all 64 features, own tiles first (replicated in the pair)
     {
       f32x4 dzr[2];
@@ -463,7 +463,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dzr[t][r] = deps * wo1[t][r] * dsilu1(zr[t][r]);
-      linear_s<2, 4, false, 0>(WB, wp, dzr, dx, V16(), ring, EpiNone{});
+      lx_lin<AR, 2, 4, false>(WB, wp, dzr, dx, V16(), ring, EpiNone{});
     }
     float dfc_part = 0.f;    // partial sums over the own channels / own latent tiles: they meet in lds.ych at the end of the tile
     float dY[D];
@@ -493,20 +493,20 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
           dfc_part += rb * hsum4(accv);
           pin(dfc_part);
         }
-        linear_s<4, 2, false, 0>(WB, wp, du, dh, V16(), ring, EpiMulRows<2>{zt});
+        lx_lin<AR, 4, 2, false>(WB, wp, du, dh, V16(), ring, EpiMulRows<2>{zt});
         x_swap<2>(X, xb, dh, pr);
         din[0] = dh[0]; din[1] = dh[1]; din[2] = pr[0]; din[3] = pr[1];
-        linear_s<4, 2, false, 0>(WB, wp, din, dh, V16(), ring, EpiMulRows<2>{rows1});
+        lx_lin<AR, 4, 2, false>(WB, wp, din, dh, V16(), ring, EpiMulRows<2>{rows1});
         x_swap<2>(X, xb, dh, pr);
         din[0] = dh[0]; din[1] = dh[1]; din[2] = pr[0]; din[3] = pr[1];
         f32x4 dcat[4];       // own x tiles (2), own scalar tiles (2)
-        linear_s<4, 4, false, 0>(WB, wp, din, dcat, V16(), ring, EpiNone{});
+        lx_lin<AR, 4, 4, false>(WB, wp, din, dcat, V16(), ring, EpiNone{});
         P[0] += dcat[0]; P[1] += dcat[1];
         ds[0] = dcat[2]; ds[1] = dcat[3];
       }
       PHASEP(PP_BLAT);
       // mix^T in place per (l, m) row: V holds dE/dV^{kk+1}, becomes dE/dV' (tensor-product output gradient)
-      if (!last) mix_rows_p<0, false>(V, WB, wp, ring, SB, 0, ds, X, xb);
+      if (!last) mix_rows_p<0, false, AR>(V, WB, wp, ring, SB, 0, ds, X, xb);
       PHASEP(PP_BMIX);
       // tensor-product gradient in place per own K-tile; the per-edge environment gradient goes through the stage
       {
@@ -616,13 +616,13 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
           for (int lm = 1; lm < D; ++lm) pin(dY[lm]);
           __builtin_amdgcn_sched_barrier(0);
         }
-        ring_prime(WB, wp, V16(), ring);
+        lx_prime<AR>(WB, wp, V16(), ring);
         if (kk > 0) {
           load_rows<2>(SB, S::R_LAYER(kk - 1) + S::O_U, upre, V16());
           load_rows<2>(SB, S::R_LAYER(kk - 1) + S::O_Z2, zt, V16());
         } else load_rows<L * HT>(SB, S::R_W0 + HT, w0pre, V16());
         __builtin_amdgcn_sched_barrier(0);
-        linear_s<EWH, 4, true, 0>(WB, wp, dom, P, V16(), ring, EpiNone{});      // split by input tile: partial sums over the own channels
+        lx_lin<AR, EWH, 4, true>(WB, wp, dom, P, V16(), ring, EpiNone{});      // split by input tile: partial sums over the own channels
       }
       if (kk > 0) {
         // dE/dx^{kk-1} = P + P(partner): reduce-scatter (each wave completes its own two tiles), then all-gather
@@ -661,7 +661,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
         for (int lm = 1; lm < D; ++lm) pin(dY[lm]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      linear_s<EWH, 4, true, 0>(WB, wp, dw0, dx, V16(), ring, EpiNone{});
+      lx_lin<AR, EWH, 4, true>(WB, wp, dw0, dx, V16(), ring, EpiNone{});
       wp = wp0;                                                            // last linear of the tile (wrap-around copy follows it)
     }
     PHASEP(PP_BEMB);
@@ -694,6 +694,12 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
         yv[1] += y0[0]; yv[2] += y0[1]; yv[3] += y0[2]; yv[4] += y0[3];
         yv[5] += y1[0]; yv[6] += y1[1]; yv[7] += y1[2]; yv[8] += y1[3];
         dfc_tot += y2[0]; dd_tot += y2[1];
+        if (AR == 3) {
+          const float ibs = A.ibscale;
+          dfc_tot *= ibs; dd_tot *= ibs;
+#pragma unroll
+          for (int lm = 1; lm < D; ++lm) yv[lm] *= ibs;
+        }
         const float dd = dfc_tot * (dfc_dx / rc) + dd_tot;
         // G = sum_lm dE/dY_lm * dY_lm/dn (n treated as a free vector), then projected onto the sphere
         float Gx = C3 * yv[3], Gy = C3 * yv[1], Gz = C3 * yv[2];
@@ -705,6 +711,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
         const float gy = dd * ny + (Gy - gn * ny) * inv;
         const float gz = dd * nz + (Gz - gn * nz) * inv;
         const float m = valid ? 1.f : 0.f;
+        if (AR == 3 && valid && !(fabsf(gx) + fabsf(gy) + fabsf(gz) + fabsf(eps) < 3.0e38f)) *A.err = 1;      // inf / NaN: an operand left float16's range
         float *const st = lds.stage[0] + s * STG_LD;
         if (g == 0) {
           st[0] = m * gx; st[1] = m * gy; st[2] = m * gz; st[3] = m * eps;
@@ -787,6 +794,8 @@ static void fusedlx2_prepare(Model &m) {
   std::memset(&A, 0, sizeof(A));
   auto mark = [&]() { while (w.size() % 64) w.push_back(0.f); return (int)w.size(); };
   auto T_ = [&](const std::string &name) -> const double * { return h.get(name).data.data(); };
+  st.arith = lx_arith_of(m);
+  bool h_range_ok = true;
   // ---- one weight stream per wave half, in the order a tile consumes it (see k_fused_lx2) ----
   for (int hf = 0; hf < 2; ++hf) {
     auto own = [&](int t) { return 2 * hf + t; };
@@ -802,7 +811,8 @@ static void fusedlx2_prepare(Model &m) {
     const std::vector<int> cat_cols = {own(0), own(1), 4 + own(0), 4 + own(1)};
     auto put = [&](const double *W, int ldw, const std::vector<int> &rt, const std::vector<int> &ct) {
       auto sub = gather_tiles(W, ldw, rt, ct);
-      append_frag(w, sub.data(), 16 * (int)rt.size(), 16 * (int)ct.size(), 16 * (int)ct.size());
+      if (st.arith == 3) h_range_ok = append_frag_h(w, sub.data(), 16 * (int)rt.size(), 16 * (int)ct.size(), 16 * (int)ct.size()) && h_range_ok;
+      else append_frag(w, sub.data(), 16 * (int)rt.size(), 16 * (int)ct.size(), 16 * (int)ct.size());
     };
     auto putT = [&](const double *W, int K, int N, const std::vector<int> &rt, const std::vector<int> &ct) {    // tiles of W^T ([N][K])
       auto t = transpose(W, K, N);
@@ -864,6 +874,13 @@ static void fusedlx2_prepare(Model &m) {
   A.wbytes = (int)(w.size() * sizeof(float));
   A.T = T; A.NL = NL; A.p = h.poly_p;
   A.cenv = (float)(1.0 / std::sqrt(h.avg_num_neighbors));
+  A.bscale = A.ibscale = 1.f;
+  if (st.arith == 3) {
+    if (!h_range_ok) throw UnsupportedError("fused_arith=f16x2: a weight of this model exceeds float16's range; use fused_arith=f32");
+    const int ex = backward_scale_exponent(h);
+    A.bscale = (float)std::ldexp(1.0, ex); A.ibscale = (float)std::ldexp(1.0, -ex);
+    A.err = alarm_word(m);
+  }
   A.wave_scratch = (long long)S::R_TOTAL(NL) * ROW;
   hipDeviceProp_t prop;
   AHIP_CHECK(hipGetDeviceProperties(&prop, m.device));
@@ -883,6 +900,8 @@ bool fusedlx2_run(Model &m, const ComputeArgs &a, std::string *why) {
   constexpr int NW = S::NW, SLOTS = S::SLOTS;
   fusedlx2_prepare(m);
   FusedLxState &st = *(FusedLxState *)m.fusedlx2_state;
+  fused_poll_alarm(m);       // raised by an EARLIER evaluation (nobody waits for the kernel): its forces were not finite
+  m.last_fused_arith = st.arith;
   hipStream_t s = a.stream;
   const int inum = m.inum;
   const int grid = std::max(1, st.ncu - (m.reserve_wgs + 1) / 2);      // see fused.hip: slots left free for the exchange kernels
@@ -897,7 +916,8 @@ bool fusedlx2_run(Model &m, const ComputeArgs &a, std::string *why) {
   (void)inum;
   {
     StageTimer tm(m, "model_fused", s);
-#define LX2_LAUNCH(NLV, PROFV) hipLaunchKernelGGL((k_fused_lx2<NLV, PROFV>), dim3(grid), dim3(NW * 64), 0, s, A)
+#define LX2_LAUNCH(NLV, PROFV) do { if (st.arith == 3) hipLaunchKernelGGL((k_fused_lx2<NLV, PROFV, 3>), dim3(grid), dim3(NW * 64), 0, s, A); \
+                                    else hipLaunchKernelGGL((k_fused_lx2<NLV, PROFV, 0>), dim3(grid), dim3(NW * 64), 0, s, A); } while (0)
     if (st.prof_on && A.NL == 3) {
       AHIP_CHECK(hipMemsetAsync(st.prof.p, 0, 64 * sizeof(long long), s));
       A.prof = st.prof.as<long long>();

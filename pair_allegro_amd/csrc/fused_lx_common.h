@@ -5,6 +5,7 @@
 #include "cg_tables.h"
 #include "engine.h"
 #include "fused_common.h"
+#include "fused_h.h"
 #include "prims.h"
 #include <algorithm>
 
@@ -43,7 +44,31 @@ struct FusedLxArgs {
   // outputs
   double *f, *eatom, *partial;            // partial [gridDim.x][7]
   long long *prof;
+  float bscale, ibscale;                  // f16x2 arithmetic: the backward pass runs scaled by this power of two (fused_h.h), undone on the edge gradient
+  int *err;                               // host-mapped word: set when an edge gradient comes out non-finite (float16 range exceeded)
 };
+
+// Arithmetic of the wide kernels' streamed linears: AR = 0 the f32-input MFMA (linear_s), AR = 3 f16x2 (fused_h.h: linear_h, one edge group).  Both
+// consume the same number of 1 KiB fragments per linear (a multiple of the ring depth, except the 32-feature mixing rows of fused_lx.hip: half a ring, alternating phase RP).
+template <int AR> struct LxRing {
+  f32x4 f[AR == 0 ? RING : 1];
+  u32x4 h[AR == 3 ? RINGH : 1];
+};
+template <int AR> __device__ __forceinline__ void lx_prime(__amdgpu_buffer_rsrc_t W, int wp, int v16, LxRing<AR> &ring) {
+  if constexpr (AR == 3) ring_prime_h(W, wp, v16, ring.h);
+  else ring_prime(W, wp, v16, ring.f);
+}
+template <int AR, int KT, int NT, bool ACC, int RP = 0, class Epi>
+__device__ __forceinline__ void lx_lin(__amdgpu_buffer_rsrc_t W, int &wp, const f32x4 (&in)[KT], f32x4 (&out)[NT], int v16, LxRing<AR> &ring, Epi epi) {
+  if constexpr (AR == 3) {
+    static_assert(KT % 2 == 0 && RINGH == RING, "K-steps are pairs of 16-feature tiles; one wrap-around copy serves both arithmetics");
+    Hop b[1][KT / 2], unused[1][NT / 2];
+#pragma unroll
+    for (int ks = 0; ks < KT / 2; ++ks) b[0][ks] = split_pair_h(in[2 * ks], in[2 * ks + 1]);
+    Epi ep[1] = {epi};
+    linear_h<1, KT / 2, NT, ACC, false, RP, Epi>(W, wp, b, reinterpret_cast<f32x4 (&)[1][NT]>(out), unused, v16, ring.h, ep);
+  } else linear_s<KT, NT, ACC, RP, Epi>(W, wp, in, out, v16, ring.f, epi);
+}
 
 // host-side state of one wide fused kernel family
 struct FusedLxState {
@@ -52,6 +77,7 @@ struct FusedLxState {
   bool ready = false, prof_on = false;
   int ncu = 256;
   int L = 0, UT = 0;
+  int arith = 0;               // 0: f32-input MFMA, 3: f16x2 (lx_arith_of)
 };
 
 // edge total for the claim-size heuristic: the value itself when it is on the host, else the last one that was, else from the list's size

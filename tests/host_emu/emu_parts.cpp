@@ -45,7 +45,6 @@ hipError_t prim_reneighbor_flag(const double *x, const double *xh, const double 
 bool fused_model_supported(const Model &, std::string *why) { if (why) *why = "host emulation has no MFMA"; return false; }
 bool fused_run(Model &, const ComputeArgs &, std::string *why) { if (why) *why = "host emulation has no MFMA"; return false; }
 void fused_free(Model &) {}
-void fused_poll_alarm(Model &) {}
 bool fusedlx_model_supported(const Model &, std::string *why) { if (why) *why = "host emulation has no MFMA"; return false; }
 bool fusedlx_run(Model &, const ComputeArgs &, std::string *why) { if (why) *why = "host emulation has no MFMA"; return false; }
 void fusedlx_free(Model &) {}

@@ -11,7 +11,7 @@ NORTH_STAR_DF = 1e-4                               # BASELINE.json: max|dF| < 1e
 F32EQ_DF = 5e-6                                    # a split arithmetic (f16x2, bf16x3) is float32-EQUIVALENT: max|dF| vs the float64 oracle on the 10 648-atom Si box within 5e-6 (f32 fmaf chains: 1.6e-6 .. 3.3e-6)
 # kernel paths whose arithmetic is float32 or float32-equivalent: exact fmaf chains; two float16 terms per operand (csrc/fused_h.h); three bf16 terms -- everything but tf32eq
 FUSED_F32EQ = ("fused_f32", "fused_f16x2", "fused_bf16x3")
-FUSED_S_DEFAULT = "fused_f16x2"                    # what fused_arith=auto selects for the l_max = 1 shapes (k_fused) when the model file has allow_tf32 = 0
+FUSED_DEFAULT = "fused_f16x2"                      # what fused_arith=auto selects on every fused kernel (k_fused, k_fused_lx2, k_fused_lx) when the model file has allow_tf32 = 0
 
 
 def check_golden(lib, model_dir, tag, dtype, grid=(1, 1, 1), options=None, shuffle_seed=None):

@@ -185,7 +185,7 @@ def test_fused_arith_auto_selection(hip_lib, model_dir):
     g = util.load_golden("CuPd-cubic-big_r5")
     path, cfg, types, names, ref = _model_S_case(model_dir, "cupd_S_auto", ["Cu", "Pd"], g["symbols"], g["cell"], g["pos"])
     run = lambda opts: util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options=opts)["info"]["path"]
-    assert run({}) == pc.FUSED_S_DEFAULT == "fused_f16x2"
+    assert run({}) == pc.FUSED_DEFAULT == "fused_f16x2"
     assert run({"fused_arith": "f32"}) == "fused_f32"
     assert run({"fused_tb": "mlp"}) == "fused_f32"
     assert run({"fused_arith": "bf16x3"}) == "fused_bf16x3"
@@ -195,13 +195,14 @@ def test_fused_arith_auto_selection(hip_lib, model_dir):
 def test_f16x2_range_alarm(hip_lib, model_dir):
     """float16 has no exponent range to spare: when an operand leaves it the edge gradient comes out non-finite, the kernel raises a flag in
     host-mapped memory and the evaluation reports AHIP_ERR_STATE naming the remedy (fused_arith=f32): the host-pointer call, which waits for the
-    kernel anyway, in the same call and before it touches f; a device-resident caller at its next evaluation.  Here: latent weights blown up by 3e4;
+    kernel anyway, in the same call and before it touches f; a device-resident caller at its next evaluation.  Here: two latent linears blown up by 1e3 each;
     fused_arith=f32 evaluates the same file."""
     from pair_allegro_amd import capi
     g = util.load_golden("CuPd-cubic-big_r5")
     cfg = model_file.model_S(type_names=["Cu", "Pd"], avg_num_neighbors=40.0)
     w = model_file.init_weights(cfg)
-    w["l1.lat.w0"] = np.asarray(w["l1.lat.w0"]) * 3e4
+    w["l1.lat.w0"] = np.asarray(w["l1.lat.w0"]) * 1e3          # hidden activations ~1e3 and ~1e6: the second exceeds 65504
+    w["l1.lat.w1"] = np.asarray(w["l1.lat.w1"]) * 1e3
     path = f"{model_dir}/h2_overflow.nequip.pth"
     allegro_torch.export_nequip_pth(path, cfg, w)
     names = ["Cu", "Pd"]

@@ -99,11 +99,11 @@ def test_one_pair_object_through_growing_shrinking_and_denser_systems(hip_lib, m
     w = model_file.init_weights(cfg)
     path = f"{model_dir}/lifecycle_S.nequip.pth"
     allegro_torch.export_nequip_pth(path, cfg, w)
-    seq = [("small", 3, 1.0, pc.FUSED_S_DEFAULT), ("grown", 5, 1.0, pc.FUSED_S_DEFAULT), ("empty", 0, 0, None), ("small again", 3, 1.0, pc.FUSED_S_DEFAULT),
-           ("rows > 64", 3, 0.86, pc.FUSED_S_DEFAULT), ("degree > 64", 3, 0.74, pc.FUSED_S_DEFAULT), ("degrees around 64", 3, 0.748, pc.FUSED_S_DEFAULT), ("degree > 128", 3, 0.55, "generic_f32"),
-           ("plain after fallback", 4, 1.0, pc.FUSED_S_DEFAULT), ("degree > 64 again", 4, 0.74, pc.FUSED_S_DEFAULT)]
+    seq = [("small", 3, 1.0, pc.FUSED_DEFAULT), ("grown", 5, 1.0, pc.FUSED_DEFAULT), ("empty", 0, 0, None), ("small again", 3, 1.0, pc.FUSED_DEFAULT),
+           ("rows > 64", 3, 0.86, pc.FUSED_DEFAULT), ("degree > 64", 3, 0.74, pc.FUSED_DEFAULT), ("degrees around 64", 3, 0.748, pc.FUSED_DEFAULT), ("degree > 128", 3, 0.55, "generic_f32"),
+           ("plain after fallback", 4, 1.0, pc.FUSED_DEFAULT), ("degree > 64 again", 4, 0.74, pc.FUSED_DEFAULT)]
     seen = _run_sequence(hip_lib, path, cfg, ["Si"], seq, {})
-    assert seen.count(pc.FUSED_S_DEFAULT) == 8 and seen.count("generic_f32") == 1
+    assert seen.count(pc.FUSED_DEFAULT) == 8 and seen.count("generic_f32") == 1
 
 
 def test_one_pair_object_with_heavy_centres_coming_and_going(hip_lib, model_dir):
@@ -114,7 +114,7 @@ def test_one_pair_object_with_heavy_centres_coming_and_going(hip_lib, model_dir)
     w = model_file.init_weights(cfg)
     path = f"{model_dir}/lifecycle_L.nequip.pth"
     allegro_torch.export_nequip_pth(path, cfg, w)
-    seq = [("no heavy centres", 3, 1.0, "fused_f32"), ("some heavy centres", 3, 0.748, "fused_f32"), ("none again", 4, 1.0, "fused_f32"),
-           ("mostly heavy", 3, 0.745, "fused_f32"), ("nearly all heavy", 3, 0.742, "fused_f32"), ("list rows > 128", 3, 0.70, "generic_f32"), ("empty", 0, 0, None), ("none at the end", 3, 1.0, "fused_f32")]
+    seq = [("no heavy centres", 3, 1.0, pc.FUSED_DEFAULT), ("some heavy centres", 3, 0.748, pc.FUSED_DEFAULT), ("none again", 4, 1.0, pc.FUSED_DEFAULT),
+           ("mostly heavy", 3, 0.745, pc.FUSED_DEFAULT), ("nearly all heavy", 3, 0.742, pc.FUSED_DEFAULT), ("list rows > 128", 3, 0.70, "generic_f32"), ("empty", 0, 0, None), ("none at the end", 3, 1.0, pc.FUSED_DEFAULT)]
     seen = _run_sequence(hip_lib, path, cfg, ["Si"], seq, {})
-    assert seen == ["fused_f32"] * 5 + ["generic_f32", "none", "fused_f32"], seen
+    assert seen == [pc.FUSED_DEFAULT] * 5 + ["generic_f32", "none", pc.FUSED_DEFAULT], seen

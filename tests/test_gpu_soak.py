@@ -87,7 +87,7 @@ def test_soak_k_fused_lx2(hip_lib, model_dir):
     cell, pos, types = lmp_like.water(10)
     cfg = model_file.model_L(avg_num_neighbors=53.6)
     masses = [lmp_like.WATER_MASSES[s] for s in cfg["type_names"]]
-    _soak(hip_lib, model_dir, "soak_L", cfg, cell, pos, (types - 1).astype(np.int32), masses, {}, "fused_f32", pc.NORTH_STAR_DF)
+    _soak(hip_lib, model_dir, "soak_L", cfg, cell, pos, (types - 1).astype(np.int32), masses, {}, pc.FUSED_DEFAULT, pc.NORTH_STAR_DF)
 
 
 def test_soak_k_fused_lx(hip_lib, model_dir):
@@ -96,4 +96,4 @@ def test_soak_k_fused_lx(hip_lib, model_dir):
     cell, pos, types = lmp_like.water(10)
     cfg = model_file.model_L(num_tensor_features=32, avg_num_neighbors=53.6)
     masses = [lmp_like.WATER_MASSES[s] for s in cfg["type_names"]]
-    _soak(hip_lib, model_dir, "soak_Y", cfg, cell, pos, (types - 1).astype(np.int32), masses, {}, "fused_f32", pc.NORTH_STAR_DF)
+    _soak(hip_lib, model_dir, "soak_Y", cfg, cell, pos, (types - 1).astype(np.int32), masses, {}, pc.FUSED_DEFAULT, pc.NORTH_STAR_DF)

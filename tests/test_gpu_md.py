@@ -180,3 +180,26 @@ def test_bench_fails_fast_when_a_rank_dies():
     assert not [l for l in r.stdout.decode().splitlines() if l.startswith("{")], "no JSON line from a failed run"
     # start-up (two torch imports, model load, neighbor build) dominates; after rank 1's exit the parent needs 0.1 s to notice and <= 10 s to stop rank 0
     assert took < 120, f"took {took:.0f} s"
+
+
+def test_rehearsal_of_the_eight_rank_run_on_one_gpu(tmp_path):
+    """pair_allegro_amd/tools/rehearse_ranks.py at a size that fits a test: the 10 648-atom Si box on the 2x2x2 brick grid of the 8-GPU run,
+    eight processes on cuda:0, both exchange schedules, every atom's force / the energy per atom / the positions after two steps against the single-rank
+    evaluation.  The full-size runs (1 M Si on 2x2x2, 102 400 Li3PO4 on 2x2x1, 499 125 water on 2x2x2) are committed under profiles/r05_g_rehearse_*.json."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "rehearse.json"
+    env = dict(os.environ, PYTHONPATH=root, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port", "29771",
+           os.path.join(root, "pair_allegro_amd", "tools", "rehearse_ranks.py"), "--config", "2", "--steps", "2", "--out", str(out)]
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    d = json.loads(open(out).read())
+    assert d["ok"] and d["ranks"] == 8 and d["grid"] == "2x2x2" and d["kernel_path"] in pc.FUSED_F32EQ
+    for sched in ("overlapped", "serial"):
+        e = d[sched]
+        assert sum(e["nlocal"]) == 10648 and min(e["nghost"]) > 0 and e["max_abs_dF_setup"] < 5e-6 and e["d_pe_per_atom_setup"] < 1e-7
+        assert e["comm_transport"] == "hosted" or e["comm_transport"].startswith("library")
+    assert min(d["overlapped"]["n_interior"]) > 0

@@ -11,8 +11,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "engine.h"
 #include "generic_engine.h"
@@ -168,6 +173,7 @@ void ahip_model_free(ahip_model *m) {
                     &m->b_ws, &m->b_misc, &m->hv_eoff, &m->hv_eii, &m->hv_ej, &m->hv_rvec, &m->hv_ilist, &m->hv_engvir, &m->b_tile_a0, &m->b_tile_e0, &m->b_centre, &m->b_ntiles})
     b->release();
   for (auto &t : m->slots) for (auto &e : t.ring) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (hipEvent_t e : m->f_events) (void)hipEventDestroy(e);
 #ifndef AHIP_HOST_EMU
   for (auto &kv : m->pinned) (void)hipHostUnregister(kv.second.first);
 #endif
@@ -248,30 +254,121 @@ namespace {
 struct Staging {
   std::mutex mu;
   void *p = nullptr;
-  static constexpr size_t BYTES = 8u << 20;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  static constexpr size_t BYTES = 8u << 20, HALF = BYTES / 2;
   void *get() {
-    if (!p) AHIP_CHECK(hipHostMalloc(&p, BYTES, hipHostMallocDefault));
+    if (!p) {
+      AHIP_CHECK(hipHostMalloc(&p, BYTES, hipHostMallocDefault));
+      for (int k = 0; k < 2; ++k) AHIP_CHECK(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+    }
     return p;
   }
 };
 Staging g_staging;      // process-wide, never freed (the runtime may be gone when static destructors run)
 }  // namespace
+
+// ---- host-side loops of the host-pointer path, on a few threads ----
+// The reference's own host loops are OpenMP loops (pair_nequip_allegro.cpp:371, 488, 566); this library links nothing but libdl, so the three O(nall)
+// loops of ahip_compute (type map, position copy into page-locked memory, f +=) and the staging copies run on std::threads instead: AHIP_HOST_THREADS
+// (default: min(16, hardware threads)), one thread below 65 536 items.  fn(begin, end) must be safe to run concurrently on disjoint ranges.
+int host_threads() {
+  static const int n = [] {
+    if (const char *e = std::getenv("AHIP_HOST_THREADS")) return std::max(1, std::atoi(e));
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(16u, hw ? hw : 1u));
+  }();
+  return n;
+}
+// A persistent pool (created at the first use, never destroyed: worker threads may outlive static destructors): forking and joining eight
+// std::threads costs ~0.3 ms, four times per call, which was half of what the loops themselves take at 1 M atoms.
+namespace {
+struct HostPool {
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  std::function<void(size_t, size_t)> job;
+  size_t n = 0, per = 0;
+  unsigned long long gen = 0;
+  int pending = 0, nworkers = 0;
+  explicit HostPool(int nw) : nworkers(nw) {
+    for (int w = 1; w <= nw; ++w) std::thread([this, w] { work(w); }).detach();
+  }
+  void work(int w) {
+    unsigned long long seen = 0;
+    for (;;) {
+      std::function<void(size_t, size_t)> fn;
+      size_t b, e;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_go.wait(lk, [&] { return gen != seen; });
+        seen = gen;
+        fn = job;
+        b = std::min(n, (size_t)w * per); e = std::min(n, b + per);
+      }
+      if (b < e) fn(b, e);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (--pending == 0) cv_done.notify_one();
+      }
+    }
+  }
+  void run(size_t count, const std::function<void(size_t, size_t)> &fn) {        // one caller at a time (run_mu)
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      job = fn; n = count; per = (count + nworkers) / (nworkers + 1); pending = nworkers; ++gen;
+    }
+    cv_go.notify_all();
+    fn((size_t)0, std::min(count, per));
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return pending == 0; });
+  }
+};
+std::mutex g_pool_run_mu;
+HostPool *g_pool = nullptr;
+}  // namespace
+template <class F> static void parallel_for(size_t n, F fn) {
+  const int nt = n < 65536 ? 1 : host_threads();
+  if (nt <= 1) { fn((size_t)0, n); return; }
+  std::lock_guard<std::mutex> lk(g_pool_run_mu);
+  if (!g_pool) g_pool = new HostPool(nt - 1);
+  g_pool->run(n, std::function<void(size_t, size_t)>(fn));
+}
+static void parallel_memcpy(void *dst, const void *src, size_t bytes) {
+  parallel_for(bytes, [=](size_t b, size_t e) { std::memcpy((char *)dst + b, (const char *)src + b, e - b); });
+}
+
+// Pageable host memory <-> device through the page-locked staging buffer, in two halves: the DMA of one half runs while the host copies the other
+// (a 184 MB neighbor list used to be 23 memcpy + synchronous-DMA pairs in a row).
 void copy_h2d(void *dst_dev, const void *src_host, size_t bytes) {
   std::lock_guard<std::mutex> lk(g_staging.mu);
   char *st = (char *)g_staging.get();
-  for (size_t o = 0; o < bytes; o += Staging::BYTES) {
-    const size_t n = std::min(Staging::BYTES, bytes - o);
-    std::memcpy(st, (const char *)src_host + o, n);
-    AHIP_CHECK(hipMemcpy((char *)dst_dev + o, st, n, hipMemcpyHostToDevice));
+  int k = 0;
+  bool used[2] = {false, false};
+  for (size_t o = 0; o < bytes; o += Staging::HALF, k ^= 1) {
+    const size_t n = std::min(Staging::HALF, bytes - o);
+    if (used[k]) AHIP_CHECK(hipEventSynchronize(g_staging.ev[k]));            // the DMA that last read this half
+    parallel_memcpy(st + k * Staging::HALF, (const char *)src_host + o, n);
+    AHIP_CHECK(hipMemcpyAsync((char *)dst_dev + o, st + k * Staging::HALF, n, hipMemcpyHostToDevice, nullptr));
+    AHIP_CHECK(hipEventRecord(g_staging.ev[k], nullptr));
+    used[k] = true;
   }
+  AHIP_CHECK(hipStreamSynchronize(nullptr));
 }
 void copy_d2h(void *dst_host, const void *src_dev, size_t bytes) {
   std::lock_guard<std::mutex> lk(g_staging.mu);
   char *st = (char *)g_staging.get();
-  for (size_t o = 0; o < bytes; o += Staging::BYTES) {
-    const size_t n = std::min(Staging::BYTES, bytes - o);
-    AHIP_CHECK(hipMemcpy(st, (const char *)src_dev + o, n, hipMemcpyDeviceToHost));
-    std::memcpy((char *)dst_host + o, st, n);
+  // half k holds chunk c: request chunk c + 1 into the other half, then copy chunk c out while that DMA runs
+  const size_t nchunk = (bytes + Staging::HALF - 1) / Staging::HALF;
+  auto req = [&](size_t c) {
+    const size_t o = c * Staging::HALF, n = std::min(Staging::HALF, bytes - o);
+    AHIP_CHECK(hipMemcpyAsync(st + (c & 1) * Staging::HALF, (const char *)src_dev + o, n, hipMemcpyDeviceToHost, nullptr));
+    AHIP_CHECK(hipEventRecord(g_staging.ev[c & 1], nullptr));
+  };
+  if (nchunk) req(0);
+  for (size_t c = 0; c < nchunk; ++c) {
+    AHIP_CHECK(hipEventSynchronize(g_staging.ev[c & 1]));
+    if (c + 1 < nchunk) req(c + 1);
+    const size_t o = c * Staging::HALF, n = std::min(Staging::HALF, bytes - o);
+    parallel_memcpy((char *)dst_host + o, st + (c & 1) * Staging::HALF, n);
   }
 }
 }  // namespace ahip
@@ -550,12 +647,21 @@ int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const i
     // types: LAMMPS 1-based -> filter index (type-1) and model type (pair_nequip_allegro.cpp:576)
     unpin_if_growing(m, m->h_ftype, (size_t)nall); unpin_if_growing(m, m->h_mtype, (size_t)nall);
     m->h_ftype.resize(nall); m->h_mtype.resize(nall);
-    for (int i = 0; i < nall; ++i) {
-      int t = type[i];
-      if (t < 1 || t > ntypes) throw ArgError("ahip_compute: atom type out of range");
-      int mt = type_mapper[t - 1];
-      if (mt < 0 || mt >= m->hm.num_types) throw ArgError("ahip_compute: LAMMPS type " + std::to_string(t) + " is not mapped to a model type (all pair coeffs are not set)");
-      m->h_ftype[i] = t - 1; m->h_mtype[i] = mt;
+    {
+      std::atomic<int> bad_range{0}, bad_map{0};           // first offending LAMMPS type of each kind (0: none): the threads report, this thread throws
+      const int nmt = m->hm.num_types;
+      int *const hft = m->h_ftype.data(), *const hmt = m->h_mtype.data();
+      parallel_for((size_t)nall, [&, hft, hmt](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+          const int t = type[i];
+          if (t < 1 || t > ntypes) { bad_range.store(t ? t : -1); hft[i] = 0; hmt[i] = 0; continue; }
+          const int mt = type_mapper[t - 1];
+          if (mt < 0 || mt >= nmt) { bad_map.store(t); hft[i] = 0; hmt[i] = 0; continue; }
+          hft[i] = t - 1; hmt[i] = mt;
+        }
+      });
+      if (bad_range.load()) throw ArgError("ahip_compute: atom type out of range");
+      if (bad_map.load()) throw ArgError("ahip_compute: LAMMPS type " + std::to_string(bad_map.load()) + " is not mapped to a model type (all pair coeffs are not set)");
     }
     std::vector<double> cutsq((size_t)ntypes * ntypes);
     for (size_t k = 0; k < cutsq.size(); ++k) cutsq[k] = cutsq_bound(m, cutoff_matrix[k]);
@@ -570,8 +676,15 @@ int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const i
     unpin_if_growing(m, m->h_x, (size_t)nall * 3);
     m->h_x.resize((size_t)nall * 3);
     pin_host(m, m->h_x); pin_host(m, m->h_ftype); pin_host(m, m->h_mtype);
-    std::memcpy(m->h_x.data(), x, (size_t)nall * 3 * sizeof(double));
-    AHIP_CHECK(hipMemcpyAsync(m->b_x.p, m->h_x.data(), (size_t)nall * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    {
+      // in chunks: the DMA of chunk c runs while the threads copy chunk c + 1 into the page-locked buffer
+      const size_t tot = (size_t)nall * 3 * sizeof(double), CH = 16u << 20;
+      for (size_t o = 0; o < tot; o += CH) {
+        const size_t n = std::min(CH, tot - o);
+        parallel_memcpy((char *)m->h_x.data() + o, (const char *)x + o, n);
+        AHIP_CHECK(hipMemcpyAsync((char *)m->b_x.p + o, (const char *)m->h_x.data() + o, n, hipMemcpyHostToDevice, s));
+      }
+    }
     AHIP_CHECK(hipMemcpyAsync(m->b_ftype.p, m->h_ftype.data(), (size_t)nall * sizeof(int), hipMemcpyHostToDevice, s));
     AHIP_CHECK(hipMemcpyAsync(m->b_mtype.p, m->h_mtype.data(), (size_t)nall * sizeof(int), hipMemcpyHostToDevice, s));
     AHIP_CHECK(hipMemcpyAsync(m->b_cutsq.p, cutsq.data(), cutsq.size() * sizeof(double), hipMemcpyHostToDevice, s));
@@ -588,20 +701,42 @@ int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const i
     m->h_f.resize((size_t)nall * 3);
     pin_host(m, m->h_f);
     double ev[7];
-    AHIP_CHECK(hipMemcpyAsync(m->h_f.data(), m->b_f.p, (size_t)nall * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    // Order on the stream: the 7 energy / virial sums and an event (the kernel has finished once it fires: the float16-range alarm of THIS evaluation is
+    // valid and is reported by this call, before f is touched), then the forces in chunks, each behind an event: the host adds chunk c into f while
+    // the DMA of chunk c + 1 runs; the per-atom energies last.
+    constexpr size_t FCH = 8u << 20;
+    const size_t ftot = (size_t)nall * 3 * sizeof(double), nfch = (ftot + FCH - 1) / FCH;
+    while (m->f_events.size() < nfch + 1) { hipEvent_t e; AHIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m->f_events.push_back(e); }
+    AHIP_CHECK(hipMemcpyAsync(ev, m->b_engvir.p, 7 * sizeof(double), hipMemcpyDeviceToHost, s));
+    AHIP_CHECK(hipEventRecord(m->f_events[nfch], s));
+    for (size_t c = 0; c < nfch; ++c) {
+      const size_t o = c * FCH, n = std::min(FCH, ftot - o);
+      AHIP_CHECK(hipMemcpyAsync((char *)m->h_f.data() + o, (const char *)m->b_f.p + o, n, hipMemcpyDeviceToHost, s));
+      AHIP_CHECK(hipEventRecord(m->f_events[c], s));
+    }
     if (want_eatom) {
       unpin_if_growing(m, m->h_eatom, (size_t)nall);
       m->h_eatom.resize(nall);
       pin_host(m, m->h_eatom);
       AHIP_CHECK(hipMemcpyAsync(m->h_eatom.data(), m->b_eatom.p, (size_t)nall * sizeof(double), hipMemcpyDeviceToHost, s));
     }
-    AHIP_CHECK(hipMemcpyAsync(ev, m->b_engvir.p, 7 * sizeof(double), hipMemcpyDeviceToHost, s));
-    AHIP_CHECK(hipStreamSynchronize(s));
-    fused_poll_alarm(*m);              // the kernel has finished here: a float16-range alarm of THIS evaluation is reported by this call, before f is touched
+    AHIP_CHECK(hipEventSynchronize(m->f_events[nfch]));
+    try { fused_poll_alarm(*m); } catch (...) { (void)hipStreamSynchronize(s); throw; }      // (the copies into the page-locked vectors finish before anybody may free them)
     // scatter: f[i] += forces[i] for locals AND ghosts (pair_nequip_allegro.cpp:370-377)
-    for (size_t k = 0; k < (size_t)nall * 3; ++k) f[k] += m->h_f[k];
-    if (eatom)
-      for (int ii = 0; ii < m->inum; ++ii) { int i = m->h_ilist.empty() ? ii : m->h_ilist[ii]; eatom[i] = m->h_eatom[i]; }
+    {
+      const double *const hf = m->h_f.data();
+      for (size_t c = 0; c < nfch; ++c) {
+        AHIP_CHECK(hipEventSynchronize(m->f_events[c]));
+        const size_t k0 = c * (FCH / sizeof(double)), k1 = std::min((size_t)nall * 3, k0 + FCH / sizeof(double));
+        parallel_for(k1 - k0, [=](size_t b, size_t e) { for (size_t k = k0 + b; k < k0 + e; ++k) f[k] += hf[k]; });
+      }
+    }
+    AHIP_CHECK(hipStreamSynchronize(s));
+    if (eatom) {
+      const double *const he = m->h_eatom.data();
+      const int *const il = m->h_ilist.empty() ? nullptr : m->h_ilist.data();
+      parallel_for((size_t)m->inum, [=](size_t b, size_t e) { for (size_t ii = b; ii < e; ++ii) { const int i = il ? il[ii] : (int)ii; eatom[i] = he[i]; } });
+    }
     *eng = ev[0];
     if (virial) for (int k = 0; k < 6; ++k) virial[k] = ev[1 + k];
     if (!m->custom_names.empty()) {

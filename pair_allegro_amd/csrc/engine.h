@@ -175,6 +175,7 @@ struct Model {
   PrimScratch prim;
 
   // fused path private state (fused.hip: model S shape; fused_lx.hip: l_max = 2 shapes)
+  std::vector<hipEvent_t> f_events;          // host-pointer path: one event per returned chunk of f (allegro_hip.hip: ahip_compute)
   int *h_alarm = nullptr;                    // page-locked, device-mapped word raised by the f16x2 instances of the fused kernels (fused_h.h): see alarm_word()
   void *fused_state = nullptr;
   void *fusedlx_state = nullptr;

@@ -23,13 +23,18 @@ def main():
     f = np.zeros_like(rs.x)
     mapper = np.array([0], np.int32)
     cm = np.array([[cfg["r_max"]]])
-    for _ in range(4):
+    m.set_option("timing", "1")
+    for _ in range(5):
         f[:] = 0
+        m.timings()
         t0 = time.perf_counter()
         m.compute(rs.nlocal, rs.nghost, rs.x, rs.type, mapper, cm, f)
         dt = time.perf_counter() - t0
+        st = m.timings()
+        dev = sum(v for k, v in st.items() if k in ("edge_build", "tile_pack", "model_fused", "model_generic"))
         print(f"ahip_compute host pointers, {rs.nlocal} atoms (+{rs.nghost} ghosts): {dt * 1e3:.2f} ms -> "
-              f"{rs.nlocal / dt / 1e6:.2f} M atom-evaluations/s PCIe-inclusive ({m.last_path})")
+              f"{rs.nlocal / dt / 1e6:.2f} M atom-evaluations/s PCIe-inclusive ({m.last_path}); device stages {dev:.2f} ms, "
+              f"host + PCIe overhead {dt * 1e3 - dev:.2f} ms = {100 * (dt * 1e3 - dev) / (dt * 1e3):.1f} % of the call")
 
 
 if __name__ == "__main__":

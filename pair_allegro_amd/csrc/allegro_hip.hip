@@ -219,9 +219,6 @@ int ahip_set_option(ahip_model *m, const char *key, const char *value) {
     } else if (k == "fused_arith") {
       if (v != "bf16x3" && v != "f32" && v != "tf32eq" && v != "f16x2" && v != "auto") throw ArgError("option fused_arith: expected auto|f32|f16x2|bf16x3|tf32eq");
       if (v != m->opt_fused_arith) { m->opt_fused_arith = v; fused_free(*m); fusedlx_free(*m); fusedlx2_free(*m); }     // weight streams are rebuilt on the next compute
-    } else if (k == "fused_groups") {
-      if (v != "1" && v != "2") throw ArgError("option fused_groups: expected 1|2");
-      if (v != m->opt_fused_groups) { m->opt_fused_groups = v; fused_free(*m); }
     } else if (k == "fused_tb") {
       if (v != "table" && v != "mlp") throw ArgError("option fused_tb: expected table|mlp");
       if (v != m->opt_fused_tb) { m->opt_fused_tb = v; fused_free(*m); }

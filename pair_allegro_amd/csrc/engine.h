@@ -103,7 +103,6 @@ struct Model {
   std::string opt_precision = "model";      // model | float64
   std::string opt_fused_tb = "table";       // table | mlp: two-body embedding of the fused kernel from the spline table or as an MLP
   std::string opt_fused_arith = "auto";     // auto | f32 | bf16x3 | tf32eq: arithmetic of the fused kernel's linears (fused.hip); auto = tf32eq iff the model file sets allow_tf32
-  std::string opt_fused_groups = "1";       // 1 | 2: edge groups per weight fragment in the model-S kernel (2 = k_fused_g2: f16x2 arithmetic + tabulated two-body embedding only)
   int last_fused_arith = 0;                 // what the last fused (model S) evaluation used: 0 f32, 1 bf16x3, 2 tf32eq
   long long chunk_edges = 2000000;
   int reserve_wgs = 0;                      // workgroup slots the persistent fused kernels leave free (for kernels of other streams)

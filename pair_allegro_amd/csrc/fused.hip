@@ -877,612 +877,6 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
 }
 
 
-void fused_launch_g2(bool prof, int grid, hipStream_t s, const FusedArgs &A);
-#if AHIP_FUSED_PART == 3
-// ---------------------------------------------------------------------------- two edge groups per weight fragment (fused_g2.o)
-// k_fused_g2 (round 5): the tile sequence of k_fused on the f16x2 arithmetic with the tabulated two-body embedding, but every wave carries TWO
-// 16-slot edge groups through every linear, so that each 1 KiB weight fragment read through the CU's 64 B/clk vector-memory path serves 32 edges
-// instead of 16 -- on the f16 matrix cores the contractions take a fifth of the f32-input form's time and k_fused waits for that path
-// (profiles/r05_c_f16x2_ablation.md).  Shape: 4 waves x 32 slots = 128-slot tiles (<= 12 centres, any centre of <= 128 edges), ONE workgroup per CU,
-// i.e. one wave per SIMD with the whole register file (512 per lane): the per-edge state of two groups (latent 2 x 16, edge tensor 2 x 32 + its image
-// 2 x 32), the rows requested ahead for the backward pass and the fragment ring all stay in registers; what the second wave of a SIMD does for
-// k_fused -- covering memory and LDS waits -- the second group's independent instruction stream has to do here.  Weight stream, scratch row map (per
-// group) and numerics are those of k_fused<4, ., 3, true, .>.
-template <int NLT> struct __attribute__((aligned(16))) LdsG {
-  static constexpr int SLOTS = 128, MAXA = 12;
-  float stage[SLOTS * STG_LD];
-  float env[NLT][MAXA * ENV_LD];
-  float denv[MAXA * ENV_LD];
-  float tp[NLT][5 * 32];
-  float park[4][2][8 * ROW];              // per wave and group: V^{k+1} forward, dE/dV backward
-  double eacc[MAXA];
-  double virw[4][6];
-  int aoff[2][MAXA + 2];
-  float rc[16], scale[16], shift[16];
-  float res[NLT][2];
-  int chunk[2];
-};
-static_assert(sizeof(LdsG<3>) <= 160 * 1024, "LDS budget of one CU");
-template <int NLT> __device__ __forceinline__ void reduce_stage_g(const LdsG<NLT> &lds, const int *aoff, float *dst, int na, float scale, int tid) {
-  const int fidx = tid & 127;
-  for (int a = tid >> 7; a < na; a += 2) {
-    const int s0 = aoff[a], s1 = aoff[a + 1];
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-    int sl = s0;
-    for (; sl + 4 <= s1; sl += 4) {
-      acc0 += lds.stage[sl * STG_LD + fidx];
-      acc1 += lds.stage[(sl + 1) * STG_LD + fidx];
-      acc2 += lds.stage[(sl + 2) * STG_LD + fidx];
-      acc3 += lds.stage[(sl + 3) * STG_LD + fidx];
-    }
-    for (; sl < s1; ++sl) acc0 += lds.stage[sl * STG_LD + fidx];
-    dst[a * ENV_LD + fidx] = scale * ((acc0 + acc1) + (acc2 + acc3));
-  }
-}
-// two-group linear of the tile sequence: both groups' inputs are split here, every fragment feeds both
-template <int KT, int NT, bool ACC, int RPI, class Epi>
-__device__ __forceinline__ void lin2(__amdgpu_buffer_rsrc_t W, int &wp, const f32x4 (&in)[2][KT], f32x4 (&out)[2][NT], int v16, u32x4 (&ring)[RINGH], Epi (&ep)[2]) {
-  static_assert(KT % 2 == 0, "K-steps are pairs of 16-feature tiles");
-  Hop b[2][KT / 2], unused[2][NT / 2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int ks = 0; ks < KT / 2; ++ks) b[q][ks] = split_pair_h(in[q][2 * ks], in[q][2 * ks + 1]);
-  linear_h<2, KT / 2, NT, ACC, false, (4 * RPI) % RINGH, Epi>(W, wp, b, out, unused, v16, ring, ep);
-}
-
-template <bool PROF, int NLT>
-__global__ void __launch_bounds__(256, 1) k_fused_g2(FusedArgs A) {
-  constexpr int NTHREADS = 256, MAXA = LdsG<NLT>::MAXA, NL = NLT, RG = R_TOTAL(NLT);      // RG: scratch rows of one group
-  __shared__ LdsG<NLT> lds;
-  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
-  const int v16 = lane * 16;
-  __amdgpu_buffer_rsrc_t SB, WB;
-  {
-    unsigned long long b = (unsigned long long)(A.scratch + (size_t)blockIdx.x * A.wg_scratch + (size_t)wave * A.wave_scratch);
-    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-    SB = __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, (int)(A.wave_scratch * 4), 0x00020000);
-    WB = __builtin_amdgcn_make_buffer_rsrc((void *)A.wbase, 0, A.wbytes, 0x00020000);
-  }
-  const float *__restrict__ Wb = A.wbase;
-  for (int k = tid; k < NL * 160; k += NTHREADS) {
-    const int pth = (k % 160) / 32;
-    lds.tp[k / 160][k % 160] = Wb[A.o_tpl + k] * (pth == 1 ? C_P1 : pth == 4 ? C_P4 : 1.f);
-  }
-  const int ntiles = *A.ntiles;
-  double acc_part = 0.0;
-  long long pacc[PH_N];
-  long long tprev = 0;
-  if (PROF) {
-#pragma unroll
-    for (int k = 0; k < PH_N; ++k) pacc[k] = 0;
-    tprev = clock64();
-  }
-  float *const pk0 = lds.park[wave][0], *const pk1 = lds.park[wave][1];
-  u32x4 ring[RINGH];
-  int wp = A.o_stream;
-  ring_prime_h(WB, wp, v16, ring);
-  if (tid < MAXA) lds.eacc[tid] = 0.0;
-  if (lane < 6) lds.virw[wave][lane] = 0.0;
-  if (A.T <= 4 && tid < A.T * A.T) lds.rc[tid] = (float)A.rcut[tid];
-  if (tid < A.T) { lds.scale[tid] = Wb[A.o_scale + tid]; lds.shift[tid] = Wb[A.o_shift + tid]; }
-  if (tid < 2 * NL) lds.res[tid >> 1][tid & 1] = Wb[A.o_res[tid >> 1] + (tid & 1)];
-
-  const int ca = tid >> 4;                     // centre slot served by this thread in the per-centre output step
-  if (tid == 0) lds.chunk[0] = (int)atomicAdd(A.tile_counter, (unsigned)A.tchunk);
-  __syncthreads();
-  int par = 0, cpar = 0, ck = 0;
-  int cbase = __builtin_amdgcn_readfirstlane(lds.chunk[0]);
-
-  for (;;) {
-    const int tile = cbase + ck;
-    if (tile >= ntiles) break;
-    int claimed = 0;
-    if (ck == 0 && tid == 0) claimed = (int)atomicAdd(A.tile_counter, (unsigned)A.tchunk);
-    const int a0 = A.tile_a0[tile], a1 = A.tile_a0[tile + 1], e0 = A.tile_e0[tile], e1 = A.tile_e0[tile + 1];
-    const int na = a1 - a0;
-    par ^= 1;
-    int *const aoffp = lds.aoff[par];
-    // ---------------- tile inputs, geometry and two-body embedding, both groups ----------------
-    bool valid[2];
-    float rx[2], ry[2], rz[2], inv[2], nx[2], ny[2], nz[2], fc[2], dfdd[2], Y1[2], Y2[2], Y3[2];
-    int aloc[2], ti[2], tj[2], jat[2], eidx[2];
-    float *st[2];
-    const float *envrow[2], *denvrow[2];
-    int c_i = 0, c_t = 0;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int s = wave * 32 + 16 * q + j;
-      const int e = e0 + s;
-      eidx[q] = e;
-      valid[q] = e < e1;
-      rx[q] = 1.f; ry[q] = 0.f; rz[q] = 0.f; aloc[q] = 0; ti[q] = 0; tj[q] = 0; jat[q] = 0;
-      if (valid[q]) {
-        rx[q] = A.rvec[3 * (size_t)e]; ry[q] = A.rvec[3 * (size_t)e + 1]; rz[q] = A.rvec[3 * (size_t)e + 2];
-        aloc[q] = A.e_ii[e] - a0;
-        jat[q] = A.e_j[e];
-        const int tt = A.e_tt[e];
-        ti[q] = tt >> 4; tj[q] = tt & 15;
-      }
-      st[q] = lds.stage + s * STG_LD;
-    }
-    if (ca < na) { const int2 ci = A.centre[a0 + ca]; c_i = ci.x; c_t = ci.y; }
-    if (tid <= na) aoffp[tid] = A.eoff[a0 + tid] - e0;
-    f32x4 x[2][4];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const float d = sqrtf(rx[q] * rx[q] + ry[q] * ry[q] + rz[q] * rz[q]);
-      inv[q] = 1.f / d;
-      nx[q] = rx[q] * inv[q]; ny[q] = ry[q] * inv[q]; nz[q] = rz[q] * inv[q];
-      const float rc = A.T <= 4 ? lds.rc[ti[q] * A.T + tj[q]] : (float)A.rcut[ti[q] * A.T + tj[q]];
-      const float xx = d / rc;
-      float dfc_dx;
-      cutoff_poly(A.p, xx, fc[q], dfc_dx);
-      if (!valid[q]) { fc[q] = 0.f; dfc_dx = 0.f; }
-      dfdd[q] = dfc_dx / rc;
-      Y1[q] = C_S3 * ny[q]; Y2[q] = C_S3 * nz[q]; Y3[q] = C_S3 * nx[q];
-      envrow[q] = lds.env[0] + aloc[q] * ENV_LD;
-      denvrow[q] = lds.denv + aloc[q] * ENV_LD;
-      // x0(d; type pair) from the per-pair cubic spline table, d x0 / dd saved for the backward pass (see k_fused)
-      const float tb_invh = (float)A.tb_nk / rc;
-      const float sft = d * tb_invh;
-      const int kq = min((int)sft, A.tb_nk - 1);
-      const float tb_t = sft - (float)kq;
-      const float *tb_ent = Wb + A.o_tbtab + ((size_t)(ti[q] * A.T + tj[q]) * A.tb_nk + kq) * 256 + 4 * g;
-      const float vm = (valid[q] && xx < 1.f) ? 1.f : 0.f;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const f32x4 c0 = *(const f32x4 *)(tb_ent + (t * 4 + 0) * 16), c1 = *(const f32x4 *)(tb_ent + (t * 4 + 1) * 16);
-        const f32x4 c2 = *(const f32x4 *)(tb_ent + (t * 4 + 2) * 16), c3 = *(const f32x4 *)(tb_ent + (t * 4 + 3) * 16);
-        x[q][t] = (c0 + tb_t * (c1 + tb_t * (c2 + tb_t * c3))) * vm;
-        bstore(SB, v16, (q * RG + R_Z1TB() + t) * ROW * 4, (c1 + tb_t * (2.f * c2 + (3.f * tb_t) * c3)) * (vm * tb_invh));
-      }
-    }
-    PHASE(PH_TB);
-    // ---------------- tensor embedding weights: w0 to scratch (backward) and to the park rows 0..3 of each group ----------------
-    {
-      f32x4 w0[2][4];
-      EpiSavePark ep[2] = {EpiSavePark{{SB, R_W0(), v16}, pk0, 0, lane}, EpiSavePark{{SB, RG + R_W0(), v16}, pk1, 0, lane}};
-      lin2<4, 4, false, 0>(WB, wp, x, w0, v16, ring, ep);
-    }
-    if (ck == 0 && tid == 0) lds.chunk[cpar ^ 1] = claimed;
-    __syncthreads();          // aoff visible; previous tile's LDS users done
-    PHASE(PH_EMB);
-
-    // ---------------- layers, forward ----------------
-    f32x4 zr[2][2];
-#pragma unroll
-    for (int kk = 0; kk < NL; ++kk) {
-      const bool last = (kk == NL - 1);
-      const int RL = R_LAYER(kk);
-      float *const envk = lds.env[kk];
-      {
-        f32x4 om[2][4];
-        EpiSave ep[2] = {EpiSave{SB, RL + 0, v16}, EpiSave{SB, RG + RL + 0, v16}};
-        lin2<4, 4, false, 0>(WB, wp, x, om, v16, ring, ep);
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            float *sp = st[q] + 16 * t + 4 * g;
-            *(f32x4 *)(sp) = om[q][t];
-            *(f32x4 *)(sp + 32) = om[q][2 + t] * Y1[q];
-            *(f32x4 *)(sp + 64) = om[q][2 + t] * Y2[q];
-            *(f32x4 *)(sp + 96) = om[q][2 + t] * Y3[q];
-          }
-        __syncthreads();
-        reduce_stage_g(lds, aoffp, envk, na, A.cenv, tid);
-        __syncthreads();
-      }
-      PHASE(PH_ENV);
-      // tensor product, both groups
-      f32x4 Vp[2][4][2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const float *pk = q ? pk1 : pk0;
-        f32x4 V[4][2];
-        if (kk == 0) {
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const f32x4 w1 = park_load(pk, 2 + t, lane);
-            V[0][t] = park_load(pk, t, lane);
-            V[1][t] = w1 * Y1[q]; V[2][t] = w1 * Y2[q]; V[3][t] = w1 * Y3[q];
-          }
-        } else {
-#pragma unroll
-          for (int lm = 0; lm < 4; ++lm)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) V[lm][t] = park_load(pk, 2 * lm + t, lane);
-        }
-        const float *en = envrow[q] + kk * (MAXA * ENV_LD);
-        const float *tp = lds.tp[kk];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int b = 16 * t + 4 * g;
-          const f32x4 e0v = *(const f32x4 *)(en + b), e1v = *(const f32x4 *)(en + 32 + b), e2v = *(const f32x4 *)(en + 64 + b),
-                      e3v = *(const f32x4 *)(en + 96 + b);
-          const f32x4 v0 = V[0][t], v1 = V[1][t], v2 = V[2][t], v3 = V[3][t];
-          Vp[q][0][t] = *(const f32x4 *)(tp + b) * v0 * e0v + *(const f32x4 *)(tp + 32 + b) * (v1 * e1v + v2 * e2v + v3 * e3v);
-          if (!last) {
-            const f32x4 p2 = *(const f32x4 *)(tp + 64 + b), p3 = *(const f32x4 *)(tp + 96 + b), c4 = *(const f32x4 *)(tp + 128 + b);
-            const f32x4 p2v0 = p2 * v0, p3e0 = p3 * e0v;
-            Vp[q][1][t] = p2v0 * e1v + p3e0 * v1 + c4 * (v2 * e3v - v3 * e2v);
-            Vp[q][2][t] = p2v0 * e2v + p3e0 * v2 + c4 * (v3 * e1v - v1 * e3v);
-            Vp[q][3][t] = p2v0 * e3v + p3e0 * v3 + c4 * (v1 * e2v - v2 * e1v);
-          }
-        }
-      }
-      PHASE(PH_TP);
-      // channel mixing -> V^{kk+1}: saved in the next layer's VIN rows and parked
-      if (!last) {
-#pragma unroll
-        for (int lm = 0; lm < 4; ++lm) {
-          f32x4 in2[2][2], o2[2][2];
-#pragma unroll
-          for (int q = 0; q < 2; ++q) { in2[q][0] = Vp[q][lm][0]; in2[q][1] = Vp[q][lm][1]; }
-          EpiSavePark ep[2] = {EpiSavePark{{SB, R_LAYER(kk + 1) + 16 + 2 * lm, v16}, pk0, 2 * lm, lane},
-                               EpiSavePark{{SB, RG + R_LAYER(kk + 1) + 16 + 2 * lm, v16}, pk1, 2 * lm, lane}};
-          if (lm == 0) lin2<2, 2, false, 0>(WB, wp, in2, o2, v16, ring, ep);
-          else if (lm == 1) lin2<2, 2, false, 1>(WB, wp, in2, o2, v16, ring, ep);
-          else if (lm == 2) lin2<2, 2, false, 2>(WB, wp, in2, o2, v16, ring, ep);
-          else lin2<2, 2, false, 3>(WB, wp, in2, o2, v16, ring, ep);
-        }
-      }
-      PHASE(PH_MIX);
-      // latent MLP
-      {
-        f32x4 cat[2][6], z[2][4], z2[2][4];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          cat[q][0] = x[q][0]; cat[q][1] = x[q][1]; cat[q][2] = x[q][2]; cat[q][3] = x[q][3]; cat[q][4] = Vp[q][0][0]; cat[q][5] = Vp[q][0][1];
-        }
-        {
-          EpiSiluSaveD ep[2] = {EpiSiluSaveD{SB, RL + 4, v16}, EpiSiluSaveD{SB, RG + RL + 4, v16}};
-          lin2<6, 4, false, 0>(WB, wp, cat, z, v16, ring, ep);
-        }
-        {
-          EpiSiluSaveD ep[2] = {EpiSiluSaveD{SB, RL + 8, v16}, EpiSiluSaveD{SB, RG + RL + 8, v16}};
-          lin2<4, 4, false, 0>(WB, wp, z, z2, v16, ring, ep);
-        }
-        const float ra = lds.res[kk][0], rb = lds.res[kk][1];
-        if (!last) {
-          f32x4 xn[2][4];
-          EpiResidual<4> ep[2] = {EpiResidual<4>{{SB, RL + 12, v16}, x[0], ra, rb * fc[0]}, EpiResidual<4>{{SB, RG + RL + 12, v16}, x[1], ra, rb * fc[1]}};
-          lin2<4, 4, false, 0>(WB, wp, z2, xn, v16, ring, ep);
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) x[q][t] = xn[q][t];
-        } else {
-          // last layer: the read-out's first linear folded in (see k_fused)
-          f32x4 za[2][2], up[2][2];
-          {
-            EpiSave ep[2] = {EpiSave{SB, RL + 12, v16}, EpiSave{SB, RG + RL + 12, v16}};
-            lin2<4, 2, false, 0>(WB, wp, z2, up, v16, ring, ep);
-          }
-          {
-            EpiNone ep[2];
-            lin2<4, 2, false, 0>(WB, wp, x, za, v16, ring, ep);
-          }
-#pragma unroll
-          for (int q = 0; q < 2; ++q) { zr[q][0] = ra * za[q][0] + (rb * fc[q]) * up[q][0]; zr[q][1] = ra * za[q][1] + (rb * fc[q]) * up[q][1]; }
-        }
-      }
-      PHASE(PH_LAT);
-    }
-
-    // ---------------- read-out ----------------
-    f32x4 upre[2][4], zt[2][4], w0h[2][2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) upre[q][t] = bload(SB, v16, (q * RG + R_LAYER(NL - 1) + 12 + t) * ROW * 4);
-      load_rows<4>(SB, q * RG + R_LAYER(NL - 1) + 8, zt[q], v16);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 wo1[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) wo1[t] = *(const f32x4 *)(Wb + A.o_out1 + 16 * t + 4 * g);
-    float eps[2];
-    f32x4 dx[2][4];
-    f32x4 dzr[2][2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      float e = 0.f;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) e += silu1(zr[q][t][r]) * wo1[t][r];
-      eps[q] = gsum(e);
-      // =========================== backward ===========================
-      const float deps = valid[q] ? lds.scale[ti[q]] * A.cenv * A.bscale : 0.f;      // scaled by a power of two: float16 has no exponent range to spare (fused_h.h)
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dzr[q][t][r] = deps * wo1[t][r] * dsilu1(zr[q][t][r]);
-    }
-    {
-      EpiNone ep[2];
-      lin2<2, 4, false, 0>(WB, wp, dzr, dx, v16, ring, ep);
-    }
-    float dfc_part[2] = {0.f, 0.f}, dY1[2] = {0.f, 0.f}, dY2[2] = {0.f, 0.f}, dY3[2] = {0.f, 0.f};
-    PHASE(PH_OUT);
-
-#pragma unroll
-    for (int kk = NL - 1; kk >= 0; --kk) {
-      const bool last = (kk == NL - 1);
-      const int RL = R_LAYER(kk);
-      f32x4 dVp[2][4][2], Vk[2][4][2], W0b[2][4], om[2][4];
-      {
-        f32x4 du[2][4], dh[2][4], zt1[2][4];
-        const float ra = lds.res[kk][0], rb = lds.res[kk][1];
-        if (!last) {
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            f32x4 accv = upre[q][0] * dx[q][0];
-#pragma unroll
-            for (int t = 1; t < 4; ++t) accv += upre[q][t] * dx[q][t];
-            const float rbfc = rb * fc[q];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { du[q][t] = rbfc * dx[q][t]; dx[q][t] = ra * dx[q][t]; }
-            dfc_part[q] += rb * ((accv[0] + accv[1]) + (accv[2] + accv[3]));
-            load_rows<4>(SB, q * RG + RL + 4, zt1[q], v16);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          EpiMulRows<4> ep[2] = {EpiMulRows<4>{zt[0]}, EpiMulRows<4>{zt[1]}};
-          lin2<4, 4, false, 0>(WB, wp, du, dh, v16, ring, ep);
-        } else {
-          f32x4 du2[2][2];
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            const f32x4 accv = upre[q][0] * dzr[q][0] + upre[q][1] * dzr[q][1];
-            const float rbfc = rb * fc[q];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) du2[q][t] = rbfc * dzr[q][t];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) dx[q][t] = ra * dx[q][t];
-            dfc_part[q] += rb * ((accv[0] + accv[1]) + (accv[2] + accv[3]));
-            load_rows<4>(SB, q * RG + RL + 4, zt1[q], v16);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          EpiMulRows<4> ep[2] = {EpiMulRows<4>{zt[0]}, EpiMulRows<4>{zt[1]}};
-          lin2<2, 4, false, 0>(WB, wp, du2, dh, v16, ring, ep);
-        }
-        // V^{kk} (input of this layer's tensor product) requested under the MFMAs that follow
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          if (kk > 0) {
-#pragma unroll
-            for (int lm = 0; lm < 4; ++lm) load_rows<2>(SB, q * RG + RL + 16 + 2 * lm, Vk[q][lm], v16);
-          } else load_rows<4>(SB, q * RG + R_W0(), W0b[q], v16);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        {
-          EpiMulRows<4> ep[2] = {EpiMulRows<4>{zt1[0]}, EpiMulRows<4>{zt1[1]}};
-          lin2<4, 4, false, 0>(WB, wp, dh, du, v16, ring, ep);
-        }
-        f32x4 dcat[2][6];
-        {
-          EpiNone ep[2];
-          lin2<4, 6, false, 0>(WB, wp, du, dcat, v16, ring, ep);
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) dx[q][t] += dcat[q][t];
-          dVp[q][0][0] = dcat[q][4]; dVp[q][0][1] = dcat[q][5];
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        if (kk == 0) {
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            Vk[q][0][t] = W0b[q][t];
-            Vk[q][1][t] = W0b[q][2 + t] * Y1[q]; Vk[q][2][t] = W0b[q][2 + t] * Y2[q]; Vk[q][3][t] = W0b[q][2 + t] * Y3[q];
-          }
-        }
-        load_rows<4>(SB, q * RG + RL + 0, om[q], v16);             // omega of this layer: used after the gradient reduction
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      PHASE(PH_BLAT);
-      if (!last) {
-#pragma unroll
-        for (int lm = 0; lm < 4; ++lm) {
-          f32x4 in2[2][2], o2[2][2];
-          in2[0][0] = park_load(pk0, 2 * lm, lane); in2[0][1] = park_load(pk0, 2 * lm + 1, lane);
-          in2[1][0] = park_load(pk1, 2 * lm, lane); in2[1][1] = park_load(pk1, 2 * lm + 1, lane);
-          EpiNone ep[2];
-          if (lm == 0) lin2<2, 2, false, 0>(WB, wp, in2, o2, v16, ring, ep);
-          else if (lm == 1) lin2<2, 2, false, 1>(WB, wp, in2, o2, v16, ring, ep);
-          else if (lm == 2) lin2<2, 2, false, 2>(WB, wp, in2, o2, v16, ring, ep);
-          else lin2<2, 2, false, 3>(WB, wp, in2, o2, v16, ring, ep);
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            if (lm == 0) { dVp[q][0][0] += o2[q][0]; dVp[q][0][1] += o2[q][1]; }
-            else { dVp[q][lm][0] = o2[q][0]; dVp[q][lm][1] = o2[q][1]; }
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      PHASE(PH_BMIX);
-      // tensor-product backward: dV (w.r.t. V^{kk}, parked) and the per-edge environment gradient
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        float *const pk = q ? pk1 : pk0;
-        const float *en = envrow[q] + kk * (MAXA * ENV_LD);
-        const float *tp = lds.tp[kk];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int b = 16 * t + 4 * g;
-          const f32x4 e0v = *(const f32x4 *)(en + b), e1v = *(const f32x4 *)(en + 32 + b), e2v = *(const f32x4 *)(en + 64 + b),
-                      e3v = *(const f32x4 *)(en + 96 + b);
-          const f32x4 v0 = Vk[q][0][t], v1 = Vk[q][1][t], v2 = Vk[q][2][t], v3 = Vk[q][3][t];
-          const f32x4 g0 = dVp[q][0][t];
-          const f32x4 q0 = *(const f32x4 *)(tp + b) * g0, q1 = *(const f32x4 *)(tp + 32 + b) * g0;
-          f32x4 a0v = q0 * e0v, a1v = q1 * e1v, a2v = q1 * e2v, a3v = q1 * e3v;       // dV
-          f32x4 b0v = q0 * v0, b1v = q1 * v1, b2v = q1 * v2, b3v = q1 * v3;           // denv_e
-          if (!last) {
-            const f32x4 g1 = dVp[q][1][t], g2 = dVp[q][2][t], g3 = dVp[q][3][t];
-            const f32x4 q2 = *(const f32x4 *)(tp + 64 + b), q3 = *(const f32x4 *)(tp + 96 + b), c4 = *(const f32x4 *)(tp + 128 + b);
-            const f32x4 q3e0 = q3 * e0v, q2v0 = q2 * v0;
-            a0v += q2 * (e1v * g1 + e2v * g2 + e3v * g3);
-            b0v += q3 * (v1 * g1 + v2 * g2 + v3 * g3);
-            a1v += q3e0 * g1 + c4 * (e2v * g3 - e3v * g2);
-            a2v += q3e0 * g2 + c4 * (e3v * g1 - e1v * g3);
-            a3v += q3e0 * g3 + c4 * (e1v * g2 - e2v * g1);
-            b1v += q2v0 * g1 + c4 * (g2 * v3 - g3 * v2);
-            b2v += q2v0 * g2 + c4 * (g3 * v1 - g1 * v3);
-            b3v += q2v0 * g3 + c4 * (g1 * v2 - g2 * v1);
-          }
-          float *sp = st[q] + b;
-          *(f32x4 *)(sp) = b0v; *(f32x4 *)(sp + 32) = b1v; *(f32x4 *)(sp + 64) = b2v; *(f32x4 *)(sp + 96) = b3v;
-          park_store(pk, 0 + t, a0v, lane);
-          park_store(pk, 2 + t, a1v, lane);
-          park_store(pk, 4 + t, a2v, lane);
-          park_store(pk, 6 + t, a3v, lane);
-        }
-      }
-      __syncthreads();
-      reduce_stage_g(lds, aoffp, lds.denv, na, A.cenv, tid);
-      __syncthreads();
-      __builtin_amdgcn_sched_barrier(0);
-      PHASE(PH_BTP);
-      {
-        f32x4 dom[2][4];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const int b = 16 * t + 4 * g;
-            const f32x4 d0 = *(const f32x4 *)(denvrow[q] + b), d1 = *(const f32x4 *)(denvrow[q] + 32 + b), d2 = *(const f32x4 *)(denvrow[q] + 64 + b),
-                        d3 = *(const f32x4 *)(denvrow[q] + 96 + b);
-            dom[q][t] = d0;
-            dom[q][2 + t] = d1 * Y1[q] + d2 * Y2[q] + d3 * Y3[q];
-            const f32x4 p1 = d1 * om[q][2 + t], p2 = d2 * om[q][2 + t], p3 = d3 * om[q][2 + t];
-            dY1[q] += (p1[0] + p1[1]) + (p1[2] + p1[3]); dY2[q] += (p2[0] + p2[1]) + (p2[2] + p2[3]); dY3[q] += (p3[0] + p3[1]) + (p3[2] + p3[3]);
-          }
-          if (kk > 0) {                                                      // next iteration's u and z2 rows
-            load_rows<4>(SB, q * RG + R_LAYER(kk - 1) + 12, upre[q], v16);
-            load_rows<4>(SB, q * RG + R_LAYER(kk - 1) + 8, zt[q], v16);
-          } else {                                                           // d x0 / dd rows of the two-body table, l = 1 embedding weights
-            load_rows<4>(SB, q * RG + R_Z1TB(), zt[q], v16);
-            load_rows<2>(SB, q * RG + R_W0() + 2, w0h[q], v16);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        EpiNone ep[2];
-        lin2<4, 4, true, 0>(WB, wp, dom, dx, v16, ring, ep);
-      }
-      PHASE(PH_BENV);
-    }
-    // ---------------- embedding backward ----------------
-    {
-      f32x4 dw0[2][4];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const float *pk = q ? pk1 : pk0;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const f32x4 d0 = park_load(pk, 0 + t, lane), d1 = park_load(pk, 2 + t, lane), d2 = park_load(pk, 4 + t, lane), d3 = park_load(pk, 6 + t, lane);
-          dw0[q][t] = d0;
-          dw0[q][2 + t] = d1 * Y1[q] + d2 * Y2[q] + d3 * Y3[q];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { dY1[q] += d1[r] * w0h[q][t][r]; dY2[q] += d2[r] * w0h[q][t][r]; dY3[q] += d3[r] * w0h[q][t][r]; }
-        }
-      }
-      EpiNone ep[2];
-      lin2<4, 4, true, 0>(WB, wp, dw0, dx, v16, ring, ep);
-      wp = A.o_stream;                                                    // last linear of the tile
-    }
-    PHASE(PH_BEMB);
-    // ---------------- two-body embedding and geometry backward, outputs ----------------
-    {
-      float w6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        f32x4 accv = dx[q][0] * zt[q][0];
-#pragma unroll
-        for (int t = 1; t < 4; ++t) accv += dx[q][t] * zt[q][t];
-        const float dd_part = (accv[0] + accv[1]) + (accv[2] + accv[3]);
-        const float ibs = A.ibscale;
-        const float dfc_tot = gsum(dfc_part[q]) * ibs;
-        const float dd = dfc_tot * dfdd[q] + gsum(dd_part) * ibs;
-        const float y1 = gsum(dY1[q]) * ibs, y2 = gsum(dY2[q]) * ibs, y3 = gsum(dY3[q]) * ibs;
-        const float Gx = C_S3 * y3, Gy = C_S3 * y1, Gz = C_S3 * y2;
-        const float gn = Gx * nx[q] + Gy * ny[q] + Gz * nz[q];
-        const float gx = dd * nx[q] + (Gx - gn * nx[q]) * inv[q];
-        const float gy = dd * ny[q] + (Gy - gn * ny[q]) * inv[q];
-        const float gz = dd * nz[q] + (Gz - gn * nz[q]) * inv[q];
-        if (A.dbg && valid[q] && g == 0) {
-          float *dp = A.dbg + 8 * (size_t)eidx[q];
-          dp[0] = gx; dp[1] = gy; dp[2] = gz; dp[3] = dd; dp[4] = dfc_tot; dp[5] = y1; dp[6] = y2; dp[7] = y3;
-        }
-        const float m = valid[q] ? 1.f : 0.f;
-        if (valid[q] && !(fabsf(gx) + fabsf(gy) + fabsf(gz) + fabsf(eps[q]) < 3.0e38f)) *A.err = 1;      // inf / NaN: an operand left float16's range
-        if (g == 0) {
-          st[q][0] = m * gx; st[q][1] = m * gy; st[q][2] = m * gz; st[q][3] = m * eps[q];
-          if (valid[q]) {
-            atomicAdd(&A.f[3 * (size_t)jat[q]], -(double)gx);
-            atomicAdd(&A.f[3 * (size_t)jat[q] + 1], -(double)gy);
-            atomicAdd(&A.f[3 * (size_t)jat[q] + 2], -(double)gz);
-          }
-        }
-        w6[0] += -m * rx[q] * gx; w6[1] += -m * ry[q] * gy; w6[2] += -m * rz[q] * gz;
-        w6[3] += -m * 0.5f * (rx[q] * gy + ry[q] * gx); w6[4] += -m * 0.5f * (rx[q] * gz + rz[q] * gx); w6[5] += -m * 0.5f * (ry[q] * gz + rz[q] * gy);
-      }
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) w6[c] += __shfl_xor(w6[c], off, 64);
-      }
-      if (lane < 6) {
-        const float mine = lane == 0 ? w6[0] : lane == 1 ? w6[1] : lane == 2 ? w6[2] : lane == 3 ? w6[3] : lane == 4 ? w6[4] : w6[5];
-        lds.virw[wave][lane] += (double)mine;
-      }
-    }
-    __syncthreads();
-    {
-      const int col = tid & 3, part = (tid >> 2) & 3;
-      float sum = 0.f;
-      if (ca < na)
-        for (int sl = aoffp[ca] + part; sl < aoffp[ca + 1]; sl += 4) sum += lds.stage[sl * STG_LD + col];
-      sum += __shfl_xor(sum, 4, 64);
-      sum += __shfl_xor(sum, 8, 64);
-      if (ca < na && part == 0) {
-        if (col < 3) atomicAdd(&A.f[3 * (size_t)c_i + col], (double)sum);
-        else {
-          const float ei = lds.scale[c_t] * (sum * A.cenv) + lds.shift[c_t];
-          if (A.eatom) A.eatom[c_i] = (double)ei;
-          lds.eacc[ca] += (double)ei;
-        }
-      }
-    }
-    PHASE(PH_FIN);
-    if (++ck == A.tchunk) { ck = 0; cpar ^= 1; cbase = __builtin_amdgcn_readfirstlane(lds.chunk[cpar]); }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    for (int a = 0; a < MAXA; ++a) acc_part += lds.eacc[a];
-  } else if (tid >= 64 && tid < 70) {
-    for (int w = 0; w < 4; ++w) acc_part += lds.virw[w][tid - 64];
-  }
-  if (PROF && lane == 0) {
-#pragma unroll
-    for (int k = 0; k < PH_N; ++k) atomicAdd((unsigned long long *)&A.prof[k], (unsigned long long)pacc[k]);
-  }
-  if (tid == 0) A.partial[7 * (size_t)blockIdx.x] = acc_part;
-  if (tid >= 64 && tid < 70) A.partial[7 * (size_t)blockIdx.x + 1 + (tid - 64)] = acc_part;
-}
-
-void fused_launch_g2(bool prof, int grid, hipStream_t s, const FusedArgs &A) {
-  if (prof && A.NL == 2) { hipLaunchKernelGGL((k_fused_g2<true, 2>), dim3(grid), dim3(256), 0, s, A); return; }
-  if (A.NL == 1) hipLaunchKernelGGL((k_fused_g2<false, 1>), dim3(grid), dim3(256), 0, s, A);
-  else if (A.NL == 2) hipLaunchKernelGGL((k_fused_g2<false, 2>), dim3(grid), dim3(256), 0, s, A);
-  else hipLaunchKernelGGL((k_fused_g2<false, 3>), dim3(grid), dim3(256), 0, s, A);
-}
-#endif
-
 // ---------------------------------------------------------------------------- the bf16-split instances (fused_bf.o)
 void fused_launch_bf16(int nw, bool prof, int arith, bool tbt, int grid, hipStream_t s, const FusedArgs &A);
 void fused_launch_f16(int nw, bool prof, int grid, hipStream_t s, const FusedArgs &A);
@@ -1520,7 +914,6 @@ struct FusedState {
   bool ready = false, prof_on = false, dbg_on = false, clk_on = false;
   bool tbt = true;             // two-body embedding from the spline table (default) or evaluated as an MLP (option fused_tb=mlp)
   int arith = 0;               // 0: f32-input MFMA; 1: bf16x3 (option fused_arith=bf16x3 / AHIP_FUSED_ARITH=b3); 2: tf32eq (two-term bf16 split; fused_arith=auto picks it when the model file says allow_tf32 = 1); 3: f16x2 (fused_h.h)
-  int groups = 1;              // 2: k_fused_g2 (two edge groups per weight fragment, f16x2 + table only; option fused_groups / AHIP_FUSED_GROUPS)
   DevBuf prof, dbg;
   int ncu = 256;
   int force_nw = 0;            // AHIP_FUSED_NW=4|8 pins the workgroup shape (A/B measurements)
@@ -1608,11 +1001,6 @@ static void fused_prepare(Model &m) {
     st.tbt = mode != "mlp";
   }
   if (st.arith == 3 && !st.tbt) st.arith = 0;        // the f16x2 instances exist with the tabulated two-body embedding only
-  {
-    const char *ge = std::getenv("AHIP_FUSED_GROUPS");
-    const std::string gs = ge ? ge : m.opt_fused_groups;
-    st.groups = (st.arith == 3 && gs == "2") ? 2 : 1;
-  }
   const bool b3 = st.arith == 1 || st.arith == 2, tbt = st.tbt;
   const int nterm = st.arith == 1 ? 3 : 2;
   bool h_range_ok = true;
@@ -1742,14 +1130,7 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
   fused_poll_alarm(m);       // raised by an EARLIER evaluation (nobody waits for the kernel): its forces were not finite
   if (st.prof_on || st.clk_on || st.dbg_on) edges_counts(m);      // instrumented runs size their buffers / reports from the counts
   int nw = 0;                                   // 0: decided on the device
-  const bool g2 = st.groups == 2;               // k_fused_g2: one shape (128 slots / 12 centres) for every degree <= 128
-  if (g2) {
-    if (!m.counts_pending && m.last_max_deg > MAX_TILE_SLOTS) {
-      if (why) *why = "an atom has " + std::to_string(m.last_max_deg) + " edges (> 128 per tile)";
-      return false;
-    }
-    nw = 8;                                     // tile packing of the 128-slot shape
-  } else if (!m.counts_pending) {
+  if (!m.counts_pending) {
     if (m.last_max_deg > MAX_TILE_SLOTS) {
       if (why) *why = "an atom has " + std::to_string(m.last_max_deg) + " edges (> 128 per tile)";
       return false;
@@ -1811,7 +1192,7 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
   // persistent workgroups fill every CU; reserve_wgs leaves a few slots free so that the exchange kernels of another stream
   // (ghost pack / unpack, RCCL send / recv) can be scheduled while this kernel runs (md.py, overlapped schedule)
   const int grid4 = std::max(1, st.ncu * 2 - m.reserve_wgs), grid8 = std::max(1, st.ncu - m.reserve_wgs);
-  const int grid = nw == 8 ? grid8 : grid4;     // rows of `partial` that are summed (k_fused_g2: one 4-wave workgroup per CU = grid8)
+  const int grid = nw == 8 ? grid8 : grid4;     // rows of `partial` that are summed
   if (nw == 0) AHIP_CHECK(hipMemsetAsync(st.partial.p, 0, (size_t)grid * 7 * sizeof(double), s));     // the shape that returns at once writes nothing
   {
     StageTimer tm(m, "model_fused", s);
@@ -1828,13 +1209,6 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
       if (nw != 0 && nw != shape) continue;
       const int g = shape == 8 ? grid8 : grid4;
       A.wg_scratch = shape * A.wave_scratch;
-      if (g2) {                                  // four waves, each with the scratch rows of two groups
-        A.wave_scratch = 2 * st.args.wave_scratch; A.wg_scratch = 4 * A.wave_scratch;
-        A.tchunk = (nedges_est / 128 > (long long)g * 256) ? TCHUNK : 1;
-        if (const char *tc = std::getenv("AHIP_TCHUNK")) A.tchunk = std::max(1, std::atoi(tc));
-        fused_launch_g2(st.prof_on, g, s, A);
-        continue;
-      }
       // claims of TCHUNK tiles amortise the counter's round trip; with few tiles per workgroup the last claim decides the makespan
       // (10 648 Si atoms: 4 659 tiles on 512 workgroups = 12 instead of 10 tile times with claims of 4)
       A.tchunk = (nedges_est / (16 * shape) > (long long)g * 256) ? TCHUNK : 1;

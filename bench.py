@@ -178,6 +178,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-ncell", type=int, default=11)
     ap.add_argument("--no-overlap", action="store_true", help="serial ghost exchange (A/B against the overlapped schedule)")
+    ap.add_argument("--eval-only", action="store_true", help="ablation runs only (timing builds that compute wrong forces): time force evaluations at fixed positions instead of NVE steps; the line is NOT a benchmark result")
     ap.add_argument("--force-overlap", action="store_true", help="overlapped three-range schedule even on one rank (A/B: what the schedule itself costs)")
     args = ap.parse_args()
 
@@ -280,8 +281,9 @@ def main():
         use_overlap = t_ov <= t_se                   # identical on every rank (all-reduced times)
         sim.set_overlap(use_overlap)
         autotune = {"overlapped_ms": round(t_ov, 3), "serial_ms": round(t_se, 3), "chosen": "overlapped" if use_overlap else "serial"}
+    step = sim.compute_forces if args.eval_only else sim.step
     for _ in range(args.warmup):
-        sim.step()
+        step()
 
     nrebuild0 = sim.nrebuild
     # Stage timings: the library records HIP events on its launch stream around every stage of every call and nobody waits for them
@@ -294,7 +296,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sim.step()
+        step()
     barrier()
     dt = time.perf_counter() - t0
     stage_sum, stage_cnt = model.timings_and_counts()
@@ -334,7 +336,14 @@ def main():
         value = natoms * args.steps / dt
         used_path = model.last_path
         # ---- roofline of the dominant kernel -------------------------------------------------
-        tb_tab = used_path == "fused_f32" and os.environ.get("AHIP_FUSED_TB", "table") != "mlp"
+        tb_tab = used_path.startswith("fused_") and os.environ.get("AHIP_FUSED_TB", "table") != "mlp"
+        # arithmetic of the fused kernels' dense contractions, by kernel path: every one but tf32eq is float32 or float32-equivalent
+        ARITH = {"fused_f32": "f32-input MFMA (v_mfma_f32_16x16x4_f32): exact float32 fmaf chains",
+                 "fused_f16x2": "f16x2: every float32 operand as two float16 terms (round-to-nearest, remainder scaled by 2^11: 22 bits + sign), three "
+                                "v_mfma_f32_16x16x32_f16 products per float32 product, float32 accumulate; backward pass scaled by a power of two; "
+                                "float32-equivalent: max|dF| vs the float64 oracle as the f32 form (parity_vs_oracle; tests/test_arith_emulation.py)",
+                 "fused_bf16x3": "bf16x3: exact three-way bf16 split of both operands, six bf16-MFMA products, float32 accumulate; float32-equivalent",
+                 "fused_tf32eq": "two-term bf16 split, three products: TF32-class, only for model files with allow_tf32 = 1"}
         # ALGORITHMIC flops = the model's dense contractions (SURVEY 8d / DESIGN 4.2), whatever the kernel does with them;
         # the fused kernels' tabulated two-body embedding executes fewer: frac_executed is priced on those.
         flops_per_edge = 2.0 * model_macs_per_edge(cfg) * 2.0       # 2 flop per MAC x (forward + input-gradient backward)
@@ -358,6 +367,11 @@ def main():
                     "flops_per_edge": flops_per_edge, "executed_flops_per_edge": executed_flops_per_edge,
                     "frac_executed": round(ach / 157.3 * executed_flops_per_edge / flops_per_edge, 4),
                     "two_body": "table" if tb_tab else "mlp",
+                    "arithmetic": ARITH.get(used_path, "float32 (layer-at-a-time kernels)"),
+                    # `peak` stays the f32-input MFMA peak for every float32-equivalent arithmetic (the yardstick of VERDICT r04 #1: the model's float32
+                    # contractions per second against what the float32 matrix path could deliver); on the f16 matrix cores (2 500 TFLOP/s dense) the f16x2
+                    # form executes three products per float32 product:
+                    "f16_matrix_core_frac": (round(3.0 * ach * executed_flops_per_edge / flops_per_edge / 2500.0, 4) if used_path == "fused_f16x2" else None),
                     # padding tax of the tile packing: edge slots that held an edge / slots of all tiles (one full evaluation)
                     "slots_used": slots_used, "slots_total": slots_total, "slot_occupancy": (round(slots_used / slots_total, 4) if slots_total else None)}
             if traffic:
@@ -389,7 +403,7 @@ def main():
             cpu, parity = cpu_baseline_and_parity(lib, args.config, dev_index, args.cpu_sample_ncell, args.path)
             max_df = parity["max_abs_dF"]
         out = {
-            "metric": "atom_steps_per_sec", "value": round(value, 1), "unit": "atom-steps/s", "n_gpus": world,
+            "metric": "atom_steps_per_sec" if not args.eval_only else "atom_evaluations_per_sec (ablation run, not the benchmark)", "value": round(value, 1), "unit": "atom-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{('BASELINE config ' + str(args.config)) if args.config <= 5 else 'extra config 6 (not in BASELINE.json)'}: {wl['name']}, r_max {cfg['r_max']} A + skin 1.0 A, NVE dt=1 fs",
@@ -535,6 +549,9 @@ def cpu_baseline_and_parity(lib, config, device_index, ncell, path):
                    "protocol": (f"{main_run['warmup']} warm-up + {main_run['reps']} timed evaluations; rule: 3 + 10 when one evaluation takes < 2 s, "
                                 f"else 1 + 3 inside a 25 s budget (this sample: {main_run['ms_model'] / 1e3:.2f} s per evaluation)"),
                    "value_glue_inclusive": round(main_run["nlocal"] / (main_run["ms_total"] * 1e-3), 1),
+                   # ... and the full SURVEY 8d protocol (3 warm-up + 10 timed) on the sample(s) small enough to allow it inside the budget, next to the line above
+                   "full_protocol_runs": [{"sample": r["sample"], "value": round(r["nlocal"] / (r["ms_model"] * 1e-3), 1), "unit": "atom-steps/s", "warmup": r["warmup"],
+                                           "reps": r["reps"], "ms_model": r["ms_model"]} for r in runs if r["warmup"] >= 3 and r["reps"] >= 10],
                    "thread_sweep": {"sample": sweep_label, "runs": sweep},
                    "runs": [{k: r[k] for k in ("sample", "nlocal", "nedges", "threads", "bind", "warmup", "reps", "ms_model", "ms_total")} for r in runs]}
     if cpu is None:

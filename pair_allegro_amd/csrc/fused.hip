@@ -426,7 +426,11 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       const float sft = d * tb_invh;
       const int kq = min((int)sft, A.tb_nk - 1);
       tb_t = sft - (float)kq;
+#ifdef ABL_NOTBGATHER   // timing experiment only (results are wrong): every edge reads the same table entry
+      tb_ent = Wb + A.o_tbtab + 4 * g;
+#else
       tb_ent = Wb + A.o_tbtab + ((size_t)(ti * A.T + tj) * A.tb_nk + kq) * 256 + 4 * g;
+#endif
       const float vm = (valid && xx < 1.f) ? 1.f : 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -476,7 +480,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       f32x4 V[4][2];
       {
         f32x4 om[4];
-        lin<AR, 4, 4, false, 0>(WB, wp, x, om, v16, ring, EpiSave{SB, RL + 0, v16});
+        lin<AR, 4, 4, false, 0>(WB, wp, x, om, v16, ring, EpiSaveFrom2{{SB, RL + 0, v16}});      // rows RL + 2, RL + 3: the l = 1 weights, all the backward pass reads
         // environment sum over the centre's edges
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -651,8 +655,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
           Vk[1][t] = W0b[2 + t] * Y1; Vk[2][t] = W0b[2 + t] * Y2; Vk[3][t] = W0b[2 + t] * Y3;
         }
       }
-      f32x4 om[4];
-      load_rows<4>(SB, RL + 0, om, v16);                     // omega of this layer: used after the gradient reduction
+      f32x4 om1[2];
+      load_rows<2>(SB, RL + 2, om1, v16);                    // omega of this layer, l = 1 part: used after the gradient reduction
       __builtin_amdgcn_sched_barrier(0);
       PHASE(PH_BLAT);
       if (!last) {
@@ -719,7 +723,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
                       d3 = *(const f32x4 *)(denvrow + 96 + b);
           dom[t] = d0;
           dom[2 + t] = d1 * Y1 + d2 * Y2 + d3 * Y3;
-          const f32x4 p1 = d1 * om[2 + t], p2 = d2 * om[2 + t], p3 = d3 * om[2 + t];
+          const f32x4 p1 = d1 * om1[t], p2 = d2 * om1[t], p3 = d3 * om1[t];
           dY1 += (p1[0] + p1[1]) + (p1[2] + p1[3]); dY2 += (p2[0] + p2[1]) + (p2[2] + p2[3]); dY3 += (p3[0] + p3[1]) + (p3[2] + p3[3]);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -813,9 +817,11 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       if (g == 0) {
         st[0] = m * gx; st[1] = m * gy; st[2] = m * gz; st[3] = m * eps;
         if (valid) {
+#ifndef ABL_NOATOM      // timing experiment only (results are wrong): no force scatter to the neighbour atoms
           atomicAdd(&A.f[3 * (size_t)jat], -(double)gx);
           atomicAdd(&A.f[3 * (size_t)jat + 1], -(double)gy);
           atomicAdd(&A.f[3 * (size_t)jat + 2], -(double)gz);
+#endif
         }
       }
       // virial of this wave's 16 edges: butterfly over the slot lanes, lane 0 publishes 6 partials

@@ -23,7 +23,7 @@ static constexpr int TCHUNK = 4;         // tiles per claim of the dynamic tile 
 
 // Switches that exist for timing experiments only and compute WRONG results (or drop a hazard pad) are refused outside an experiment build.
 #if (defined(ABL_NOROWS) || defined(ABL_NOW) || defined(AHIP_NO_STORE_PAD) || defined(ABL_NO_ENVSTAGE) || defined(ABL_NO_FTP) || defined(ABL_NO_LAT) || defined(ABL_NO_MIX) || \
-     defined(ABL_NOSYNC) || defined(ABL_NOREDUCE) || defined(ABL_NOROWST) || defined(ABL_NOROWLD)) && !defined(AHIP_EXPERIMENT_SWITCHES)
+     defined(ABL_NOSYNC) || defined(ABL_NOREDUCE) || defined(ABL_NOROWST) || defined(ABL_NOROWLD) || defined(ABL_NOATOM) || defined(ABL_NOTBGATHER)) && !defined(AHIP_EXPERIMENT_SWITCHES)
 #error "ABL_* / AHIP_NO_STORE_PAD are timing-experiment switches (wrong results): add -DAHIP_EXPERIMENT_SWITCHES, never in the product build"
 #endif
 
@@ -130,6 +130,9 @@ struct EpiSave {             // raw rows to scratch, value unchanged
   __device__ __forceinline__ void tile_done(int ot, const f32x4 &acc) const { bstore(S, v16, (row0 + ot) * ROW * 4, acc); }
   __device__ __forceinline__ float apply(int, int, float v) const { return v; }
   __device__ __forceinline__ void flush(int) const {}
+};
+struct EpiSaveFrom2 : EpiSave {  // raw rows to scratch from output tile 2 on (the backward pass reads only those: omega's l = 1 part), value unchanged
+  __device__ __forceinline__ void tile_done(int ot, const f32x4 &acc) const { if (ot >= 2) EpiSave::tile_done(ot, acc); }
 };
 struct EpiSavePark : EpiSave {  // raw rows to scratch (for the backward pass) and to the LDS park (next layer's forward)
   float *pk; int prow, lane;

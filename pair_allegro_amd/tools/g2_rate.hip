@@ -87,6 +87,112 @@ __global__ void __launch_bounds__(256, OCC) k_rate_h(const float *W, int wbytes,
   if (sum == 12345.678f) out[0] = (long long)pad[lane];
 }
 
+
+// ---- round 5, second probe: weight fragments SHARED by the four waves of a workgroup through an LDS ring filled by LDS-DMA ----
+// Each wave requests a quarter of every step's four fragments (one global_load_lds_dwordx4 = 1 KiB per wave and step, inline asm: hipcc drains every
+// builtin LDS-DMA with vmcnt(0) at the next barrier), three steps ahead; a step = s_waitcnt vmcnt(2) (the wave's own request for this step has
+// landed: in-order completion, two younger requests may stay in flight) + s_barrier (everybody's has) + four ds_read_b128 + the MFMAs of linear_h.
+// Ring: 4 steps x 4 KiB; the slot refilled at step s was read at step s - 1, i.e. before every wave reached this step's barrier.
+__device__ __forceinline__ void hs_dma(const float *wbase, int wo_bytes, unsigned lds_dst, int lane) {
+  const char *src = (const char *)wbase + wo_bytes + lane * 16;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+}
+template <int KS, int NT, bool SPLIT, class Epi>
+__device__ __forceinline__ void linear_hs(const float *wbase, unsigned ring_lds, int uwave, int lane, int &gs, int &wo, const Hop (&in)[KS], f32x4 (&out)[NT], Hop (&outb)[NT / 2], Epi &epi) {
+  constexpr int NP = NT / 2, NSTEP = NP * KS;
+  f32x4 ah[2], ac[2], prev[2];
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    const int p = s / KS, ks = s % KS;
+    if (ks == 0) { ah[0] = ah[1] = ac[0] = ac[1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    u32x4 a[4];
+    {
+      const unsigned ad = ring_lds + (unsigned)(gs & 3) * 4096u + (unsigned)lane * 16u;
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]) : "v"(ad) : "memory");
+    }
+    hs_dma(wbase, wo + uwave * 1024, ring_lds + (unsigned)((gs + 3) & 3) * 4096u + (unsigned)uwave * 1024u, lane);
+    wo += 4096;
+    pin_s(wo);
+    ++gs;
+    pin_s(gs);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        if (m == 0) ac[hh] = mfma_h(a[2 + hh], in[ks].hi, ac[hh]);
+        else if (m == 1) ac[hh] = mfma_h(a[hh], in[ks].lo, ac[hh]);
+        else ah[hh] = mfma_h(a[hh], in[ks].hi, ah[hh]);
+        if (p > 0) {
+          const int idx = ks * 6 + m * 2 + hh, tot = KS * 6, NE = 4;
+          const int e0 = (idx * NE + tot - 1) / tot, e1 = ((idx + 1) * NE + tot - 1) / tot;
+#pragma unroll
+          for (int e = 0; e < NE; ++e)
+            if (e >= e0 && e < e1) {
+              const int th = e / 2, r = 2 * (e % 2), ot = 2 * (p - 1) + th;
+              const f32x2 y = epi_apply2(epi, ot, r, f32x2{prev[th][r], prev[th][r + 1]}, 0);
+              out[ot][r] = y[0]; out[ot][r + 1] = y[1];
+              if (e == 3) {
+                epi.flush(2 * (p - 1));
+                if (SPLIT) outb[p - 1] = split_pair_h(out[2 * (p - 1)], out[2 * (p - 1) + 1]);
+              }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (ks == KS - 1) {
+      const f32x4 r0 = ac[0] * H_LO_INV + ah[0], r1 = ac[1] * H_LO_INV + ah[1];
+      epi.tile_done(2 * p, r0);
+      epi.tile_done(2 * p + 1, r1);
+      if (p == NP - 1) {
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const f32x2 y0 = epi_apply2(epi, 2 * p, r, f32x2{r0[r], r0[r + 1]}, 0), y1 = epi_apply2(epi, 2 * p + 1, r, f32x2{r1[r], r1[r + 1]}, 0);
+          out[2 * p][r] = y0[0]; out[2 * p][r + 1] = y0[1]; out[2 * p + 1][r] = y1[0]; out[2 * p + 1][r + 1] = y1[1];
+        }
+        epi.flush(2 * p);
+        if (SPLIT) outb[p] = split_pair_h(out[2 * p], out[2 * p + 1]);
+      } else { prev[0] = r0; prev[1] = r1; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+template <class EPI>
+__global__ void __launch_bounds__(256, 2) k_rate_hs(const float *W, int wbytes, float *scr, long long *out, int iters) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, v16 = lane * 16;
+  const int uwave = __builtin_amdgcn_readfirstlane(wave);
+  __shared__ float ringl[4 * 1024];               // 4 steps x 4 fragments x 1 KiB
+  __shared__ float pad[16000];                    // ~80 KB per workgroup in all: two workgroups per CU
+  pad[threadIdx.x] = 0.f;
+  __amdgpu_buffer_rsrc_t SB;
+  {
+    unsigned long long b = (unsigned long long)(scr + ((size_t)blockIdx.x * 4 + wave) * 16 * ROW);
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    SB = __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, 16 * ROW * 4, 0x00020000);
+  }
+  const unsigned ring_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void *)ringl;
+  f32x4 x[4], y[4];
+  for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r) x[t][r] = 0.001f * (float)((lane * 7 + t * 4 + r) % 13);
+  Hop xa[2], ya[2];
+  xa[0] = split_pair_h(x[0], x[1]); xa[1] = split_pair_h(x[2], x[3]);
+  int gs = 0, wo = 0;
+  for (int k = 0; k < 3; ++k) { hs_dma(W, wo + uwave * 1024, ring_lds + (unsigned)k * 4096u + (unsigned)uwave * 1024u, lane); wo += 4096; }
+  for (int it = 0; it < iters; ++it) {
+    wo = 3 * 4096;                                  // the stream ends with a copy of its first three steps
+    EPI e0{SB, 0, v16}, e1{SB, 4, v16};
+    linear_hs<2, 4, true>(W, ring_lds, uwave, lane, gs, wo, xa, y, ya, e0);
+    linear_hs<2, 4, true>(W, ring_lds, uwave, lane, gs, wo, ya, x, xa, e1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float sum = 0.f;
+  for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r) sum += x[t][r];
+  if (sum == 12345.678f) out[0] = (long long)pad[lane];
+}
+
 int main() {
   {
     float *d; hipMalloc((void **)&d, 64);
@@ -126,7 +232,7 @@ int main() {
     }
   }
   {
-    const int eb = 32 + RINGH;       // two 64 -> 64 linears of 16 entries + wrap copy
+    const int eb = 32 + 12;          // two 64 -> 64 linears of 16 entries + wrap copy (the LDS-shared ring runs three steps ahead)
     float *dWb, *scrb; long long *out;
     hipMalloc((void **)&dWb, (size_t)eb * 1024); hipMemset(dWb, 0, (size_t)eb * 1024);
     hipMalloc((void **)&scrb, (size_t)1024 * 4 * 16 * ROW * 4);
@@ -151,6 +257,8 @@ int main() {
     run("f16x2 two groups, + 64 live regs, 2 waves/SIMD", 512, 2, k_rate_h<2, 2, 64>);
     run("f16x2 two groups, + 96 live regs, 2 waves/SIMD", 512, 2, k_rate_h<2, 2, 96>);
     run("f16x2 one group, + 96 live regs, 2 waves/SIMD", 512, 1, k_rate_h<1, 2, 96>);
+    run("f16x2 LDS-shared ring (4 waves), silu+save+split, 2 waves/SIMD", 512, 1, k_rate_hs<EpiSiluSaveD>);
+    run("f16x2 LDS-shared ring (4 waves), no epilogue (split only)", 512, 1, k_rate_hs<EpiNoneX>);
     run("f16x2 one group, packed silu, 1 wave/SIMD", 256, 1, k_rate_h<1, 1, 0, EpiSiluSaveD2>);
     run("f16x2 one group, packed silu, 2 waves/SIMD", 512, 1, k_rate_h<1, 2, 0, EpiSiluSaveD2>);
     run("f16x2 two groups, packed silu, 1 wave/SIMD", 256, 2, k_rate_h<2, 1, 0, EpiSiluSaveD2>);

@@ -23,15 +23,19 @@ def averages(tag):
 
 for tag, cfg, natoms, label in ((t4, 4, 1000000, "config4_1M_Si"), (t5, 5, 499125, "config5_500k_water")):
     a = averages(tag)
-    for kern, key in (("k_fused", f"config{cfg}:fused_f32:{natoms}"), ("k_build_edges", f"config{cfg}:k_build_edges:{natoms}")):
+    line = open(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "bench_default.json")).read().strip().splitlines()[-1]
+    path = json.loads(line)["config"]["kernel_path"]          # the entry is keyed by the kernel path the run actually took (fused_f16x2 since round 5)
+    for kern, key in (("k_fused", f"config{cfg}:{path}:{natoms}"), ("k_build_edges", f"config{cfg}:k_build_edges:{natoms}")):
+        if key not in t:
+            t[key] = dict(t[f"config{cfg}:fused_f32:{natoms}"], kernel=f"{'k_fused' if cfg == 4 else 'k_fused_lx2'} on {path}")
         e = t[key]
+        e["source"] = f"profiles/{prefix}_final.md (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, tools/final_profile.sh on the final tree)"
         e["fetch_size_kb"], e["write_size_kb"] = a[(kern, "FETCH_SIZE")], a[(kern, "WRITE_SIZE")]
         e["traffic_bytes_per_launch"] = (e["fetch_size_kb"] * e["fetch_correction"] + e["write_size_kb"]) * 1024.0
         e["kernel_hash"] = h
         e["measured_on"] = f"final tree, run {tag}"
         print(f"{key}: {e['traffic_bytes_per_launch'] / 1e9:.3f} GB")
     shutil.copy(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "trace", "t_kernel_stats.csv"), os.path.join(ROOT, "profiles", f"{prefix}_kernel_stats_{label}.csv"))
-    line = open(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "bench_default.json")).read().strip().splitlines()[-1]
     open(os.path.join(ROOT, "profiles", f"{prefix}_bench_config{cfg}.json"), "w").write(line + "\n")
 json.dump(t, open(tj, "w"), indent=1)
 print("kernel hash", h)

@@ -68,9 +68,11 @@ int ahip_model_meta(const ahip_model *m, double *r_max, int *num_types, const ch
  *                                                 kernels launched on OTHER streams (ghost exchange) can run beside them (default 0)
  *   "cutoff_compare" = "le" | "lt"               edge kept iff rsq <= cut^2 (default; pair_nequip_allegro.cpp:507) or rsq < cut^2
  *                                                 (the KOKKOS path of the reference, pair_nequip_allegro_kokkos.cpp:174)
- *   "fused_arith" = "auto" | "f32" | "bf16x3" | "tf32eq"   arithmetic of the dense contractions of the l_max = 1 fused kernel: f32-input MFMA;
- *                                                 three-term bf16 split (float32-equivalent); two-term bf16 split (TF32-class).  auto = f32 unless
- *                                                 the model file says allow_tf32 = 1 (pair_nequip_allegro.cpp:267-270), then tf32eq
+ *   "fused_arith" = "auto" | "f32" | "f16x2" | "bf16x3" | "tf32eq"   arithmetic of the dense contractions of the fused kernels: f32-input MFMA (exact float32
+ *                                                 fmaf chains); two float16 terms per operand, three f16-MFMA products (float32-equivalent inside float16's exponent
+ *                                                 range; an evaluation that leaves it returns AHIP_ERR_STATE: host-pointer calls at once, _dev calls at the next
+ *                                                 evaluation); three-term bf16 split (float32-equivalent; l_max = 1 kernel); two-term bf16 split (TF32-class; l_max = 1
+ *                                                 kernel).  auto = f16x2 unless the model file says allow_tf32 = 1 (pair_nequip_allegro.cpp:267-270), then tf32eq
  *   "fused_tb"  = "table" | "mlp"                two-body embedding of the fused kernels: tabulated cubic splines (default) or the MLP itself
  *   "edge_schedule" = "auto" | "static" | "dynamic"   unit schedule of the single-pass edge build (dynamic: safe beside other resident kernels)
  *   "tile_pack" = "auto" | "separate" | "fused"  tile packing of the fused kernels inside the edge build or as its own kernels
@@ -198,10 +200,10 @@ int ahip_last_tile_occupancy(ahip_model *m, long long *slots_used, long long *sl
 /* The model file's fifth metadata key, `allow_tf32` ("0" / "1").  The reference hands it to libtorch
  * (pair_nequip_allegro.cpp:267-270: at::globalContext().setAllowTF32CuBLAS / CuDNN): 1 = the model's author permits TF32-class
  * matrix arithmetic.  Here: with 1 (and option fused_arith=auto, the default) the fused model-S kernel runs its linears on the bf16
- * matrix cores with a two-term split (ahip_last_path reports "fused_tf32eq"); with 0 every path is float32-exact or better. */
+ * matrix cores with a two-term split (ahip_last_path reports "fused_tf32eq"); with 0 every path is float32-exact, float32-equivalent ("fused_f16x2", the default of the fused kernels) or better. */
 int ahip_model_allow_tf32(const ahip_model *m, int *allow);
 
-/* Kernel family used by the last compute: "generic_f32" | "generic_f64" | "fused_f32" | "fused_tf32eq" ("" before). */
+/* Kernel family and arithmetic used by the last compute: "generic_f32" | "generic_f64" | "fused_f16x2" | "fused_f32" | "fused_bf16x3" | "fused_tf32eq" ("" before). */
 const char *ahip_last_path(ahip_model *m);
 /* Largest number of edges of any centre atom in the last compute. */
 int ahip_last_max_degree(ahip_model *m);

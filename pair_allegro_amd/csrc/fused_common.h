@@ -131,9 +131,10 @@ struct EpiSave {             // raw rows to scratch, value unchanged
   __device__ __forceinline__ float apply(int, int, float v) const { return v; }
   __device__ __forceinline__ void flush(int) const {}
 };
-struct EpiSaveFrom2 : EpiSave {  // raw rows to scratch from output tile 2 on (the backward pass reads only those: omega's l = 1 part), value unchanged
-  __device__ __forceinline__ void tile_done(int ot, const f32x4 &acc) const { if (ot >= 2) EpiSave::tile_done(ot, acc); }
+template <int FIRST> struct EpiSaveFrom : EpiSave {  // raw rows to scratch from output tile FIRST on (the backward pass reads only omega's l >= 1 part), value unchanged
+  __device__ __forceinline__ void tile_done(int ot, const f32x4 &acc) const { if (ot >= FIRST) EpiSave::tile_done(ot, acc); }
 };
+typedef EpiSaveFrom<2> EpiSaveFrom2;
 struct EpiSavePark : EpiSave {  // raw rows to scratch (for the backward pass) and to the LDS park (next layer's forward)
   float *pk; int prow, lane;
   __device__ __forceinline__ void tile_done(int ot, const f32x4 &acc) const {

@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
       float *const envk = lds.env[kk];
       {
         f32x4 om[EW];
-        lx_lin<AR, 4, EW, false>(WB, wp, x, om, v16, ring, EpiSave{SB, RL + S::O_OM, v16});
+        lx_lin<AR, 4, EW, false>(WB, wp, x, om, v16, ring, EpiSaveFrom<UT>{{SB, RL + S::O_OM, v16}});        // the backward pass reads the l >= 1 rows only
         // environment sum over the centre's edges, one K-tile at a time through the double-buffered stage
 #ifndef ABL_NO_ENVSTAGE
 #pragma unroll

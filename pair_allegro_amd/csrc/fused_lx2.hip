@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
       float *const envk = lds.env[kk];
       {
         f32x4 om[EWH];
-        lx_lin<AR, 4, EWH, false>(WB, wp, x, om, V16(), ring, EpiSave{SB, RL + S::O_OM, V16()});
+        lx_lin<AR, 4, EWH, false>(WB, wp, x, om, V16(), ring, EpiSaveFrom<HT>{{SB, RL + S::O_OM, V16()}});        // the backward pass reads the l >= 1 rows only
         // environment sum over the centre's edges: both halves stage one own K-tile, all waves reduce both
 #pragma unroll
         for (int t = 0; t < HT; ++t) {

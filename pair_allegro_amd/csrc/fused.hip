@@ -25,7 +25,8 @@
 //            only for model files that set allow_tf32).
 //
 // Supported model shape (others run the generic path): l_max = 1, 32 tensor features, 64 scalars,
-// MLP 2 x 64, read-out 1 x 32, <= 3 layers, <= 16 types; any number of Bessel functions and any cutoff-polynomial order (the radial basis only
+// MLPs of 2 hidden layers x 64 (1 or 3 hidden layers on the f16x2 instances with the tabulated two-body embedding: template parameter MD, round 5),
+// read-out 1 x 32, <= 3 layers, <= 16 types; any number of Bessel functions and any cutoff-polynomial order (the radial basis only
 // enters through the tabulated two-body embedding; fused_tb=mlp needs 8).  Reference graph:
 // the TorchScript model executed at /root/reference/pair_nequip_allegro.cpp:409-430.
 #include <hip/hip_runtime.h>
@@ -122,8 +123,10 @@ __device__ __host__ constexpr int R_Z1TB() { return 0; }
 __device__ __host__ constexpr int R_Z2TB() { return 4; }
 __device__ __host__ constexpr int R_U0() { return 8; }
 __device__ __host__ constexpr int R_W0() { return 12; }
-__device__ __host__ constexpr int R_LAYER(int kk) { return 16 + 24 * kk; }      // OM 4, Z1 4, Z2 4, U 4, VIN 8
-__device__ __host__ constexpr int R_TOTAL(int NL) { return 16 + 24 * NL; }
+// per layer: omega 4 | silu' of the MD hidden layers of the latent MLP, 4 each | u 4 | V_in 8   (MD = latent MLP depth, 1..3; 2 = the reference YAML's, 24 rows)
+__device__ __host__ constexpr int R_LSZ(int MD) { return 16 + 4 * MD; }
+__device__ __host__ constexpr int R_LAYER(int kk, int MD = 2) { return 16 + R_LSZ(MD) * kk; }
+__device__ __host__ constexpr int R_TOTAL(int NL, int MD = 2) { return 16 + R_LSZ(MD) * NL; }
 
 static constexpr float C_S3 = 1.7320508075688772f;
 static constexpr float C_P1 = 0.5773502691896258f;     // (1,1,0): sqrt(1) * w3j = 1/sqrt(3)
@@ -315,9 +318,13 @@ __device__ __forceinline__ void lin(__amdgpu_buffer_rsrc_t W, int &wp, const f32
   }
 }
 
-template <int NW, bool PROF, int AR, bool TBT, int NLT>
+// MD: hidden layers of the latent MLP (allegro_mlp_hidden_layers_depth of /root/reference/tests/test_data/test_repro_allegro.yaml:94; 2 there).  1 and 3 exist for the
+// f16x2 instances with the tabulated two-body embedding (round 5: the fused family widened by one axis); every MD-dependent piece below is `if constexpr`.
+template <int NW, bool PROF, int AR, bool TBT, int NLT, int MD = 2>
 __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
   constexpr int NTHREADS = NW * 64, MAXA = Lds<NW>::MAXA;
+  constexpr int OZL = 4 + 4 * (MD - 1), OU = 4 + 4 * MD, OVIN = 8 + 4 * MD;      // row offsets inside a layer: silu' of the LAST hidden layer, u, V_in (MD = 2: 8, 12, 16)
+  static_assert(MD >= 1 && MD <= 3 && (MD == 2 || (AR == 3 && TBT)), "latent MLP depth 1 / 3: f16x2 instances with the two-body table only");
   __shared__ Lds<NW> lds;
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
   const int v16 = lane * 16;
@@ -475,7 +482,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
 #pragma unroll
     for (int kk = 0; kk < NL; ++kk) {
       const bool last = (kk == NL - 1);
-      const int RL = R_LAYER(kk);
+      const int RL = R_LAYER(kk, MD);
       float *const envk = lds.env[0] + kk * (MAXA * ENV_LD);
       f32x4 V[4][2];
       {
@@ -536,10 +543,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       // channel mixing -> V^{kk+1}: saved in the next layer's VIN rows and parked in LDS
       if (!last) {
         f32x4 o2[2];
-        lin<AR, 2, 2, false, 0>(WB, wp, Vp[0], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1) + 16 + 0, v16}, pk, 0, lane});
-        lin<AR, 2, 2, false, 1>(WB, wp, Vp[1], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1) + 16 + 2, v16}, pk, 2, lane});
-        lin<AR, 2, 2, false, 2>(WB, wp, Vp[2], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1) + 16 + 4, v16}, pk, 4, lane});
-        lin<AR, 2, 2, false, 3>(WB, wp, Vp[3], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1) + 16 + 6, v16}, pk, 6, lane});
+        lin<AR, 2, 2, false, 0>(WB, wp, Vp[0], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 0, v16}, pk, 0, lane});
+        lin<AR, 2, 2, false, 1>(WB, wp, Vp[1], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 2, v16}, pk, 2, lane});
+        lin<AR, 2, 2, false, 2>(WB, wp, Vp[2], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 4, v16}, pk, 4, lane});
+        lin<AR, 2, 2, false, 3>(WB, wp, Vp[3], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 6, v16}, pk, 6, lane});
       }
       PHASE(PH_MIX);
       // latent MLP
@@ -547,11 +554,13 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         f32x4 cat[6], z[4], z2[4];
         cat[0] = x[0]; cat[1] = x[1]; cat[2] = x[2]; cat[3] = x[3]; cat[4] = Vp[0][0]; cat[5] = Vp[0][1];
         lin<AR, 6, 4, false, 0>(WB, wp, cat, z, v16, ring, EpiSiluSaveD{SB, RL + 4, v16});
-        lin<AR, 4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, RL + 8, v16});
+        if constexpr (MD >= 2) lin<AR, 4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, RL + 8, v16});
+        if constexpr (MD >= 3) lin<AR, 4, 4, false, 0>(WB, wp, z2, z, v16, ring, EpiSiluSaveD{SB, RL + 12, v16});
+        f32x4 (&zl)[4] = MD == 2 ? z2 : z;              // output of the last hidden layer
         const float ra = lds.res[kk][0], rbf = lds.res[kk][1] * fc;
         if (!last) {
           f32x4 xn[4];
-          lin<AR, 4, 4, false, 0>(WB, wp, z2, xn, v16, ring, EpiResidual<4>{{SB, RL + 12, v16}, x, ra, rbf});
+          lin<AR, 4, 4, false, 0>(WB, wp, zl, xn, v16, ring, EpiResidual<4>{{SB, RL + OU, v16}, x, ra, rbf});
           x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2]; x[3] = xn[3];
         } else {
           // Last layer: its new latent x' = ra x + rb fc (z2 W3) feeds nothing but the read-out's first linear, and no non-linearity
@@ -559,7 +568,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
           // 64 -> 32 linears instead of a 64 -> 64 and a 64 -> 32 one, here and (transposed) in the backward pass: 64 of the tile's
           // 1472 MFMAs per wave and two saved rows less.  z2 first: it dies there.
           f32x4 za[2], up[2];
-          lin<AR, 4, 2, false, 0>(WB, wp, z2, up, v16, ring, EpiSave{SB, RL + 12, v16});
+          lin<AR, 4, 2, false, 0>(WB, wp, zl, up, v16, ring, EpiSave{SB, RL + OU, v16});
           lin<AR, 4, 2, false, 0>(WB, wp, x, za, v16, ring, EpiNone{});
           zr[0] = ra * za[0] + rbf * up[0]; zr[1] = ra * za[1] + rbf * up[1];
         }
@@ -572,8 +581,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     // round trip is an L2 miss: ~2 us): u and z2 of the last layer now, under the read-out MFMAs
     f32x4 upre[4], zt[4], w0h[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) upre[t] = bload(SB, v16, (R_LAYER(NL - 1) + 12 + t) * ROW * 4);       // the last layer saved two rows: z2 (W3 Wr)
-    load_rows<4>(SB, R_LAYER(NL - 1) + 8, zt, v16);
+    for (int t = 0; t < 2; ++t) upre[t] = bload(SB, v16, (R_LAYER(NL - 1, MD) + OU + t) * ROW * 4);       // the last layer saved two rows: z2 (W3 Wr)
+    load_rows<4>(SB, R_LAYER(NL - 1, MD) + OZL, zt, v16);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 wo1[2];
 #pragma unroll
@@ -602,7 +611,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
 #pragma unroll
     for (int kk = NL - 1; kk >= 0; --kk) {
       const bool last = (kk == NL - 1);
-      const int RL = R_LAYER(kk);
+      const int RL = R_LAYER(kk, MD);
       f32x4 dVp[4][2], Vk[4][2], W0b[4];
       {
         f32x4 du[4], dh[4];
@@ -616,7 +625,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) { du[t] = rbfc * dx[t]; dx[t] = ra * dx[t]; }
           dfc_part += rb * ((accv[0] + accv[1]) + (accv[2] + accv[3]));
-          load_rows<4>(SB, RL + 4, zt1, v16);                  // z1: first used 96 MFMAs from here
+          if constexpr (MD >= 2) load_rows<4>(SB, RL + OZL - 4, zt1, v16);                  // silu' of the hidden layer below the last: first used 96 MFMAs from here
           __builtin_amdgcn_sched_barrier(0);
           lin<AR, 4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt});
         } else {
@@ -631,19 +640,28 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) dx[t] = ra * dx[t];
           dfc_part += rb * ((accv[0] + accv[1]) + (accv[2] + accv[3]));
-          load_rows<4>(SB, RL + 4, zt1, v16);
+          if constexpr (MD >= 2) load_rows<4>(SB, RL + OZL - 4, zt1, v16);
           __builtin_amdgcn_sched_barrier(0);
           lin<AR, 2, 4, false, 0>(WB, wp, du2, dh, v16, ring, EpiMulRows<4>{zt});
         }
         // prefetch V^{kk} (input of this layer's tensor product) under the MFMAs that follow
         if (kk > 0) {
 #pragma unroll
-          for (int lm = 0; lm < 4; ++lm) load_rows<2>(SB, RL + 16 + 2 * lm, Vk[lm], v16);
+          for (int lm = 0; lm < 4; ++lm) load_rows<2>(SB, RL + OVIN + 2 * lm, Vk[lm], v16);
         } else load_rows<4>(SB, R_W0(), W0b, v16);
         __builtin_amdgcn_sched_barrier(0);
-        lin<AR, 4, 4, false, 0>(WB, wp, dh, du, v16, ring, EpiMulRows<4>{zt1});
+        // down the hidden layers: g_{k-1} = (g_k W_k^T) * silu'(z_{k-1}), then dcat = g_0 W_0^T
         f32x4 dcat[6];
-        lin<AR, 4, 6, false, 0>(WB, wp, du, dcat, v16, ring, EpiNone{});
+        if constexpr (MD == 1) lin<AR, 4, 6, false, 0>(WB, wp, dh, dcat, v16, ring, EpiNone{});
+        else {
+          f32x4 zt0[4];
+          if constexpr (MD == 3) load_rows<4>(SB, RL + 4, zt0, v16);
+          lin<AR, 4, 4, false, 0>(WB, wp, dh, du, v16, ring, EpiMulRows<4>{zt1});
+          if constexpr (MD == 3) {
+            lin<AR, 4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt0});
+            lin<AR, 4, 6, false, 0>(WB, wp, dh, dcat, v16, ring, EpiNone{});
+          } else lin<AR, 4, 6, false, 0>(WB, wp, du, dcat, v16, ring, EpiNone{});
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) dx[t] += dcat[t];
         dVp[0][0] = dcat[4]; dVp[0][1] = dcat[5];             // ds
@@ -728,8 +746,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
           __builtin_amdgcn_sched_barrier(0);
         }
         if (kk > 0) {                                                      // next iteration's u and z2 rows
-          load_rows<4>(SB, R_LAYER(kk - 1) + 12, upre, v16);
-          load_rows<4>(SB, R_LAYER(kk - 1) + 8, zt, v16);
+          load_rows<4>(SB, R_LAYER(kk - 1, MD) + OU, upre, v16);
+          load_rows<4>(SB, R_LAYER(kk - 1, MD) + OZL, zt, v16);
         } else {                                                           // two-body u and z2 rows, l=1 embedding weights
           if constexpr (!TBT) {
             load_rows<4>(SB, R_U0(), upre, v16);
@@ -885,14 +903,18 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
 
 // ---------------------------------------------------------------------------- the bf16-split instances (fused_bf.o)
 void fused_launch_bf16(int nw, bool prof, int arith, bool tbt, int grid, hipStream_t s, const FusedArgs &A);
-void fused_launch_f16(int nw, bool prof, int grid, hipStream_t s, const FusedArgs &A);
+void fused_launch_f16(int nw, bool prof, int md, int grid, hipStream_t s, const FusedArgs &A);
 #if AHIP_FUSED_PART == 2
-// the f16x2 instances (fused_h.o): two-body table only
-void fused_launch_f16(int nw, bool prof, int grid, hipStream_t s, const FusedArgs &A) {
-#define AHIP_LAUNCH_NL(NWV, PROFV, NLV) hipLaunchKernelGGL((k_fused<NWV, PROFV, 3, true, NLV>), dim3(grid), dim3(NWV * 64), 0, s, A)
-#define AHIP_LAUNCH(NWV, PROFV) do { if (A.NL == 1) AHIP_LAUNCH_NL(NWV, PROFV, 1); else if (A.NL == 2) AHIP_LAUNCH_NL(NWV, PROFV, 2); else AHIP_LAUNCH_NL(NWV, PROFV, 3); } while (0)
-  if (prof) { if (nw == 4) AHIP_LAUNCH(4, true); else AHIP_LAUNCH(8, true); }
-  else { if (nw == 4) AHIP_LAUNCH(4, false); else AHIP_LAUNCH(8, false); }
+// the f16x2 instances (fused_h.o): two-body table only; latent MLP depth 1..3 (profiling build for depth 2 only)
+void fused_launch_f16(int nw, bool prof, int md, int grid, hipStream_t s, const FusedArgs &A) {
+#define AHIP_LAUNCH_NL(NWV, PROFV, NLV, MDV) hipLaunchKernelGGL((k_fused<NWV, PROFV, 3, true, NLV, MDV>), dim3(grid), dim3(NWV * 64), 0, s, A)
+#define AHIP_LAUNCH(NWV, PROFV, MDV) do { if (A.NL == 1) AHIP_LAUNCH_NL(NWV, PROFV, 1, MDV); else if (A.NL == 2) AHIP_LAUNCH_NL(NWV, PROFV, 2, MDV); else AHIP_LAUNCH_NL(NWV, PROFV, 3, MDV); } while (0)
+#define AHIP_LAUNCH_NW(PROFV, MDV) do { if (nw == 4) AHIP_LAUNCH(4, PROFV, MDV); else AHIP_LAUNCH(8, PROFV, MDV); } while (0)
+  if (md == 1) AHIP_LAUNCH_NW(false, 1);
+  else if (md == 3) AHIP_LAUNCH_NW(false, 3);
+  else if (prof) AHIP_LAUNCH_NW(true, 2);
+  else AHIP_LAUNCH_NW(false, 2);
+#undef AHIP_LAUNCH_NW
 #undef AHIP_LAUNCH
 #undef AHIP_LAUNCH_NL
 }
@@ -919,6 +941,7 @@ struct FusedState {
   FusedArgs args;
   bool ready = false, prof_on = false, dbg_on = false, clk_on = false;
   bool tbt = true;             // two-body embedding from the spline table (default) or evaluated as an MLP (option fused_tb=mlp)
+  int md = 2;                  // hidden layers of the latent MLP (template parameter MD of k_fused)
   int arith = 0;               // 0: f32-input MFMA; 1: bf16x3 (option fused_arith=bf16x3 / AHIP_FUSED_ARITH=b3); 2: tf32eq (two-term bf16 split; fused_arith=auto picks it when the model file says allow_tf32 = 1); 3: f16x2 (fused_h.h)
   DevBuf prof, dbg;
   int ncu = 256;
@@ -959,12 +982,27 @@ static int append_frag_b(std::vector<float> &out, const double *W, int K, int N,
             }
   return 2 * nterm * KS * (NT / 2);
 }
+// arithmetic (FusedState::arith) and two-body mode that options, environment and model metadata resolve to
+static int fused_resolve_arith(const Model &m, bool &tbt) {
+  const HostModel &h = m.hm;
+  const char *tb = std::getenv("AHIP_FUSED_TB");
+  tbt = (tb ? std::string(tb) : m.opt_fused_tb) != "mlp";
+  const char *ar = std::getenv("AHIP_FUSED_ARITH");
+  const std::string arith = ar ? ar : m.opt_fused_arith;
+  int a = (arith == "b3" || arith == "bf16x3") ? 1 : (arith == "tf32eq" || (arith == "auto" && h.allow_tf32)) ? 2 : (arith == "f16x2" || arith == "auto") ? 3 : 0;
+  if (a == 3 && !tbt) a = 0;        // the f16x2 instances exist with the tabulated two-body embedding only
+  return a;
+}
 bool fused_model_supported(const Model &m, std::string *why) {
   const HostModel &h = m.hm;
   auto no = [&](const char *msg) { if (why) *why = msg; return false; };
   if (h.l_max != 1) return no("fused kernels need l_max = 1");
   if (h.U != 32 || h.S != 64 || h.mlp_width != 64 || h.readout_width != 32) return no("fused kernels need U=32, S=64, MLP width 64, read-out width 32");
-  if (h.mlp_depth != 2 || h.readout_depth != 1) return no("fused kernels need MLP depth 2 and read-out depth 1");
+  if (h.mlp_depth < 1 || h.mlp_depth > 3 || h.readout_depth != 1) return no("fused kernels need MLP depth 1..3 and read-out depth 1");
+  if (h.mlp_depth != 2) {           // round 5: depth 1 and 3 on the f16x2 instances with the tabulated two-body embedding
+    bool tbt;
+    if (fused_resolve_arith(m, tbt) != 3) return no("MLP depth 1 / 3 runs on the f16x2 arithmetic with the tabulated two-body embedding only (fused_arith=auto|f16x2, fused_tb=table, allow_tf32 = 0)");
+  }
   // the radial basis only enters through the two-body embedding: tabulated (default) any number of Bessel functions will do, evaluated in the kernel
   // (fused_tb=mlp) its first linear is laid out for 8
   {
@@ -996,17 +1034,9 @@ static void fused_prepare(Model &m) {
   // ---- the weight stream, in the order one tile consumes it ----
   A.o_stream = mark();
   const size_t stream0 = w.size();
-  {
-    const char *ar = std::getenv("AHIP_FUSED_ARITH");
-    std::string arith = ar ? ar : m.opt_fused_arith;
-    st.arith = (arith == "b3" || arith == "bf16x3") ? 1 : (arith == "tf32eq" || (arith == "auto" && h.allow_tf32)) ? 2 : (arith == "f16x2" || arith == "auto") ? 3 : 0;
-  }
-  {
-    const char *tb = std::getenv("AHIP_FUSED_TB");
-    std::string mode = tb ? tb : m.opt_fused_tb;
-    st.tbt = mode != "mlp";
-  }
-  if (st.arith == 3 && !st.tbt) st.arith = 0;        // the f16x2 instances exist with the tabulated two-body embedding only
+  st.arith = fused_resolve_arith(m, st.tbt);
+  st.md = h.mlp_depth;
+  const int MD = st.md;
   const bool b3 = st.arith == 1 || st.arith == 2, tbt = st.tbt;
   const int nterm = st.arith == 1 ? 3 : 2;
   bool h_range_ok = true;
@@ -1023,11 +1053,12 @@ static void fused_prepare(Model &m) {
   const double *wc = w0.data.data() + (size_t)2 * T * 64;       // Bessel block [8][64]
   std::vector<double> w3r((size_t)64 * 32, 0.0);                // W3 (last layer) @ Wr (read-out), float64
   {
-    const double *W3 = T_("l" + std::to_string(NL) + ".lat.w2"), *Wr = T_("out.w0");
+    const double *W3 = T_("l" + std::to_string(NL) + ".lat.w" + std::to_string(MD)), *Wr = T_("out.w0");
     for (int i = 0; i < 64; ++i)
       for (int q = 0; q < 64; ++q)
         for (int n = 0; n < 32; ++n) w3r[(size_t)i * 32 + n] += W3[(size_t)i * 64 + q] * Wr[(size_t)q * 32 + n];
   }
+  if (!tbt && MD != 2) throw UnsupportedError("fused_tb=mlp needs MLP depth 2");
   if (!tbt) {
     fwd(wc, 8, 64);
     fwd(T_("tb.w1"), 64, 64);
@@ -1043,8 +1074,8 @@ static void fused_prepare(Model &m) {
       for (int c = 0; c < 3; ++c) fwd(mx + 1024, 32, 32);
     }
     fwd(T_(lk + ".lat.w0"), 96, 64);
-    fwd(T_(lk + ".lat.w1"), 64, 64);
-    if (k < NL - 1) fwd(T_(lk + ".lat.w2"), 64, 64);
+    for (int hl = 1; hl < MD; ++hl) fwd(T_(lk + ".lat.w" + std::to_string(hl)), 64, 64);
+    if (k < NL - 1) fwd(T_(lk + ".lat.w" + std::to_string(MD)), 64, 64);
     else {            // last layer: the read-out's first linear applied, multiplied into W3, to z2 and then to x (k_fused, latent MLP)
       fwd(w3r.data(), 64, 32);
       fwd(T_("out.w0"), 64, 32);
@@ -1053,9 +1084,9 @@ static void fused_prepare(Model &m) {
   bwd(T_("out.w0"), 64, 32);
   for (int k = NL - 1; k >= 0; --k) {
     const std::string lk = "l" + std::to_string(k + 1);
-    if (k < NL - 1) bwd(T_(lk + ".lat.w2"), 64, 64);
+    if (k < NL - 1) bwd(T_(lk + ".lat.w" + std::to_string(MD)), 64, 64);
     else bwd(w3r.data(), 64, 32);
-    bwd(T_(lk + ".lat.w1"), 64, 64);
+    for (int hl = MD - 1; hl >= 1; --hl) bwd(T_(lk + ".lat.w" + std::to_string(hl)), 64, 64);
     bwd(T_(lk + ".lat.w0"), 96, 64);
     if (k < NL - 1) {
       const double *mx = T_(lk + ".mix");
@@ -1110,7 +1141,7 @@ static void fused_prepare(Model &m) {
   AHIP_CHECK(hipGetDeviceProperties(&prop, m.device));
   st.ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   // Persistent workgroups, 8 waves per CU either way (two per SIMD, 256 registers each).
-  A.wave_scratch = (long long)R_TOTAL(NL) * ROW;
+  A.wave_scratch = (long long)R_TOTAL(NL, MD) * ROW;
   st.scratch.reserve((size_t)st.ncu * 8 * A.wave_scratch * sizeof(float));
   A.scratch = st.scratch.as<float>();
   st.partial.reserve((size_t)st.ncu * 2 * 7 * sizeof(double));
@@ -1219,7 +1250,7 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
       // (10 648 Si atoms: 4 659 tiles on 512 workgroups = 12 instead of 10 tile times with claims of 4)
       A.tchunk = (nedges_est / (16 * shape) > (long long)g * 256) ? TCHUNK : 1;
       if (const char *tc = std::getenv("AHIP_TCHUNK")) A.tchunk = std::max(1, std::atoi(tc));       // experiments
-      if (st.arith == 3) { fused_launch_f16(shape, st.prof_on, g, s, A); continue; }                        // fused_h.o
+      if (st.arith == 3) { fused_launch_f16(shape, st.prof_on, st.md, g, s, A); continue; }                        // fused_h.o
       if (st.arith != 0) { fused_launch_bf16(shape, st.prof_on, st.arith, st.tbt, g, s, A); continue; }     // fused_bf.o
 #define AHIP_LAUNCH_NL(NWV, PROFV, TBV, NLV) hipLaunchKernelGGL((k_fused<NWV, PROFV, 0, TBV, NLV>), dim3(g), dim3(NWV * 64), 0, s, A)
 #define AHIP_LAUNCH(NWV, PROFV, TBV) do { if (A.NL == 1) AHIP_LAUNCH_NL(NWV, PROFV, TBV, 1); else if (A.NL == 2) AHIP_LAUNCH_NL(NWV, PROFV, TBV, 2); else AHIP_LAUNCH_NL(NWV, PROFV, TBV, 3); } while (0)

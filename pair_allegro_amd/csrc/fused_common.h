@@ -432,7 +432,10 @@ static void append_two_body_table(std::vector<float> &w, const HostModel &h, con
   struct { const std::vector<double> &rcut_model_host; } m{rcut_model_host};
   const int NK = NKin;
   const double PI = 3.14159265358979323846;
-  const double *W1 = T_("tb.w1"), *W2 = T_("tb.w2");
+  // hidden layers beyond the first: tb.w1 .. tb.w{depth-1} (64 x 64), output layer tb.w{depth}; depth = the model's MLP depth (1..3 on the fused paths)
+  const int depth = h.mlp_depth;
+  std::vector<const double *> Wh;
+  for (int k = 1; k <= depth; ++k) Wh.push_back(T_("tb.w" + std::to_string(k)));
   auto silu = [](double z) { return z / (1.0 + std::exp(-z)); };
   auto dsilu = [](double z) { const double sg = 1.0 / (1.0 + std::exp(-z)); return sg * (1.0 + z * (1.0 - sg)); };
   std::vector<double> y((size_t)(NK + 1) * 64), dy((size_t)(NK + 1) * 64);
@@ -450,23 +453,27 @@ static void append_two_body_table(std::vector<float> &w, const HostModel &h, con
           fcv = 1.0 - ca * xp + cb * xp * xq - cc * xp * xq * xq;
           dfc = -ca * p * xp1 + cb * (p + 1) * xp - cc * (p + 2) * xp * xq;
         }
-        double z1[64], dz1[64], h1[64], dh1[64], z2[64], dz2[64], h2[64], dh2[64];
-        for (int n = 0; n < 64; ++n) { z1[n] = w0.data[(size_t)ti * 64 + n] + w0.data[(size_t)(T + tj) * 64 + n]; dz1[n] = 0; }
+        double z[64], dz[64], hh[64], dh[64];
+        for (int n = 0; n < 64; ++n) { z[n] = w0.data[(size_t)ti * 64 + n] + w0.data[(size_t)(T + tj) * 64 + n]; dz[n] = 0; }
         for (int b = 1; b <= h.num_bessels; ++b) {
           const double a = b * PI / rc;
           double sv, ds;                                // s = sin(a d)/d and ds/dd, series near 0
           if (a * d < 1e-4) { sv = a * (1.0 - a * a * d * d / 6.0); ds = -a * a * a * d / 3.0; }
           else { sv = std::sin(a * d) / d; ds = (a * d * std::cos(a * d) - std::sin(a * d)) / (d * d); }
           const double bf = 2.0 / rc * sv * fcv, dbf = 2.0 / rc * (ds * fcv + sv * dfc / rc);
-          for (int n = 0; n < 64; ++n) { z1[n] += wc[(size_t)(b - 1) * 64 + n] * bf; dz1[n] += wc[(size_t)(b - 1) * 64 + n] * dbf; }
+          for (int n = 0; n < 64; ++n) { z[n] += wc[(size_t)(b - 1) * 64 + n] * bf; dz[n] += wc[(size_t)(b - 1) * 64 + n] * dbf; }
         }
-        for (int n = 0; n < 64; ++n) { h1[n] = silu(z1[n]); dh1[n] = dsilu(z1[n]) * dz1[n]; z2[n] = 0; dz2[n] = 0; }
-        for (int q = 0; q < 64; ++q)
-          for (int n = 0; n < 64; ++n) { z2[n] += h1[q] * W1[(size_t)q * 64 + n]; dz2[n] += dh1[q] * W1[(size_t)q * 64 + n]; }
-        for (int n = 0; n < 64; ++n) { h2[n] = silu(z2[n]); dh2[n] = dsilu(z2[n]) * dz2[n]; }
+        for (int n = 0; n < 64; ++n) { hh[n] = silu(z[n]); dh[n] = dsilu(z[n]) * dz[n]; }
+        for (int l = 0; l + 1 < depth; ++l) {            // hidden layers 2 .. depth, value and d/dd (forward mode)
+          for (int n = 0; n < 64; ++n) { z[n] = 0; dz[n] = 0; }
+          for (int q = 0; q < 64; ++q)
+            for (int n = 0; n < 64; ++n) { z[n] += hh[q] * Wh[l][(size_t)q * 64 + n]; dz[n] += dh[q] * Wh[l][(size_t)q * 64 + n]; }
+          for (int n = 0; n < 64; ++n) { hh[n] = silu(z[n]); dh[n] = dsilu(z[n]) * dz[n]; }
+        }
+        const double *Wo = Wh[depth - 1];
         for (int n = 0; n < 64; ++n) {
           double u = 0, du = 0;
-          for (int q = 0; q < 64; ++q) { u += h2[q] * W2[(size_t)q * 64 + n]; du += dh2[q] * W2[(size_t)q * 64 + n]; }
+          for (int q = 0; q < 64; ++q) { u += hh[q] * Wo[(size_t)q * 64 + n]; du += dh[q] * Wo[(size_t)q * 64 + n]; }
           y[(size_t)k * 64 + n] = fcv * u;
           dy[(size_t)k * 64 + n] = dfc / rc * u + fcv * du;
         }

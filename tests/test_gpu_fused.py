@@ -226,6 +226,27 @@ def test_f16x2_range_alarm(hip_lib, model_dir):
     pair.model.close()
 
 
+@pytest.mark.parametrize("depth", [1, 3])
+def test_fused_latent_mlp_depth_1_and_3(hip_lib, model_dir, depth):
+    """The fused family widened by one axis: allegro_mlp_hidden_layers_depth 1 and 3 (2 in /root/reference/tests/test_data/test_repro_allegro.yaml:94) --
+    the two-body MLP behind the spline table and the latent MLP of every layer -- select the fused path (template parameter MD of k_fused, f16x2 instances) and
+    match the float64 oracle like depth 2 does: 256-atom CuPd box, 2 types, 2 and 3 layers, against the layer-at-a-time kernels too; fused_arith=f32 (no such instance)
+    falls back to them."""
+    g = util.load_golden("CuPd-cubic-big_r5")
+    for nl in (2, 3):
+        path, cfg, types, names, ref = _model_S_case(model_dir, f"cupd_S_md{depth}_nl{nl}", ["Cu", "Pd"], g["symbols"], g["cell"], g["pos"], nl=nl, mlp_depth=depth)
+        fused = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names)
+        assert fused["info"]["path"] == "fused_f16x2"
+        util.assert_close_to(fused, ref, 5e-4, what=f"fused, MLP depth {depth}, {nl} layers vs f64 oracle")
+        err = np.abs(fused["forces"] - ref["forces"]).max()
+        gen = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "generic"})
+        egen = np.abs(gen["forces"] - ref["forces"]).max()
+        print(f"MLP depth {depth}, {nl} layers: max|dF| vs f64 oracle fused {err:.3e}, layer-at-a-time f32 {egen:.3e}")
+        assert err < pc.F32EQ_DF * 2 and err < max(3.0 * egen, 1e-5)
+    exact = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"fused_arith": "f32"})
+    assert exact["info"]["path"] == "generic_f32"
+
+
 def test_fused_two_body_table_matches_mlp(hip_lib, model_dir):
     """Default: the two-body embedding x0(d; type pair) comes from a per-pair cubic spline table built from the float64 MLP
     (512 intervals); option fused_tb=mlp evaluates the three linears in the kernel.  Both must sit at the same distance

@@ -82,6 +82,14 @@ def test_soak_k_fused(hip_lib, model_dir, arith, expect, tol, layers):
           expect, tol if layers == 2 else None)
 
 
+@pytest.mark.parametrize("depth", [1, 3])
+def test_soak_k_fused_mlp_depth(hip_lib, model_dir, depth):
+    """The latent-MLP-depth instances of k_fused (round 5), 10 648-atom Si box."""
+    cell, pos, types = lmp_like.diamond_si(11)
+    cfg = model_file.model_S(mlp_depth=depth, seed=5)
+    _soak(hip_lib, model_dir, f"soak_S_md{depth}", cfg, cell, pos, (types - 1).astype(np.int32), [28.0855], {}, "fused_f16x2", pc.F32EQ_DF)
+
+
 def test_soak_k_fused_lx2(hip_lib, model_dir):
     """3 000-atom water box, model L (l_max = 2, 64 tensor features, 3 layers): k_fused_lx2 (wave pairs)."""
     cell, pos, types = lmp_like.water(10)

@@ -323,6 +323,10 @@ __device__ __forceinline__ void lin(__amdgpu_buffer_rsrc_t W, int &wp, const f32
 template <int NW, bool PROF, int AR, bool TBT, int NLT, int MD = 2>
 __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
   constexpr int NTHREADS = NW * 64, MAXA = Lds<NW>::MAXA;
+  // f16x2 instances (round 5): the last hidden layer of the latent MLP saves its RAW pre-activation rows and the layer's output rows u are not saved at all: the backward
+  // pass needs u only for <u, g> (the cutoff gradient), and <u, g> = <silu(z), g W^T> falls out of its first linear's epilogue (EpiMulSiluZ), which rebuilds silu and silu'
+  // from z -- 6 row stores and 6 row loads fewer per wave-tile of a two-layer model for ~10 VALU operations per value there: 45.8 -> 44.4 ms at 1 M Si atoms.
+  constexpr bool SAVEZ = AR == 3;
   constexpr int OZL = 4 + 4 * (MD - 1), OU = 4 + 4 * MD, OVIN = 8 + 4 * MD;      // row offsets inside a layer: silu' of the LAST hidden layer, u, V_in (MD = 2: 8, 12, 16)
   static_assert(MD >= 1 && MD <= 3 && (MD == 2 || (AR == 3 && TBT)), "latent MLP depth 1 / 3: f16x2 instances with the two-body table only");
   __shared__ Lds<NW> lds;
@@ -553,14 +557,22 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       {
         f32x4 cat[6], z[4], z2[4];
         cat[0] = x[0]; cat[1] = x[1]; cat[2] = x[2]; cat[3] = x[3]; cat[4] = Vp[0][0]; cat[5] = Vp[0][1];
-        lin<AR, 6, 4, false, 0>(WB, wp, cat, z, v16, ring, EpiSiluSaveD{SB, RL + 4, v16});
-        if constexpr (MD >= 2) lin<AR, 4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, RL + 8, v16});
-        if constexpr (MD >= 3) lin<AR, 4, 4, false, 0>(WB, wp, z2, z, v16, ring, EpiSiluSaveD{SB, RL + 12, v16});
+        if constexpr (SAVEZ && MD == 1) lin<AR, 6, 4, false, 0>(WB, wp, cat, z, v16, ring, EpiSiluSaveZ{SB, RL + 4, v16});
+        else lin<AR, 6, 4, false, 0>(WB, wp, cat, z, v16, ring, EpiSiluSaveD{SB, RL + 4, v16});
+        if constexpr (MD >= 2) {
+          if constexpr (SAVEZ && MD == 2) lin<AR, 4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSaveZ{SB, RL + 8, v16});
+          else lin<AR, 4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, RL + 8, v16});
+        }
+        if constexpr (MD >= 3) {
+          if constexpr (SAVEZ) lin<AR, 4, 4, false, 0>(WB, wp, z2, z, v16, ring, EpiSiluSaveZ{SB, RL + 12, v16});
+          else lin<AR, 4, 4, false, 0>(WB, wp, z2, z, v16, ring, EpiSiluSaveD{SB, RL + 12, v16});
+        }
         f32x4 (&zl)[4] = MD == 2 ? z2 : z;              // output of the last hidden layer
         const float ra = lds.res[kk][0], rbf = lds.res[kk][1] * fc;
         if (!last) {
           f32x4 xn[4];
-          lin<AR, 4, 4, false, 0>(WB, wp, zl, xn, v16, ring, EpiResidual<4>{{SB, RL + OU, v16}, x, ra, rbf});
+          if constexpr (SAVEZ) lin<AR, 4, 4, false, 0>(WB, wp, zl, xn, v16, ring, EpiResidualNS<4>{x, ra, rbf});
+          else lin<AR, 4, 4, false, 0>(WB, wp, zl, xn, v16, ring, EpiResidual<4>{{SB, RL + OU, v16}, x, ra, rbf});
           x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2]; x[3] = xn[3];
         } else {
           // Last layer: its new latent x' = ra x + rb fc (z2 W3) feeds nothing but the read-out's first linear, and no non-linearity
@@ -568,7 +580,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
           // 64 -> 32 linears instead of a 64 -> 64 and a 64 -> 32 one, here and (transposed) in the backward pass: 64 of the tile's
           // 1472 MFMAs per wave and two saved rows less.  z2 first: it dies there.
           f32x4 za[2], up[2];
-          lin<AR, 4, 2, false, 0>(WB, wp, zl, up, v16, ring, EpiSave{SB, RL + OU, v16});
+          if constexpr (SAVEZ) lin<AR, 4, 2, false, 0>(WB, wp, zl, up, v16, ring, EpiNone{});
+          else lin<AR, 4, 2, false, 0>(WB, wp, zl, up, v16, ring, EpiSave{SB, RL + OU, v16});
           lin<AR, 4, 2, false, 0>(WB, wp, x, za, v16, ring, EpiNone{});
           zr[0] = ra * za[0] + rbf * up[0]; zr[1] = ra * za[1] + rbf * up[1];
         }
@@ -581,7 +594,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     // round trip is an L2 miss: ~2 us): u and z2 of the last layer now, under the read-out MFMAs
     f32x4 upre[4], zt[4], w0h[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) upre[t] = bload(SB, v16, (R_LAYER(NL - 1, MD) + OU + t) * ROW * 4);       // the last layer saved two rows: z2 (W3 Wr)
+    for (int t = 0; t < 2; ++t) if (!SAVEZ) upre[t] = bload(SB, v16, (R_LAYER(NL - 1, MD) + OU + t) * ROW * 4);       // the last layer saved two rows: z2 (W3 Wr)
     load_rows<4>(SB, R_LAYER(NL - 1, MD) + OZL, zt, v16);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 wo1[2];
@@ -616,7 +629,26 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       {
         f32x4 du[4], dh[4];
         f32x4 zt1[4];
-        if (!last) {
+        if (!last && SAVEZ) {
+          // the u rows are not saved: <u, g> = <silu(z), g W^T> comes out of the first backward linear's epilogue (EpiMulSiluZ), whose input is the unscaled gradient
+          const float ra = lds.res[kk][0], rb = lds.res[kk][1];
+          if constexpr (MD >= 2) load_rows<4>(SB, RL + OZL - 4, zt1, v16);
+          __builtin_amdgcn_sched_barrier(0);
+          float ug = 0.f;
+          lin<AR, 4, 4, false, 0>(WB, wp, dx, dh, v16, ring, EpiMulSiluZ<4>{zt, rb * fc, ug});
+          dfc_part += rb * ug;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) dx[t] = ra * dx[t];
+        } else if (last && SAVEZ) {
+          const float ra = lds.res[kk][0], rb = lds.res[kk][1];
+          if constexpr (MD >= 2) load_rows<4>(SB, RL + OZL - 4, zt1, v16);
+          __builtin_amdgcn_sched_barrier(0);
+          float ug = 0.f;
+          lin<AR, 2, 4, false, 0>(WB, wp, dzr, dh, v16, ring, EpiMulSiluZ<4>{zt, rb * fc, ug});
+          dfc_part += rb * ug;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) dx[t] = ra * dx[t];
+        } else if (!last) {
           const float ra = lds.res[kk][0], rb = lds.res[kk][1];
           f32x4 accv = upre[0] * dx[0];
 #pragma unroll
@@ -746,7 +778,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
           __builtin_amdgcn_sched_barrier(0);
         }
         if (kk > 0) {                                                      // next iteration's u and z2 rows
-          load_rows<4>(SB, R_LAYER(kk - 1, MD) + OU, upre, v16);
+          if (!SAVEZ) load_rows<4>(SB, R_LAYER(kk - 1, MD) + OU, upre, v16);
           load_rows<4>(SB, R_LAYER(kk - 1, MD) + OZL, zt, v16);
         } else {                                                           // two-body u and z2 rows, l=1 embedding weights
           if constexpr (!TBT) {

@@ -170,6 +170,35 @@ template <int NT> struct EpiMulRows {        // out = v * d (d = the saved silu'
   __device__ __forceinline__ float apply(int ot, int r, float v) const { return v * d[ot][r]; }
   __device__ __forceinline__ void flush(int) const {}
 };
+// out = silu(z); the RAW pre-activation rows are saved (straight from the result registers): the backward pass rebuilds both silu(z) and silu'(z)
+// from them (EpiMulSiluZ), which is what lets it do without the saved u rows of the layer above
+struct EpiSiluSaveZ {
+  static constexpr bool STORES = true;
+  __amdgpu_buffer_rsrc_t S; int row0, v16;
+  __device__ __forceinline__ void tile_done(int ot, const f32x4 &acc) const { bstore(S, v16, (row0 + ot) * ROW * 4, acc); }
+  __device__ __forceinline__ float apply(int, int, float z) const { return z * sigmoidf_fast(z); }
+  __device__ __forceinline__ void flush(int) const {}
+};
+// Backward twin: q = (g W^T) raw, z = the saved pre-activation rows: out = c q silu'(z), and acc += q silu(z) -- the contraction <u, g> of the layer's output
+// u = silu(z) W with its gradient g, i.e. what dE/dfc needs of u, without u: <u, g> = <silu(z), g W^T>.
+template <int NT> struct EpiMulSiluZ {
+  static constexpr bool STORES = false;
+  const f32x4 (&z)[NT]; float c; float &acc;
+  __device__ __forceinline__ void tile_done(int, const f32x4 &) const {}
+  __device__ __forceinline__ float apply(int ot, int r, float q) const {
+    const float zz = z[ot][r], sg = sigmoidf_fast(zz), h = zz * sg;
+    acc = fmaf(h, q, acc);
+    return q * (c * fmaf(h, 1.f - sg, sg));
+  }
+  __device__ __forceinline__ void flush(int) const {}
+};
+template <int NT> struct EpiResidualNS {   // out = ra * xold + rbf * u, nothing saved
+  static constexpr bool STORES = false;
+  const f32x4 (&xold)[NT]; float ra, rbf;
+  __device__ __forceinline__ void tile_done(int, const f32x4 &) const {}
+  __device__ __forceinline__ float apply(int ot, int r, float v) const { return ra * xold[ot][r] + rbf * v; }
+  __device__ __forceinline__ void flush(int) const {}
+};
 template <int NT> struct EpiResidual : EpiSave {   // raw u rows to scratch, out = ra * xold + rbf * u
   const f32x4 (&xold)[NT]; float ra, rbf;
   __device__ __forceinline__ float apply(int ot, int r, float v) const { return ra * xold[ot][r] + rbf * v; }

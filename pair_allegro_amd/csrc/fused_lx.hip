@@ -138,6 +138,7 @@ template <int L, int UT, int NW, int NLT, bool PROF, int AR>
 __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
   using S = ShapeX<L, UT, NW>;
   constexpr int NTHREADS = NW * 64, D = S::D, U = S::U, EW = S::EW, MAXA = S::MAXA, STG_LD = S::STG_LD, ENVA = S::ENVA, NP = S::NP;
+  constexpr bool SAVEZ = AR == 3;          // f16x2: raw pre-activation rows of the last hidden layer instead of silu' rows, no u rows (see fused.hip)
   __shared__ LdsX<L, UT, NW> lds;
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
   const int uwave = __builtin_amdgcn_readfirstlane(wave);
@@ -341,10 +342,12 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
 #pragma unroll
         for (int t = 0; t < UT; ++t) cat[4 + t] = sc[t];
         lx_lin<AR, 4 + UT, 4, false>(WB, wp, cat, z, v16, ring, EpiSiluSaveD{SB, RL + S::O_Z1, v16});
-        lx_lin<AR, 4, 4, false>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, RL + S::O_Z2, v16});
+        if constexpr (SAVEZ) lx_lin<AR, 4, 4, false>(WB, wp, z, z2, v16, ring, EpiSiluSaveZ{SB, RL + S::O_Z2, v16});
+        else lx_lin<AR, 4, 4, false>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, RL + S::O_Z2, v16});
         const float ra = lds.res[kk][0], rbf = lds.res[kk][1] * fc;
         f32x4 xn[4];
-        lx_lin<AR, 4, 4, false>(WB, wp, z2, xn, v16, ring, EpiResidual<4>{{SB, RL + S::O_U, v16}, x, ra, rbf});
+        if constexpr (SAVEZ) lx_lin<AR, 4, 4, false>(WB, wp, z2, xn, v16, ring, EpiResidualNS<4>{x, ra, rbf});
+        else lx_lin<AR, 4, 4, false>(WB, wp, z2, xn, v16, ring, EpiResidual<4>{{SB, RL + S::O_U, v16}, x, ra, rbf});
 #pragma unroll
         for (int t = 0; t < 4; ++t) x[t] = xn[t];
       }
@@ -363,7 +366,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
     // saved rows are requested well ahead of their first use all through the backward pass (their round trip is an L2 miss:
     // 1-2 us, and with one wave per SIMD nothing else covers it): u and silu'(z2) of the last layer under the read-out MFMAs
     f32x4 upre[4], zt[4], w0pre[L * UT];
-    load_rows<4>(SB, S::R_LAYER(NL - 1) + S::O_U, upre, v16);
+    if constexpr (!SAVEZ) load_rows<4>(SB, S::R_LAYER(NL - 1) + S::O_U, upre, v16);
     load_rows<4>(SB, S::R_LAYER(NL - 1) + S::O_Z2, zt, v16);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 zr[2];
@@ -406,7 +409,16 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
         f32x4 rows1[4];
         load_rows<4>(SB, RL + S::O_Z1, rows1, v16);            // silu'(z1): first used one linear from here
         __builtin_amdgcn_sched_barrier(0);
-        {
+        if constexpr (SAVEZ) {
+          // the u rows are not saved (fused.hip: SAVEZ): <u, g> falls out of the epilogue of the first backward linear, fed with the unscaled gradient
+          const float ra = lds.res[kk][0], rb = lds.res[kk][1];
+          float ug = 0.f;
+          lx_lin<AR, 4, 4, false>(WB, wp, dx, dh, v16, ring, EpiMulSiluZ<4>{zt, rb * fc, ug});
+#pragma unroll
+          for (int t = 0; t < 4; ++t) dx[t] = ra * dx[t];
+          dfc_part += rb * ug;
+          pin(dfc_part);
+        } else {
           const float ra = lds.res[kk][0], rb = lds.res[kk][1];
           f32x4 accv = upre[0] * dx[0];
 #pragma unroll
@@ -416,8 +428,8 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
           for (int t = 0; t < 4; ++t) { du[t] = rbfc * dx[t]; dx[t] = ra * dx[t]; }
           dfc_part += rb * hsum4(accv);
           pin(dfc_part);
+          lx_lin<AR, 4, 4, false>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt});
         }
-        lx_lin<AR, 4, 4, false>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt});
         lx_lin<AR, 4, 4, false>(WB, wp, dh, du, v16, ring, EpiMulRows<4>{rows1});
         f32x4 dcat[4 + UT];
         lx_lin<AR, 4, 4 + UT, false>(WB, wp, du, dcat, v16, ring, EpiNone{});
@@ -532,7 +544,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
         lx_prime<AR>(WB, wp, v16, ring);          // RING_DROP: requested again only now -- the d omega / dY arithmetic above needs the registers
         // next iteration's u / silu'(z2) rows (or the l >= 1 embedding weights for the last step) under this linear
         if (kk > 0) {
-          load_rows<4>(SB, S::R_LAYER(kk - 1) + S::O_U, upre, v16);
+          if constexpr (!SAVEZ) load_rows<4>(SB, S::R_LAYER(kk - 1) + S::O_U, upre, v16);
           load_rows<4>(SB, S::R_LAYER(kk - 1) + S::O_Z2, zt, v16);
         } else load_rows<L * UT>(SB, S::R_W0 + UT, w0pre, v16);
         __builtin_amdgcn_sched_barrier(0);

@@ -209,6 +209,7 @@ template <int NLT, bool PROF, int AR>
 __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
   using S = ShapeP;
   constexpr int NTHREADS = 512, D = S::D, U = S::U, HT = S::HT, EWH = S::EWH, MAXA = S::MAXA, STG_LD = S::STG_LD, ENVA = S::ENVA, NP = S::NP, L = S::L;
+  constexpr bool SAVEZ = AR == 3;          // f16x2: raw pre-activation rows of the last hidden layer instead of silu' rows, no u rows (see fused.hip)
   __shared__ LdsP lds;
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
   const int uwave = __builtin_amdgcn_readfirstlane(wave);
@@ -421,12 +422,14 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
         lx_lin<AR, 8, 2, false>(WB, wp, cat, z, V16(), ring, EpiSiluSaveD{SB, RL + S::O_Z1, V16()});
         x_swap<2>(X, xb, z, pr);
         zin[0] = z[0]; zin[1] = z[1]; zin[2] = pr[0]; zin[3] = pr[1];
-        lx_lin<AR, 4, 2, false>(WB, wp, zin, z2, V16(), ring, EpiSiluSaveD{SB, RL + S::O_Z2, V16()});
+        if constexpr (SAVEZ) lx_lin<AR, 4, 2, false>(WB, wp, zin, z2, V16(), ring, EpiSiluSaveZ{SB, RL + S::O_Z2, V16()});
+        else lx_lin<AR, 4, 2, false>(WB, wp, zin, z2, V16(), ring, EpiSiluSaveD{SB, RL + S::O_Z2, V16()});
         x_swap<2>(X, xb, z2, pr);
         zin[0] = z2[0]; zin[1] = z2[1]; zin[2] = pr[0]; zin[3] = pr[1];
         const float ra = lds.res[kk][0], rbf = lds.res[kk][1] * fc;
         f32x4 xo[2] = {x[0], x[1]};
-        lx_lin<AR, 4, 2, false>(WB, wp, zin, xn, V16(), ring, EpiResidual<2>{{SB, RL + S::O_U, V16()}, xo, ra, rbf});
+        if constexpr (SAVEZ) lx_lin<AR, 4, 2, false>(WB, wp, zin, xn, V16(), ring, EpiResidualNS<2>{xo, ra, rbf});
+        else lx_lin<AR, 4, 2, false>(WB, wp, zin, xn, V16(), ring, EpiResidual<2>{{SB, RL + S::O_U, V16()}, xo, ra, rbf});
         x_swap<2>(X, xb, xn, pr);
         x[0] = xn[0]; x[1] = xn[1]; x[2] = pr[0]; x[3] = pr[1];
       }
@@ -438,7 +441,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
 
     // ---------------- read-out (both waves of a pair evaluate it) ----------------
     f32x4 upre[2], zt[2], w0pre[L * HT];
-    load_rows<2>(SB, S::R_LAYER(NL - 1) + S::O_U, upre, V16());
+    if constexpr (!SAVEZ) load_rows<2>(SB, S::R_LAYER(NL - 1) + S::O_U, upre, V16());
     load_rows<2>(SB, S::R_LAYER(NL - 1) + S::O_Z2, zt, V16());
     __builtin_amdgcn_sched_barrier(0);
     f32x4 zr[2];
@@ -482,7 +485,16 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
         f32x4 rows1[2];
         load_rows<2>(SB, RL + S::O_Z1, rows1, V16());            // silu'(z1), own tiles: first used one linear from here
         __builtin_amdgcn_sched_barrier(0);
-        {
+        if constexpr (SAVEZ) {
+          // the u rows are not saved (fused.hip: SAVEZ): <u, g> over this wave's hidden tiles falls out of the epilogue of the first backward linear, fed with the unscaled gradient
+          const float ra = lds.res[kk][0], rb = lds.res[kk][1];
+          float ug = 0.f;
+          lx_lin<AR, 4, 2, false>(WB, wp, dx, dh, V16(), ring, EpiMulSiluZ<2>{zt, rb * fc, ug});
+          P[0] = ra * dx[0]; P[1] = ra * dx[1];
+          P[2] = f32x4{0.f, 0.f, 0.f, 0.f}; P[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dfc_part += rb * ug;
+          pin(dfc_part);
+        } else {
           const float ra = lds.res[kk][0], rb = lds.res[kk][1];
           const f32x4 accv = upre[0] * dx[0] + upre[1] * dx[1];       // u is split by output tile: own tiles only
           const float rbfc = rb * fc;
@@ -492,8 +504,8 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
           P[2] = f32x4{0.f, 0.f, 0.f, 0.f}; P[3] = f32x4{0.f, 0.f, 0.f, 0.f};
           dfc_part += rb * hsum4(accv);
           pin(dfc_part);
+          lx_lin<AR, 4, 2, false>(WB, wp, du, dh, V16(), ring, EpiMulRows<2>{zt});
         }
-        lx_lin<AR, 4, 2, false>(WB, wp, du, dh, V16(), ring, EpiMulRows<2>{zt});
         x_swap<2>(X, xb, dh, pr);
         din[0] = dh[0]; din[1] = dh[1]; din[2] = pr[0]; din[3] = pr[1];
         lx_lin<AR, 4, 2, false>(WB, wp, din, dh, V16(), ring, EpiMulRows<2>{rows1});
@@ -618,7 +630,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
         }
         lx_prime<AR>(WB, wp, V16(), ring);
         if (kk > 0) {
-          load_rows<2>(SB, S::R_LAYER(kk - 1) + S::O_U, upre, V16());
+          if constexpr (!SAVEZ) load_rows<2>(SB, S::R_LAYER(kk - 1) + S::O_U, upre, V16());
           load_rows<2>(SB, S::R_LAYER(kk - 1) + S::O_Z2, zt, V16());
         } else load_rows<L * HT>(SB, S::R_W0 + HT, w0pre, V16());
         __builtin_amdgcn_sched_barrier(0);

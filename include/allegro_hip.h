@@ -230,6 +230,15 @@ int ahip_build_neighbors_dev(ahip_model *m, int nlocal, int nall, const double *
 int ahip_reneighbor_flag_dev(ahip_model *m, int n, const double *x_dev, const double *xhold_dev, const double *v_dev, double dt,
                              double half_skin, int *flag_dev, void *stream);
 
+/* Ghost atoms of ONE rank that owns the whole periodic box (the stand-alone driver's `borders` step at a re-neighboring; LAMMPS' Comm::borders on a
+ * 1 x 1 x 1 grid): every periodic image of an owned atom that lies inside the halo of thickness rc around [lo, hi) -- shift +box_d allowed where
+ * x_d < lo_d + rc, -box_d where x_d >= hi_d - rc, every combination but (0, 0, 0).  Writes, per ghost, its position, model type, the index of the
+ * owned atom it images (int64) and the shift (what ahip_comm_set_plan_local takes); *nghost is the number of images, which may exceed `capacity`
+ * (then only the first `capacity` were written: call again with larger arrays).  Needs box_d >= rc.  Synchronises `stream` (one 4-byte read-back). */
+int ahip_borders_local_dev(ahip_model *m, int nlocal, const double *x_dev, const int *mtype_dev, const double *lo, const double *hi,
+                           const double *box, double rc, int capacity, double *xg_dev, int *mtg_dev, long long *src_dev, double *shift_dev,
+                           int *nghost, void *stream);
+
 /* v += dtf*f/m ; x += dt*v  style velocity-Verlet half steps on device arrays (NVE).
  *   mode 0: v += 0.5*dt*f*ftm2v/mass[type]; x += dt*v      (initial_integrate)
  *   mode 1: v += 0.5*dt*f*ftm2v/mass[type]                  (final_integrate)  */

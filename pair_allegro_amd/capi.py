@@ -35,7 +35,7 @@ SYMBOLS = [
     "ahip_compute_dev_range", "ahip_last_list_size", "ahip_neigh_update_dev_table", "ahip_map_types_dev", "ahip_reneighbor_flag_dev",
     "ahip_last_path", "ahip_last_max_degree", "ahip_debug_fused_linear", "ahip_debug_fused_edges", "ahip_build_neighbors_dev", "ahip_nve_dev", "ahip_nve_first_dev",
     "ahip_model_allow_tf32", "ahip_comm_unique_id", "ahip_comm_create_rccl", "ahip_comm_create_hosted", "ahip_comm_rccl_version", "ahip_comm_free", "ahip_comm_set_plan", "ahip_comm_set_plan_local",
-    "ahip_comm_forward", "ahip_comm_reverse", "ahip_comm_allreduce", "ahip_comm_selftest", "ahip_fill_zero_dev",
+    "ahip_comm_forward", "ahip_comm_reverse", "ahip_comm_allreduce", "ahip_comm_selftest", "ahip_fill_zero_dev", "ahip_borders_local_dev",
 ]
 
 
@@ -263,6 +263,17 @@ class Model:
             cm = np.ascontiguousarray(cutoff_matrix_model, dtype=np.float64)
         self.L.check(self.L.lib.ahip_compute_dev_range(self.h, c0, c1, nlocal, nghost, x_ptr, mtype_ptr, _p(cm, C.c_double), f_ptr,
                                                         eatom_ptr or None, engvir_ptr, stream or None))
+
+    def borders_local_dev(self, nlocal: int, x_ptr: int, mtype_ptr: int, lo, hi, box, rc: float, capacity: int, xg_ptr: int, mtg_ptr: int,
+                          src_ptr: int, shift_ptr: int, stream: int = 0) -> int:
+        """periodic images of a single rank's own atoms inside the halo (ahip_borders_local_dev); returns their number (> capacity: retry with larger arrays)"""
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (lo, hi, box)]
+        ng = C.c_int(0)
+        self.L.lib.ahip_borders_local_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                                      C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
+        self.L.check(self.L.lib.ahip_borders_local_dev(self.h, nlocal, x_ptr or None, mtype_ptr or None, _p(a[0], C.c_double), _p(a[1], C.c_double), _p(a[2], C.c_double),
+                                                        float(rc), capacity, xg_ptr or None, mtg_ptr or None, src_ptr or None, shift_ptr or None, C.byref(ng), stream or None))
+        return int(ng.value)
 
     def nve_dev(self, mode: int, n: int, x_ptr: int, v_ptr: int, f_ptr: int, mtype_ptr: int, mass_by_mtype,
                 dt: float, ftm2v: float, stream: int = 0) -> None:

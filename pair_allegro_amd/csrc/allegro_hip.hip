@@ -1014,6 +1014,18 @@ int ahip_reneighbor_flag_dev(ahip_model *m, int n, const double *x_dev, const do
   });
 }
 
+int ahip_borders_local_dev(ahip_model *m, int nlocal, const double *x_dev, const int *mtype_dev, const double *lo, const double *hi, const double *box, double rc,
+                           int capacity, double *xg_dev, int *mtg_dev, long long *src_dev, double *shift_dev, int *nghost, void *stream) {
+  return guarded([&] {
+    require_model(m);
+    if (nlocal < 0 || capacity < 0 || !lo || !hi || !box || !nghost || !(rc > 0.0) || (nlocal > 0 && (!x_dev || !mtype_dev)) ||
+        (capacity > 0 && (!xg_dev || !mtg_dev || !src_dev || !shift_dev)))
+      throw ArgError("ahip_borders_local_dev: bad argument");
+    AHIP_CHECK(hipSetDevice(m->device));
+    *nghost = borders_local(*m, nlocal, x_dev, mtype_dev, lo, hi, box, rc, capacity, xg_dev, mtg_dev, src_dev, shift_dev, (hipStream_t)stream);
+  });
+}
+
 int ahip_nve_first_dev(ahip_model *m, int nlocal, int nall, double *x_dev, double *v_dev, double *f_dev, const int *mtype_dev,
                        const double *mass_by_mtype, double dt, double ftm2v, void *stream) {
   return guarded([&] {

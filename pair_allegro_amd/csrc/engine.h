@@ -297,6 +297,9 @@ void neigh_from_table(Model &m, int inum, int nall, const int *ilist_dev, const 
                       long long stride_atom, long long stride_slot, int mask, hipStream_t s);
 void map_types(Model &m, int n, const int *type_dev, int ntypes, const int *mapper_host, int *out_dev, hipStream_t s);
 void neigh_free(Model &m);
+// periodic images of a single rank's own atoms inside the halo (neigh.hip); returns their number (may exceed `capacity`: then the arrays hold the first `capacity`)
+int borders_local(Model &m, int nlocal, const double *x, const int *mtype, const double *lo, const double *hi, const double *box, double rc, int capacity,
+                  double *xg, int *mtg, long long *src, double *shift, hipStream_t s);
 void nve_first_step(int n, int nall, double *x, double *v, double *f, const int *mtype, const double *mass_host, int ntypes, double dt, double ftm2v,
                     hipStream_t s);
 void nve_step(int mode, int n, double *x, double *v, const double *f, const int *mtype, const double *mass_dev_or_host,

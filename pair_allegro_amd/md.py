@@ -94,6 +94,11 @@ class HipBackend:
     def fill_zero(self, t: torch.Tensor, stream: int = 0) -> None:
         self.model.L.check(self.model.L.lib.ahip_fill_zero_dev(t.data_ptr(), t.numel() * t.element_size(), stream or None))
 
+    def borders_local(self, nlocal: int, x, mtype, lo, hi, box, rc: float, capacity: int, xg, mtg, src, shift) -> int:
+        """ghosts of a single rank = periodic images of its own atoms inside the halo, built by the library (ahip_borders_local_dev)"""
+        return self.model.borders_local_dev(nlocal, x.data_ptr(), mtype.data_ptr(), lo, hi, box, rc, capacity, xg.data_ptr(), mtg.data_ptr(),
+                                            src.data_ptr(), shift.data_ptr())
+
     def reneighbor_flag(self, n: int, x, x_hold, v, dt: float, half_skin: float, flag) -> None:
         """flag[0] = max displacement since the last build + 2 dt max|v| > half_skin (ahip_reneighbor_flag_dev)."""
         self.model.reneighbor_flag_dev(n, x.data_ptr(), x_hold.data_ptr() if n else 0, v.data_ptr(), dt, half_skin, flag.data_ptr())
@@ -383,7 +388,38 @@ class Simulation:
         self.nlocal = x.shape[0]
         self.x, self.v, self.tag, self.mtype = x.contiguous(), v.contiguous(), tag.contiguous(), mt.contiguous()
 
+    def _borders_local(self) -> bool:
+        """One rank, library backend: the ghosts (periodic images of the rank's own atoms) come from ONE library call -- count, scan, fill -- instead of six
+        rounds of torch masking / indexing (0.8 of the 1.9 ms a re-neighboring of 10 648 atoms cost, every 16 steps at 300 K).  The per-step exchange of a
+        single rank only needs the image -> source map and the shifts (ahip_comm_set_plan_local), which the call returns; no swap list is built."""
+        if self.nranks != 1 or not hasattr(self.backend, "borders_local") or not hasattr(self.backend.model.L.lib, "ahip_borders_local_dev"):
+            return False
+        if min(self.box) < self.rc:
+            return False
+        nl = self.nlocal
+        cap = max(1024, int(1.25 * getattr(self, "_nghost_last", 0)) or int(nl * (np.prod(1.0 + 2.0 * self.rc / np.asarray(self.box)) - 1.0) * 1.25) + 1024)
+        while True:                                            # locals and images in one allocation: the call writes the images behind the locals
+            xa = torch.empty((nl + cap, 3), dtype=torch.float64, device=self.dev)
+            mta = torch.empty(nl + cap, dtype=torch.int32, device=self.dev)
+            src = torch.empty(cap, dtype=torch.long, device=self.dev)
+            shv = torch.empty((cap, 3), dtype=torch.float64, device=self.dev)
+            ng = self.backend.borders_local(nl, self.x, self.mtype, self.lo, self.hi, np.asarray(self.box, dtype=np.float64), self.rc, cap,
+                                            xa[nl:], mta[nl:], src, shv)
+            if ng <= cap:
+                break
+            cap = int(1.1 * ng) + 64
+        self._nghost_last = ng
+        self.swaps = []
+        xa[:nl] = self.x[:nl]
+        mta[:nl] = self.mtype[:nl]
+        self.x, self.mtype = xa[: nl + ng], mta[: nl + ng]
+        self.nall = nl + ng
+        self._ghost_src, self._ghost_shift = (src[:ng], shv[:ng]) if ng else (None, None)
+        return True
+
     def _borders(self) -> None:
+        if self._borders_local():
+            return
         self.swaps = []
         x, mt = self.x, self.mtype
         for d in range(3):

@@ -161,3 +161,48 @@ def test_neigh_modify_every_delay_check(emu_lib, model_dir):
     np.testing.assert_allclose(f_every, f_default, atol=1e-9)         # a fresher list changes nothing while the skin holds
     with pytest.raises(ValueError):
         run(neigh_every=0)
+
+
+@pytest.mark.parametrize("ncell,two_types", [(3, False), (2, True)])
+def test_library_borders_equal_the_swap_chain_borders(emu_lib, model_dir, ncell, two_types):
+    """One rank: ahip_borders_local_dev (count / scan / fill in the library) produces the same SET of ghosts -- (source atom, shift) pairs, positions,
+    types -- as the per-dimension swap chain (reference: LAMMPS Comm::borders, which pair_allegro relies on for its ghosts), also when an atom needs
+    images in several directions and when a capacity guess is too small (the call reports the count, the caller retries)."""
+    cfg = _small_cfg()
+    if two_types:
+        cfg = dict(cfg, type_names=["Si", "C"])
+    path = os.path.join(model_dir, f"md_borders{ncell}.ahip")
+    model_file.save_ahip(path, cfg, model_file.init_weights(cfg))
+    cell, pos, _ = lmp_like.diamond_si(ncell)
+    rng = np.random.default_rng(5)
+    pos = pos + rng.normal(0, 0.05, pos.shape)
+    box = np.diag(cell)
+    pos -= np.floor(pos / box) * box
+    mt = (np.arange(len(pos)) % 2).astype(np.int32) if two_types else np.zeros(len(pos), np.int32)
+    vel = np.zeros_like(pos)
+
+    def ghosts(use_lib):
+        model = capi.Model(path, 0, emu_lib)
+        sim = md.Simulation(md.HipBackend(model, [28.0855, 12.011]), box, cfg["r_max"], 1.0, pos, mt, vel, torch.device("cpu"), dt=0.001)
+        nl = sim.nlocal                                           # (the constructor built the borders once; build them again the chosen way)
+        sim.x, sim.mtype = sim.x[:nl].contiguous(), sim.mtype[:nl].contiguous()
+        if not use_lib:
+            sim._borders_local = lambda: False
+        else:
+            sim._nghost_last = 8                                  # a deliberately small first guess: exercises the retry
+        sim._borders()
+        assert sim.nall == sim.x.shape[0] == sim.mtype.shape[0]
+        g = np.concatenate([sim._ghost_src.numpy()[:, None].astype(np.float64), sim._ghost_shift.numpy(), sim.x[nl:].numpy(),
+                            sim.mtype[nl:].numpy()[:, None].astype(np.float64)], axis=1)
+        xl = sim.x[:nl].numpy().copy()
+        model.close()
+        return xl, g[np.lexsort(g.T[::-1])]
+
+    xa, ga = ghosts(False)
+    xb, gb = ghosts(True)
+    np.testing.assert_array_equal(xa, xb)
+    assert ga.shape == gb.shape and ga.shape[0] > 0
+    np.testing.assert_array_equal(ga[:, :4], gb[:, :4])          # same (source, shift) set
+    np.testing.assert_allclose(ga[:, 4:7], gb[:, 4:7], rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(ga[:, 7], gb[:, 7])
+    np.testing.assert_allclose(gb[:, 4:7], xb[gb[:, 0].astype(int)] + gb[:, 1:4], rtol=0, atol=1e-12)

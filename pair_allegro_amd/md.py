@@ -363,7 +363,9 @@ class Simulation:
     def _migrate(self) -> None:
         n = self.nlocal
         x, v, tag, mt = self.x[:n], self.v[:n], self.tag[:n], self.mtype[:n]
-        box = torch.tensor(self.box, dtype=torch.float64, device=self.dev)
+        if getattr(self, "_box_t", None) is None:
+            self._box_t = torch.tensor(self.box, dtype=torch.float64, device=self.dev)       # once: a host -> device copy per re-neighboring otherwise
+        box = self._box_t
         x = x - torch.floor(x / box) * box                      # periodic wrap into the global box
         for d in range(3):
             if self.grid[d] == 1:

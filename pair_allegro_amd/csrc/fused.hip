@@ -320,6 +320,31 @@ __device__ __forceinline__ void lin(__amdgpu_buffer_rsrc_t W, int &wp, const f32
 
 // MD: hidden layers of the latent MLP (allegro_mlp_hidden_layers_depth of /root/reference/tests/test_data/test_repro_allegro.yaml:94; 2 there).  1 and 3 exist for the
 // f16x2 instances with the tabulated two-body embedding (round 5: the fused family widened by one axis); every MD-dependent piece below is `if constexpr`.
+// What a tile reads from the edge lists: bounds (scalar), this lane's edge slot, this thread's centre, one slot offset.
+struct TileIn {
+  int a0, a1, e0, e1;
+  float rx, ry, rz;
+  int eii, jat, tt;
+  int2 ci;
+  int eoff;
+};
+__device__ __forceinline__ void tile_fetch(const FusedArgs &A, int tile, int ntiles, int s, int ca, int tid, TileIn &n) {
+  n.a0 = n.a1 = n.e0 = n.e1 = 0;
+  n.rx = 1.f; n.ry = 0.f; n.rz = 0.f;
+  n.eii = 0; n.jat = 0; n.tt = 0; n.ci = make_int2(0, 0); n.eoff = 0;
+  if (tile >= ntiles) return;                      // (uniform)
+  n.a0 = A.tile_a0[tile]; n.a1 = A.tile_a0[tile + 1]; n.e0 = A.tile_e0[tile]; n.e1 = A.tile_e0[tile + 1];
+  const int e = n.e0 + s, na = n.a1 - n.a0;
+  if (e < n.e1) {
+    n.rx = A.rvec[3 * (size_t)e]; n.ry = A.rvec[3 * (size_t)e + 1]; n.rz = A.rvec[3 * (size_t)e + 2];
+    n.eii = A.e_ii[e];
+    n.jat = A.e_j[e];
+    n.tt = A.e_tt[e];
+  }
+  if (ca < na) n.ci = A.centre[n.a0 + ca];
+  if (tid <= na) n.eoff = A.eoff[n.a0 + tid];
+}
+
 template <int NW, bool PROF, int AR, bool TBT, int NLT, int MD = 2>
 __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
   constexpr int NTHREADS = NW * 64, MAXA = Lds<NW>::MAXA;
@@ -382,6 +407,9 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
   int par = 0, cpar = 0, ck = 0;
   int cbase = __builtin_amdgcn_readfirstlane(lds.chunk[0]);
 
+  TileIn nx_;
+  tile_fetch(A, cbase, ntiles, s, ca, tid, nx_);
+
   for (;;) {
     const int tile = cbase + ck;
     if (tile >= ntiles) break;
@@ -389,25 +417,17 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     if (ck == 0 && tid == 0) claimed = (int)atomicAdd(A.tile_counter, (unsigned)A.tchunk);
     // Everything a tile reads from the lists is ONE level of loads behind the (scalar) tile bounds: the edge
     // build packs the type pair per edge and k_tile_info the centre index/type, so no dependent chain
-    // (edge -> centre -> type) is exposed here.
-    const int a0 = A.tile_a0[tile], a1 = A.tile_a0[tile + 1], e0 = A.tile_e0[tile], e1 = A.tile_e0[tile + 1];
+    // (edge -> centre -> type) is exposed here.  The whole set was requested a phase before the previous tile ended (tile_fetch below).
+    const int a0 = nx_.a0, a1 = nx_.a1, e0 = nx_.e0, e1 = nx_.e1;
     const int na = a1 - a0;
     par ^= 1;
     int *const aoffp = lds.aoff[par];
     const int e = e0 + s;
     const bool valid = e < e1;
-    float rx = 1.f, ry = 0.f, rz = 0.f;
-    int aloc = 0, ti = 0, tj = 0, jat = 0, c_i = 0, c_t = 0;
-    if (valid) {
-      rx = A.rvec[3 * (size_t)e]; ry = A.rvec[3 * (size_t)e + 1]; rz = A.rvec[3 * (size_t)e + 2];
-      aloc = A.e_ii[e] - a0;
-      jat = A.e_j[e];
-      const int tt = A.e_tt[e];
-      ti = tt >> 4; tj = tt & 15;
-    }
-    if (ca < na) { const int2 ci = A.centre[a0 + ca]; c_i = ci.x; c_t = ci.y; }   // per-centre output step: atom index, type
-    if (tid <= na) aoffp[tid] = A.eoff[a0 + tid] - e0;
-
+    const float rx = nx_.rx, ry = nx_.ry, rz = nx_.rz;
+    const int aloc = valid ? nx_.eii - a0 : 0, jat = nx_.jat, ti = nx_.tt >> 4, tj = nx_.tt & 15;
+    const int c_i = nx_.ci.x, c_t = nx_.ci.y;                                     // per-centre output step: atom index, type
+    if (tid <= na) aoffp[tid] = nx_.eoff - e0;
     // ---------------- geometry ----------------
     const float d = sqrtf(rx * rx + ry * ry + rz * rz);
     const float inv = 1.f / d;
@@ -793,6 +813,13 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       PHASE(PH_BENV);
     }
     // ---------------- embedding backward ----------------
+    // The NEXT tile's list entries are requested here, two phases before they are used: at the top of a tile they were two dependent
+    // round trips (bounds, then entries) behind the wrap-around weight fragments in the in-order return queue -- 8 % of the wave-cycles.
+    // (The next chunk's first tile was published in lds.chunk by thread 0 during the chunk's first tile, several barriers ago.)
+    {
+      const int ntile = (ck + 1 == A.tchunk) ? __builtin_amdgcn_readfirstlane(lds.chunk[cpar ^ 1]) : tile + 1;
+      tile_fetch(A, ntile, ntiles, s, ca, tid, nx_);
+    }
     f32x4 zt1b[4];
     if constexpr (!TBT) load_rows<4>(SB, R_Z1TB(), zt1b, v16);
     __builtin_amdgcn_sched_barrier(0);

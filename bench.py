@@ -386,6 +386,14 @@ def main():
                 # measured HBM bytes (committed --pmc passes) over its HIP-event time of this run, next to the MFMA figure above
                 hb = traffic / (stage_avg[dom] * 1e-3) / 1e9
                 roof["hbm_measured"] = {"achieved": round(hb, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(hb / 8000.0, 4)}
+            vj = os.path.join(ROOT, "profiles", "vector_memory_path.json")
+            if os.path.exists(vj):
+                # What actually bounds the f16x2 kernels is neither figure above: the CU's vector-memory data-return unit (TD, 64 B/clk) -- weight fragments,
+                # saved rows and gathers all return through it.  Its busy fraction comes from committed --pmc passes on a reduced box of the same workload.
+                vent = json.load(open(vj)).get(f"config{args.config}:{used_path}")
+                if vent:
+                    roof["vector_memory_path"] = {"td_busy": vent["td_busy"], "ta_busy": vent["ta_busy"], "natoms_measured": vent["natoms_measured"],
+                                                  "source": vent["source"], "stale": vent["kernel_hash"] != kernel_source_hash()}
             if "edge_build" in stage_avg:
                 # the neighbor gather (HBM-bound): algorithmic bytes per list entry 4 (j) + 24 (x_j) + 4 (type_j), per edge 20
                 # (e_ii, e_j, rvec) + 1 (packed types) -- DESIGN.md 4.1

@@ -392,7 +392,7 @@ def main():
                 # saved rows and gathers all return through it.  Its busy fraction comes from committed --pmc passes on a reduced box of the same workload.
                 vent = json.load(open(vj)).get(f"config{args.config}:{used_path}")
                 if vent:
-                    roof["vector_memory_path"] = {"td_busy": vent["td_busy"], "ta_busy": vent["ta_busy"], "natoms_measured": vent["natoms_measured"],
+                    roof["vector_memory_path"] = {"td_busy": vent["td_busy"], "ta_busy": vent["ta_busy"], "byte_utilisation": vent.get("return_path_byte_utilisation"), "natoms_measured": vent["natoms_measured"],
                                                   "source": vent["source"], "stale": vent["kernel_hash"] != kernel_source_hash()}
             if "edge_build" in stage_avg:
                 # the neighbor gather (HBM-bound): algorithmic bytes per list entry 4 (j) + 24 (x_j) + 4 (type_j), per edge 20

@@ -203,3 +203,43 @@ def test_rehearsal_of_the_eight_rank_run_on_one_gpu(tmp_path):
         assert sum(e["nlocal"]) == 10648 and min(e["nghost"]) > 0 and e["max_abs_dF_setup"] < 5e-6 and e["d_pe_per_atom_setup"] < 1e-7
         assert e["comm_transport"] == "hosted" or e["comm_transport"].startswith("library")
     assert min(d["overlapped"]["n_interior"]) > 0
+
+
+@pytest.mark.parametrize("ncell", [2, 6])
+def test_library_borders_on_the_device_equal_the_swap_chain(hip_lib, model_dir, ncell):
+    """ahip_borders_local_dev on the GPU (count / scan / fill kernels) against the torch swap chain of md.py on the same positions: same set of
+    (source atom, shift) images, same image positions and types; ncell = 2: a box thinner than two halos (images in both directions of a dimension),
+    and a first capacity guess that is too small (the call reports the count, the driver retries).  CPU twin: tests/test_md_emu.py."""
+    cfg, w, _m = _model(model_dir, hip_lib)
+    _m.close()
+    path = os.path.join(model_dir, "md_float32.ahip")
+    cell, pos, _ = lmp_like.diamond_si(ncell)
+    box = np.diag(cell)
+    pos = pos + np.random.default_rng(7).normal(0, 0.05, pos.shape)
+    pos -= np.floor(pos / box) * box
+    mt = np.zeros(len(pos), np.int32)
+    dev = torch.device("cuda", 0)
+
+    def ghosts(use_lib):
+        model = capi.Model(path, 0, hip_lib)
+        sim = md.Simulation(md.HipBackend(model, [MASS]), box, cfg["r_max"], 1.0, pos, mt, None, dev, overlap=False)
+        nl = sim.nlocal
+        sim.x, sim.mtype = sim.x[:nl].contiguous(), sim.mtype[:nl].contiguous()
+        if use_lib:
+            sim._nghost_last = 8
+        else:
+            sim._borders_local = lambda: False
+        sim._borders()
+        assert sim.nall == sim.x.shape[0] == sim.mtype.shape[0]
+        g = np.concatenate([sim._ghost_src.cpu().numpy()[:, None].astype(np.float64), sim._ghost_shift.cpu().numpy(), sim.x[nl:].cpu().numpy()], axis=1)
+        xl = sim.x[:nl].cpu().numpy().copy()
+        torch.cuda.synchronize()
+        model.close()
+        return xl, g[np.lexsort(g.T[::-1])]
+
+    xa, ga = ghosts(False)
+    xb, gb = ghosts(True)
+    np.testing.assert_array_equal(xa, xb)
+    assert ga.shape == gb.shape and ga.shape[0] > 0
+    np.testing.assert_array_equal(ga[:, :4], gb[:, :4])
+    np.testing.assert_allclose(ga[:, 4:7], gb[:, 4:7], rtol=0, atol=1e-12)

@@ -285,11 +285,19 @@ enum { PH_GEOM = 0, PH_TB, PH_EMB, PH_ENV, PH_TP, PH_MIX, PH_LAT, PH_OUT, PH_BLA
 // AR: arithmetic of the tile's linears: 0 = f32-input MFMA, 1 = bf16x3 (three-term split, float32-equivalent), 2 = tf32eq (two-term bf16 split),
 // 3 = f16x2 (two float16 terms, float32-equivalent inside float16's exponent range: fused_h.h)
 template <int AR> struct RingT {
+  int act = 1;                 // wave-uniform: 0 while the wave's 16 slots of the current tile hold no edge (its linears are skipped, see the tile loop)
   f32x4 f[AR != 0 ? 1 : RING];
   u32x4 b[AR == 0 ? 1 : (AR == 1 ? RINGB : AR == 2 ? RINGB2 : RINGH)];
 };
 template <int AR, int KT, int NT, bool ACC, int RPI, class Epi>
 __device__ __forceinline__ void lin(__amdgpu_buffer_rsrc_t W, int &wp, const f32x4 (&in)[KT], f32x4 (&out)[NT], int v16, RingT<AR> &ring, Epi epi) {
+  if (!ring.act) {             // (uniform) a wave without edges in this tile: no fragments, no MFMAs, no epilogue; finite outputs for the arithmetic around the linears
+    if constexpr (!ACC) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) out[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    return;
+  }
   if constexpr (AR == 3) {
     static_assert(KT % 2 == 0, "K-steps are pairs of 16-feature tiles");
     Hop b[1][KT / 2], unused[1][NT / 2];
@@ -419,6 +427,17 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     // build packs the type pair per edge and k_tile_info the centre index/type, so no dependent chain
     // (edge -> centre -> type) is exposed here.  The whole set was requested a phase before the previous tile ended (tile_fetch below).
     const int a0 = nx_.a0, a1 = nx_.a1, e0 = nx_.e0, e1 = nx_.e1;
+    // A wave whose 16 slots lie behind the tile's last edge (one 33..48-edge centre in a 64-slot tile: Li3PO4, 45 % of the tiles) skips every linear of the tile
+    // (lin: ring.act) and addresses its saved rows out of range (loads return 0, stores are dropped); it still takes part in the barriers and in the per-centre
+    // reductions, which never read its slots.  Its stream position needs no repair: a tile ends with wp = stream start and the ring holding the stream's first
+    // fragments, which is what the wave's ring has held since its last active tile.
+    // The branch pays twice.  Li3PO4 (102 400 atoms): 9.30 -> 7.77 ms.  And 1 M Si, where no wave is ever empty (56 of 64 slots): 44.7 -> 39.7 ms -- the same with
+    // a condition that is always true (profiles/r05_w_last_experiments.md §6): a wave-uniform branch around each linear makes it a scheduling / allocation region of
+    // its own (spills of the headline instance 304 -> 120 B per lane).  The wide kernels lose with the same branch (fused_lx2: 20.3 -> 21.9 ms): their linears are
+    // ordered by hand across each other.
+    const int wact = __builtin_amdgcn_readfirstlane(e0 + wave * 16 < e1 ? 1 : 0);
+    ring.act = wact;
+    const int v16t = wact ? v16 : 0x7ffffff0;
     const int na = a1 - a0;
     par ^= 1;
     int *const aoffp = lds.aoff[par];
@@ -469,7 +488,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         const f32x4 c2 = *(const f32x4 *)(tb_ent + (t * 4 + 2) * 16), c3 = *(const f32x4 *)(tb_ent + (t * 4 + 3) * 16);
         x[t] = (c0 + tb_t * (c1 + tb_t * (c2 + tb_t * c3))) * vm;
         // d x0 / dd for the backward pass: one coalesced row now instead of three per-edge gathers then
-        bstore(SB, v16, (R_Z1TB() + t) * ROW * 4, (c1 + tb_t * (2.f * c2 + (3.f * tb_t) * c3)) * (vm * tb_invh));
+        bstore(SB, v16t, (R_Z1TB() + t) * ROW * 4, (c1 + tb_t * (2.f * c2 + (3.f * tb_t) * c3)) * (vm * tb_invh));
       }
     } else {
       f32x4 z[4], z2[4];
@@ -486,16 +505,16 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         bfin[0][r] = g < 2 ? pref * __builtin_amdgcn_sinf(0.5f * n * xx) * inv * fc : 0.f;
         bfin[1][r] = 0.f;
       }
-      lin<AR, 2, 4, true, 0>(WB, wp, bfin, z, v16, ring, EpiSiluSaveD{SB, R_Z1TB(), v16});
-      lin<AR, 4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, R_Z2TB(), v16});
-      lin<AR, 4, 4, false, 0>(WB, wp, z2, x, v16, ring, EpiSaveScale{{SB, R_U0(), v16}, fc});
+      lin<AR, 2, 4, true, 0>(WB, wp, bfin, z, v16t, ring, EpiSiluSaveD{SB, R_Z1TB(), v16t});
+      lin<AR, 4, 4, false, 0>(WB, wp, z, z2, v16t, ring, EpiSiluSaveD{SB, R_Z2TB(), v16t});
+      lin<AR, 4, 4, false, 0>(WB, wp, z2, x, v16t, ring, EpiSaveScale{{SB, R_U0(), v16t}, fc});
     }
     PHASE(PH_TB);
     // ---------------- tensor embedding weights (V^0 = w0 (x) Y is rebuilt where needed) -------------
     {
       f32x4 w0[4];
       // w0 goes to scratch (backward) and to the LDS park rows 0..3, where layer 0 picks it up
-      lin<AR, 4, 4, false, 0>(WB, wp, x, w0, v16, ring, EpiSavePark{{SB, R_W0(), v16}, pk, 0, lane});
+      lin<AR, 4, 4, false, 0>(WB, wp, x, w0, v16t, ring, EpiSavePark{{SB, R_W0(), v16t}, pk, 0, lane});
     }
     if (ck == 0 && tid == 0) lds.chunk[cpar ^ 1] = claimed;
     __syncthreads();          // aoff visible; previous tile's LDS users done
@@ -511,7 +530,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       f32x4 V[4][2];
       {
         f32x4 om[4];
-        lin<AR, 4, 4, false, 0>(WB, wp, x, om, v16, ring, EpiSaveFrom2{{SB, RL + 0, v16}});      // rows RL + 2, RL + 3: the l = 1 weights, all the backward pass reads
+        lin<AR, 4, 4, false, 0>(WB, wp, x, om, v16t, ring, EpiSaveFrom2{{SB, RL + 0, v16t}});      // rows RL + 2, RL + 3: the l = 1 weights, all the backward pass reads
         // environment sum over the centre's edges
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -567,32 +586,32 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       // channel mixing -> V^{kk+1}: saved in the next layer's VIN rows and parked in LDS
       if (!last) {
         f32x4 o2[2];
-        lin<AR, 2, 2, false, 0>(WB, wp, Vp[0], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 0, v16}, pk, 0, lane});
-        lin<AR, 2, 2, false, 1>(WB, wp, Vp[1], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 2, v16}, pk, 2, lane});
-        lin<AR, 2, 2, false, 2>(WB, wp, Vp[2], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 4, v16}, pk, 4, lane});
-        lin<AR, 2, 2, false, 3>(WB, wp, Vp[3], o2, v16, ring, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 6, v16}, pk, 6, lane});
+        lin<AR, 2, 2, false, 0>(WB, wp, Vp[0], o2, v16t, ring, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 0, v16t}, pk, 0, lane});
+        lin<AR, 2, 2, false, 1>(WB, wp, Vp[1], o2, v16t, ring, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 2, v16t}, pk, 2, lane});
+        lin<AR, 2, 2, false, 2>(WB, wp, Vp[2], o2, v16t, ring, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 4, v16t}, pk, 4, lane});
+        lin<AR, 2, 2, false, 3>(WB, wp, Vp[3], o2, v16t, ring, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 6, v16t}, pk, 6, lane});
       }
       PHASE(PH_MIX);
       // latent MLP
       {
         f32x4 cat[6], z[4], z2[4];
         cat[0] = x[0]; cat[1] = x[1]; cat[2] = x[2]; cat[3] = x[3]; cat[4] = Vp[0][0]; cat[5] = Vp[0][1];
-        if constexpr (SAVEZ && MD == 1) lin<AR, 6, 4, false, 0>(WB, wp, cat, z, v16, ring, EpiSiluSaveZ{SB, RL + 4, v16});
-        else lin<AR, 6, 4, false, 0>(WB, wp, cat, z, v16, ring, EpiSiluSaveD{SB, RL + 4, v16});
+        if constexpr (SAVEZ && MD == 1) lin<AR, 6, 4, false, 0>(WB, wp, cat, z, v16t, ring, EpiSiluSaveZ{SB, RL + 4, v16t});
+        else lin<AR, 6, 4, false, 0>(WB, wp, cat, z, v16t, ring, EpiSiluSaveD{SB, RL + 4, v16t});
         if constexpr (MD >= 2) {
-          if constexpr (SAVEZ && MD == 2) lin<AR, 4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSaveZ{SB, RL + 8, v16});
-          else lin<AR, 4, 4, false, 0>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, RL + 8, v16});
+          if constexpr (SAVEZ && MD == 2) lin<AR, 4, 4, false, 0>(WB, wp, z, z2, v16t, ring, EpiSiluSaveZ{SB, RL + 8, v16t});
+          else lin<AR, 4, 4, false, 0>(WB, wp, z, z2, v16t, ring, EpiSiluSaveD{SB, RL + 8, v16t});
         }
         if constexpr (MD >= 3) {
-          if constexpr (SAVEZ) lin<AR, 4, 4, false, 0>(WB, wp, z2, z, v16, ring, EpiSiluSaveZ{SB, RL + 12, v16});
-          else lin<AR, 4, 4, false, 0>(WB, wp, z2, z, v16, ring, EpiSiluSaveD{SB, RL + 12, v16});
+          if constexpr (SAVEZ) lin<AR, 4, 4, false, 0>(WB, wp, z2, z, v16t, ring, EpiSiluSaveZ{SB, RL + 12, v16t});
+          else lin<AR, 4, 4, false, 0>(WB, wp, z2, z, v16t, ring, EpiSiluSaveD{SB, RL + 12, v16t});
         }
         f32x4 (&zl)[4] = MD == 2 ? z2 : z;              // output of the last hidden layer
         const float ra = lds.res[kk][0], rbf = lds.res[kk][1] * fc;
         if (!last) {
           f32x4 xn[4];
-          if constexpr (SAVEZ) lin<AR, 4, 4, false, 0>(WB, wp, zl, xn, v16, ring, EpiResidualNS<4>{x, ra, rbf});
-          else lin<AR, 4, 4, false, 0>(WB, wp, zl, xn, v16, ring, EpiResidual<4>{{SB, RL + OU, v16}, x, ra, rbf});
+          if constexpr (SAVEZ) lin<AR, 4, 4, false, 0>(WB, wp, zl, xn, v16t, ring, EpiResidualNS<4>{x, ra, rbf});
+          else lin<AR, 4, 4, false, 0>(WB, wp, zl, xn, v16t, ring, EpiResidual<4>{{SB, RL + OU, v16t}, x, ra, rbf});
           x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2]; x[3] = xn[3];
         } else {
           // Last layer: its new latent x' = ra x + rb fc (z2 W3) feeds nothing but the read-out's first linear, and no non-linearity
@@ -600,9 +619,9 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
           // 64 -> 32 linears instead of a 64 -> 64 and a 64 -> 32 one, here and (transposed) in the backward pass: 64 of the tile's
           // 1472 MFMAs per wave and two saved rows less.  z2 first: it dies there.
           f32x4 za[2], up[2];
-          if constexpr (SAVEZ) lin<AR, 4, 2, false, 0>(WB, wp, zl, up, v16, ring, EpiNone{});
-          else lin<AR, 4, 2, false, 0>(WB, wp, zl, up, v16, ring, EpiSave{SB, RL + OU, v16});
-          lin<AR, 4, 2, false, 0>(WB, wp, x, za, v16, ring, EpiNone{});
+          if constexpr (SAVEZ) lin<AR, 4, 2, false, 0>(WB, wp, zl, up, v16t, ring, EpiNone{});
+          else lin<AR, 4, 2, false, 0>(WB, wp, zl, up, v16t, ring, EpiSave{SB, RL + OU, v16t});
+          lin<AR, 4, 2, false, 0>(WB, wp, x, za, v16t, ring, EpiNone{});
           zr[0] = ra * za[0] + rbf * up[0]; zr[1] = ra * za[1] + rbf * up[1];
         }
       }
@@ -614,8 +633,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     // round trip is an L2 miss: ~2 us): u and z2 of the last layer now, under the read-out MFMAs
     f32x4 upre[4], zt[4], w0h[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) if (!SAVEZ) upre[t] = bload(SB, v16, (R_LAYER(NL - 1, MD) + OU + t) * ROW * 4);       // the last layer saved two rows: z2 (W3 Wr)
-    load_rows<4>(SB, R_LAYER(NL - 1, MD) + OZL, zt, v16);
+    for (int t = 0; t < 2; ++t) if (!SAVEZ) upre[t] = bload(SB, v16t, (R_LAYER(NL - 1, MD) + OU + t) * ROW * 4);       // the last layer saved two rows: z2 (W3 Wr)
+    load_rows<4>(SB, R_LAYER(NL - 1, MD) + OZL, zt, v16t);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 wo1[2];
 #pragma unroll
@@ -637,7 +656,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) dzr[t][r] = deps * wo1[t][r] * dsilu1(zr[t][r]);
-    lin<AR, 2, 4, false, 0>(WB, wp, dzr, dx, v16, ring, EpiNone{});               // dzr Wr^T = the gradient w.r.t. x' of the last layer
+    lin<AR, 2, 4, false, 0>(WB, wp, dzr, dx, v16t, ring, EpiNone{});               // dzr Wr^T = the gradient w.r.t. x' of the last layer
     float dfc_part = 0.f, dY1 = 0.f, dY2 = 0.f, dY3 = 0.f;
     PHASE(PH_OUT);
 
@@ -652,19 +671,19 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         if (!last && SAVEZ) {
           // the u rows are not saved: <u, g> = <silu(z), g W^T> comes out of the first backward linear's epilogue (EpiMulSiluZ), whose input is the unscaled gradient
           const float ra = lds.res[kk][0], rb = lds.res[kk][1];
-          if constexpr (MD >= 2) load_rows<4>(SB, RL + OZL - 4, zt1, v16);
+          if constexpr (MD >= 2) load_rows<4>(SB, RL + OZL - 4, zt1, v16t);
           __builtin_amdgcn_sched_barrier(0);
           float ug = 0.f;
-          lin<AR, 4, 4, false, 0>(WB, wp, dx, dh, v16, ring, EpiMulSiluZ<4>{zt, rb * fc, ug});
+          lin<AR, 4, 4, false, 0>(WB, wp, dx, dh, v16t, ring, EpiMulSiluZ<4>{zt, rb * fc, ug});
           dfc_part += rb * ug;
 #pragma unroll
           for (int t = 0; t < 4; ++t) dx[t] = ra * dx[t];
         } else if (last && SAVEZ) {
           const float ra = lds.res[kk][0], rb = lds.res[kk][1];
-          if constexpr (MD >= 2) load_rows<4>(SB, RL + OZL - 4, zt1, v16);
+          if constexpr (MD >= 2) load_rows<4>(SB, RL + OZL - 4, zt1, v16t);
           __builtin_amdgcn_sched_barrier(0);
           float ug = 0.f;
-          lin<AR, 2, 4, false, 0>(WB, wp, dzr, dh, v16, ring, EpiMulSiluZ<4>{zt, rb * fc, ug});
+          lin<AR, 2, 4, false, 0>(WB, wp, dzr, dh, v16t, ring, EpiMulSiluZ<4>{zt, rb * fc, ug});
           dfc_part += rb * ug;
 #pragma unroll
           for (int t = 0; t < 4; ++t) dx[t] = ra * dx[t];
@@ -677,9 +696,9 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) { du[t] = rbfc * dx[t]; dx[t] = ra * dx[t]; }
           dfc_part += rb * ((accv[0] + accv[1]) + (accv[2] + accv[3]));
-          if constexpr (MD >= 2) load_rows<4>(SB, RL + OZL - 4, zt1, v16);                  // silu' of the hidden layer below the last: first used 96 MFMAs from here
+          if constexpr (MD >= 2) load_rows<4>(SB, RL + OZL - 4, zt1, v16t);                  // silu' of the hidden layer below the last: first used 96 MFMAs from here
           __builtin_amdgcn_sched_barrier(0);
-          lin<AR, 4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt});
+          lin<AR, 4, 4, false, 0>(WB, wp, du, dh, v16t, ring, EpiMulRows<4>{zt});
         } else {
           // last layer (read-out folded in, see the forward pass): upre = the two rows z2 (W3 Wr); the z2 gradient comes straight
           // from dzr through (W3 Wr)^T
@@ -692,27 +711,27 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) dx[t] = ra * dx[t];
           dfc_part += rb * ((accv[0] + accv[1]) + (accv[2] + accv[3]));
-          if constexpr (MD >= 2) load_rows<4>(SB, RL + OZL - 4, zt1, v16);
+          if constexpr (MD >= 2) load_rows<4>(SB, RL + OZL - 4, zt1, v16t);
           __builtin_amdgcn_sched_barrier(0);
-          lin<AR, 2, 4, false, 0>(WB, wp, du2, dh, v16, ring, EpiMulRows<4>{zt});
+          lin<AR, 2, 4, false, 0>(WB, wp, du2, dh, v16t, ring, EpiMulRows<4>{zt});
         }
         // prefetch V^{kk} (input of this layer's tensor product) under the MFMAs that follow
         if (kk > 0) {
 #pragma unroll
-          for (int lm = 0; lm < 4; ++lm) load_rows<2>(SB, RL + OVIN + 2 * lm, Vk[lm], v16);
-        } else load_rows<4>(SB, R_W0(), W0b, v16);
+          for (int lm = 0; lm < 4; ++lm) load_rows<2>(SB, RL + OVIN + 2 * lm, Vk[lm], v16t);
+        } else load_rows<4>(SB, R_W0(), W0b, v16t);
         __builtin_amdgcn_sched_barrier(0);
         // down the hidden layers: g_{k-1} = (g_k W_k^T) * silu'(z_{k-1}), then dcat = g_0 W_0^T
         f32x4 dcat[6];
-        if constexpr (MD == 1) lin<AR, 4, 6, false, 0>(WB, wp, dh, dcat, v16, ring, EpiNone{});
+        if constexpr (MD == 1) lin<AR, 4, 6, false, 0>(WB, wp, dh, dcat, v16t, ring, EpiNone{});
         else {
           f32x4 zt0[4];
-          if constexpr (MD == 3) load_rows<4>(SB, RL + 4, zt0, v16);
-          lin<AR, 4, 4, false, 0>(WB, wp, dh, du, v16, ring, EpiMulRows<4>{zt1});
+          if constexpr (MD == 3) load_rows<4>(SB, RL + 4, zt0, v16t);
+          lin<AR, 4, 4, false, 0>(WB, wp, dh, du, v16t, ring, EpiMulRows<4>{zt1});
           if constexpr (MD == 3) {
-            lin<AR, 4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt0});
-            lin<AR, 4, 6, false, 0>(WB, wp, dh, dcat, v16, ring, EpiNone{});
-          } else lin<AR, 4, 6, false, 0>(WB, wp, du, dcat, v16, ring, EpiNone{});
+            lin<AR, 4, 4, false, 0>(WB, wp, du, dh, v16t, ring, EpiMulRows<4>{zt0});
+            lin<AR, 4, 6, false, 0>(WB, wp, dh, dcat, v16t, ring, EpiNone{});
+          } else lin<AR, 4, 6, false, 0>(WB, wp, du, dcat, v16t, ring, EpiNone{});
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) dx[t] += dcat[t];
@@ -726,20 +745,20 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         }
       }
       f32x4 om1[2];
-      load_rows<2>(SB, RL + 2, om1, v16);                    // omega of this layer, l = 1 part: used after the gradient reduction
+      load_rows<2>(SB, RL + 2, om1, v16t);                    // omega of this layer, l = 1 part: used after the gradient reduction
       __builtin_amdgcn_sched_barrier(0);
       PHASE(PH_BLAT);
       if (!last) {
         f32x4 in2[2], o2[2];
         in2[0] = park_load(pk, 0, lane); in2[1] = park_load(pk, 1, lane);
-        lin<AR, 2, 2, false, 0>(WB, wp, in2, o2, v16, ring, EpiNone{});
+        lin<AR, 2, 2, false, 0>(WB, wp, in2, o2, v16t, ring, EpiNone{});
         dVp[0][0] += o2[0]; dVp[0][1] += o2[1];
         in2[0] = park_load(pk, 2, lane); in2[1] = park_load(pk, 3, lane);
-        lin<AR, 2, 2, false, 1>(WB, wp, in2, dVp[1], v16, ring, EpiNone{});
+        lin<AR, 2, 2, false, 1>(WB, wp, in2, dVp[1], v16t, ring, EpiNone{});
         in2[0] = park_load(pk, 4, lane); in2[1] = park_load(pk, 5, lane);
-        lin<AR, 2, 2, false, 2>(WB, wp, in2, dVp[2], v16, ring, EpiNone{});
+        lin<AR, 2, 2, false, 2>(WB, wp, in2, dVp[2], v16t, ring, EpiNone{});
         in2[0] = park_load(pk, 6, lane); in2[1] = park_load(pk, 7, lane);
-        lin<AR, 2, 2, false, 3>(WB, wp, in2, dVp[3], v16, ring, EpiNone{});
+        lin<AR, 2, 2, false, 3>(WB, wp, in2, dVp[3], v16t, ring, EpiNone{});
       }
       __builtin_amdgcn_sched_barrier(0);
       PHASE(PH_BMIX);
@@ -798,17 +817,17 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
           __builtin_amdgcn_sched_barrier(0);
         }
         if (kk > 0) {                                                      // next iteration's u and z2 rows
-          if (!SAVEZ) load_rows<4>(SB, R_LAYER(kk - 1, MD) + OU, upre, v16);
-          load_rows<4>(SB, R_LAYER(kk - 1, MD) + OZL, zt, v16);
+          if (!SAVEZ) load_rows<4>(SB, R_LAYER(kk - 1, MD) + OU, upre, v16t);
+          load_rows<4>(SB, R_LAYER(kk - 1, MD) + OZL, zt, v16t);
         } else {                                                           // two-body u and z2 rows, l=1 embedding weights
           if constexpr (!TBT) {
-            load_rows<4>(SB, R_U0(), upre, v16);
-            load_rows<4>(SB, R_Z2TB(), zt, v16);
-          } else load_rows<4>(SB, R_Z1TB(), zt, v16);                      // d x0 / dd rows of the two-body table
-          load_rows<2>(SB, R_W0() + 2, w0h, v16);
+            load_rows<4>(SB, R_U0(), upre, v16t);
+            load_rows<4>(SB, R_Z2TB(), zt, v16t);
+          } else load_rows<4>(SB, R_Z1TB(), zt, v16t);                      // d x0 / dd rows of the two-body table
+          load_rows<2>(SB, R_W0() + 2, w0h, v16t);
         }
         __builtin_amdgcn_sched_barrier(0);
-        lin<AR, 4, 4, true, 0>(WB, wp, dom, dx, v16, ring, EpiNone{});
+        lin<AR, 4, 4, true, 0>(WB, wp, dom, dx, v16t, ring, EpiNone{});
       }
       PHASE(PH_BENV);
     }
@@ -821,7 +840,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       tile_fetch(A, ntile, ntiles, s, ca, tid, nx_);
     }
     f32x4 zt1b[4];
-    if constexpr (!TBT) load_rows<4>(SB, R_Z1TB(), zt1b, v16);
+    if constexpr (!TBT) load_rows<4>(SB, R_Z1TB(), zt1b, v16t);
     __builtin_amdgcn_sched_barrier(0);
     {
       f32x4 dw0[4];
@@ -833,7 +852,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { dY1 += d1[r] * w0h[t][r]; dY2 += d2[r] * w0h[t][r]; dY3 += d3[r] * w0h[t][r]; }
       }
-      lin<AR, 4, 4, true, 0>(WB, wp, dw0, dx, v16, ring, EpiNone{});
+      lin<AR, 4, 4, true, 0>(WB, wp, dw0, dx, v16t, ring, EpiNone{});
       if constexpr (TBT) wp = A.o_stream;                                 // last linear of the tile
     }
     PHASE(PH_BEMB);
@@ -854,10 +873,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         for (int r = 0; r < 4; ++r) { acc += upre[t][r] * dx[t][r]; du[t][r] = fc * dx[t][r]; }
       dfc_part += acc;
       __builtin_amdgcn_sched_barrier(0);
-      lin<AR, 4, 4, false, 0>(WB, wp, du, dh, v16, ring, EpiMulRows<4>{zt});
-      lin<AR, 4, 4, false, 0>(WB, wp, dh, du, v16, ring, EpiMulRows<4>{zt1b});
+      lin<AR, 4, 4, false, 0>(WB, wp, du, dh, v16t, ring, EpiMulRows<4>{zt});
+      lin<AR, 4, 4, false, 0>(WB, wp, dh, du, v16t, ring, EpiMulRows<4>{zt1b});
       f32x4 dbf[2];
-      lin<AR, 4, 2, false, 0>(WB, wp, du, dbf, v16, ring, EpiNone{});   // its prefetches already fetch the next tile's first fragments
+      lin<AR, 4, 2, false, 0>(WB, wp, du, dbf, v16t, ring, EpiNone{});   // its prefetches already fetch the next tile's first fragments
       wp = A.o_stream;                                                    // (the stream ends with a copy of its first RING entries)
       const float dfdd = dfc_dx / rc;
 #pragma unroll
@@ -887,12 +906,11 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         float *dp = A.dbg + 8 * (size_t)e;
         dp[0] = gx; dp[1] = gy; dp[2] = gz; dp[3] = dd; dp[4] = dfc_tot; dp[5] = y1; dp[6] = y2; dp[7] = y3;
       }
-      const float m = valid ? 1.f : 0.f;
 #if !defined(ABL_NOW) && !defined(ABL_NOROWS) && !defined(ABL_NOROWLD) && !defined(ABL_NOROWST)
       if (AR == 3 && valid && !(fabsf(gx) + fabsf(gy) + fabsf(gz) + fabsf(eps) < 3.0e38f)) *A.err = 1;      // inf / NaN: an operand left float16's range
 #endif
       if (g == 0) {
-        st[0] = m * gx; st[1] = m * gy; st[2] = m * gz; st[3] = m * eps;
+        st[0] = valid ? gx : 0.f; st[1] = valid ? gy : 0.f; st[2] = valid ? gz : 0.f; st[3] = valid ? eps : 0.f;      // selects, not products: a skipped wave's values are arbitrary
         if (valid) {
 #ifndef ABL_NOATOM      // timing experiment only (results are wrong): no force scatter to the neighbour atoms
           atomicAdd(&A.f[3 * (size_t)jat], -(double)gx);
@@ -902,8 +920,9 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         }
       }
       // virial of this wave's 16 edges: butterfly over the slot lanes, lane 0 publishes 6 partials
-      float w6[6] = {-m * rx * gx, -m * ry * gy, -m * rz * gz, -m * 0.5f * (rx * gy + ry * gx),
-                     -m * 0.5f * (rx * gz + rz * gx), -m * 0.5f * (ry * gz + rz * gy)};
+      float w6[6] = {-rx * gx, -ry * gy, -rz * gz, -0.5f * (rx * gy + ry * gx), -0.5f * (rx * gz + rz * gx), -0.5f * (ry * gz + rz * gy)};
+#pragma unroll
+      for (int c = 0; c < 6; ++c) w6[c] = valid ? w6[c] : 0.f;
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
 #pragma unroll

@@ -13,6 +13,7 @@ case $obj in
   fused_lx2|fused_lx) SPEC="-mllvm -pragma-unroll-threshold=1000000" ;;
   *) echo "unknown object $obj"; exit 1 ;;
 esac
+[ -n "$ABL_SPEC" ] && SPEC="$ABL_SPEC"      # ABL_SPEC=... replaces the per-object options of the Makefile (e.g. to drop an -mllvm flag)
 ALL="allegro_hip.o prims.o neigh.o edges.o gemm.o fused.o fused_bf.o fused_h.o fused_lx.o fused_lx2.o comm.o model_io.o"
 for v in "$@"; do
   name=${v%%:*}; flags=${v#*:}

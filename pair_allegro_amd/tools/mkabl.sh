@@ -10,7 +10,8 @@ COMMON="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -fno-slp-
 case $obj in
   fused_h)   SPEC="-DAHIP_FUSED_PART=2 -mllvm -amdgpu-use-amdgpu-trackers=1 -mllvm -disable-machine-licm -mllvm -disable-postra-machine-licm"; SRC=fused.hip ;;
   fused)     SPEC="-DAHIP_FUSED_PART=0 -mllvm -amdgpu-use-amdgpu-trackers=1 -mllvm -disable-machine-licm -mllvm -disable-postra-machine-licm" ;;
-  fused_lx2|fused_lx) SPEC="-mllvm -pragma-unroll-threshold=1000000" ;;
+  fused_lx2) SPEC="-mllvm -pragma-unroll-threshold=1000000 -mllvm -disable-machine-licm -mllvm -disable-postra-machine-licm -mllvm -amdgpu-use-amdgpu-trackers=1" ;;
+  fused_lx)  SPEC="-mllvm -pragma-unroll-threshold=1000000 -mllvm -disable-machine-licm -mllvm -disable-postra-machine-licm" ;;
   *) echo "unknown object $obj"; exit 1 ;;
 esac
 [ -n "$ABL_SPEC" ] && SPEC="$ABL_SPEC"      # ABL_SPEC=... replaces the per-object options of the Makefile (e.g. to drop an -mllvm flag)

@@ -43,6 +43,9 @@
 // weight fragments in flight per wave: 4 (two steps ahead) instead of the wide kernels' 8 -- the 16 registers are worth more to this kernel than the deeper prefetch
 // (1 M-atom Si: 58.3 -> 56.8 ms; 2 fragments: slower than 4)
 #define AHIP_RING 4
+#ifndef AHIP_X_PARKV
+#define AHIP_X_PARKV 1
+#endif
 #include "fused_common.h"
 #include "fused_h.h"
 #include "prims.h"
@@ -99,20 +102,20 @@ struct FusedArgs {
   int *err;                               // host-mapped word: set when an edge gradient comes out non-finite (float16 range exceeded)
 };
 
-template <int NW> struct __attribute__((aligned(16))) Lds {
+template <int NW, int NL = MAXNL> struct __attribute__((aligned(16))) Lds {
   static constexpr int SLOTS = 16 * NW;
-  static constexpr int MAXA = NW == 4 ? 6 : 12;   // centre atoms per tile (LDS budget)
+  static constexpr int MAXA = NW == 2 ? 3 : NW == 4 ? 6 : 12;   // centre atoms per tile (LDS budget)
   float stage[SLOTS * STG_LD];
-  float env[MAXNL][MAXA * ENV_LD];
+  float env[NL][MAXA * ENV_LD];
   float denv[MAXA * ENV_LD];
-  float tp[MAXNL][5 * 32];                // tensor-product path weights [layer][path][u]
+  float tp[NL][5 * 32];                   // tensor-product path weights [layer][path][u]
   float park[NW][8 * ROW];                // per-wave private park: V^{k+1} forward, dE/dV backward ([lm][t] images)
   double eacc[MAXA];                      // energy accumulated over this workgroup's tiles, per centre slot (one owner thread each)
   double virw[NW][6];                     // virial accumulated per wave (owner: lanes 0..5 of the wave)
   int aoff[2][MAXA + 2];                  // slot offsets of the tile's centres, double-buffered by tile parity
   float rc[16];                           // model cutoff table [T*T] for T <= 4 (more types: read from A.rcut, the LDS budget of two workgroups per CU is spent)
   float scale[16], shift[16];             // per-type energy scale / shift
-  float res[MAXNL][2];                    // residual update coefficients per layer
+  float res[NL][2];                       // residual update coefficients per layer
   int chunk[2];                           // first tile of the current / next claimed chunk
 };
 
@@ -259,7 +262,7 @@ template <int RB> __device__ __forceinline__ void ring_prime_b(__amdgpu_buffer_r
 
 // Per-centre sum of the staged tile: dst[a][f] = scale * sum_{slots of a} stage[slot][f], f < 128.
 // 128 features x (NW/2) atoms per pass; 4 independent accumulators keep 4 LDS reads in flight.
-template <int NW> __device__ __forceinline__ void reduce_stage(const Lds<NW> &lds, const int *aoff, float *dst, int na, float scale, int tid) {
+template <int NW, int NL> __device__ __forceinline__ void reduce_stage(const Lds<NW, NL> &lds, const int *aoff, float *dst, int na, float scale, int tid) {
   const int fidx = tid & 127;
   for (int a = tid >> 7; a < na; a += NW / 2) {
     const int s0 = aoff[a], s1 = aoff[a + 1];
@@ -360,9 +363,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
   // pass needs u only for <u, g> (the cutoff gradient), and <u, g> = <silu(z), g W^T> falls out of its first linear's epilogue (EpiMulSiluZ), which rebuilds silu and silu'
   // from z -- 6 row stores and 6 row loads fewer per wave-tile of a two-layer model for ~10 VALU operations per value there: 45.8 -> 44.4 ms at 1 M Si atoms.
   constexpr bool SAVEZ = AR == 3;
+  constexpr bool PARKV = AHIP_X_PARKV != 0;
   constexpr int OZL = 4 + 4 * (MD - 1), OU = 4 + 4 * MD, OVIN = 8 + 4 * MD;      // row offsets inside a layer: silu' of the LAST hidden layer, u, V_in (MD = 2: 8, 12, 16)
   static_assert(MD >= 1 && MD <= 3 && (MD == 2 || (AR == 3 && TBT)), "latent MLP depth 1 / 3: f16x2 instances with the two-body table only");
-  __shared__ Lds<NW> lds;
+  __shared__ Lds<NW, NLT> lds;
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
   const int v16 = lane * 16;
   // wave-uniform buffer descriptors (made provably uniform with readfirstlane)
@@ -586,10 +590,19 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       // channel mixing -> V^{kk+1}: saved in the next layer's VIN rows and parked in LDS
       if (!last) {
         f32x4 o2[2];
-        lin<AR, 2, 2, false, 0>(WB, wp, Vp[0], o2, v16t, ring, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 0, v16t}, pk, 0, lane});
-        lin<AR, 2, 2, false, 1>(WB, wp, Vp[1], o2, v16t, ring, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 2, v16t}, pk, 2, lane});
-        lin<AR, 2, 2, false, 2>(WB, wp, Vp[2], o2, v16t, ring, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 4, v16t}, pk, 4, lane});
-        lin<AR, 2, 2, false, 3>(WB, wp, Vp[3], o2, v16t, ring, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 6, v16t}, pk, 6, lane});
+        if (PARKV && kk + 1 == NL - 1) {
+          // the LAST layer's input tensor is not saved: nothing writes the park between its forward tensor product and its backward one (the last layer has
+          // no channel mixing), so the backward pass reads it from there -- 8 row stores and 8 row loads fewer per wave-tile
+          lin<AR, 2, 2, false, 0>(WB, wp, Vp[0], o2, v16t, ring, EpiPark{pk, 0, lane});
+          lin<AR, 2, 2, false, 1>(WB, wp, Vp[1], o2, v16t, ring, EpiPark{pk, 2, lane});
+          lin<AR, 2, 2, false, 2>(WB, wp, Vp[2], o2, v16t, ring, EpiPark{pk, 4, lane});
+          lin<AR, 2, 2, false, 3>(WB, wp, Vp[3], o2, v16t, ring, EpiPark{pk, 6, lane});
+        } else {
+          lin<AR, 2, 2, false, 0>(WB, wp, Vp[0], o2, v16t, ring, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 0, v16t}, pk, 0, lane});
+          lin<AR, 2, 2, false, 1>(WB, wp, Vp[1], o2, v16t, ring, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 2, v16t}, pk, 2, lane});
+          lin<AR, 2, 2, false, 2>(WB, wp, Vp[2], o2, v16t, ring, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 4, v16t}, pk, 4, lane});
+          lin<AR, 2, 2, false, 3>(WB, wp, Vp[3], o2, v16t, ring, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 6, v16t}, pk, 6, lane});
+        }
       }
       PHASE(PH_MIX);
       // latent MLP
@@ -717,8 +730,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         }
         // prefetch V^{kk} (input of this layer's tensor product) under the MFMAs that follow
         if (kk > 0) {
+          if (!(PARKV && last)) {
 #pragma unroll
-          for (int lm = 0; lm < 4; ++lm) load_rows<2>(SB, RL + OVIN + 2 * lm, Vk[lm], v16t);
+            for (int lm = 0; lm < 4; ++lm) load_rows<2>(SB, RL + OVIN + 2 * lm, Vk[lm], v16t);
+          }
         } else load_rows<4>(SB, R_W0(), W0b, v16t);
         __builtin_amdgcn_sched_barrier(0);
         // down the hidden layers: g_{k-1} = (g_k W_k^T) * silu'(z_{k-1}), then dcat = g_0 W_0^T
@@ -743,6 +758,12 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
           Vk[0][t] = W0b[t];
           Vk[1][t] = W0b[2 + t] * Y1; Vk[2][t] = W0b[2 + t] * Y2; Vk[3][t] = W0b[2 + t] * Y3;
         }
+      }
+      if (PARKV && last && kk > 0) {                          // the last layer's input tensor, still in the park since its forward pass
+#pragma unroll
+        for (int lm = 0; lm < 4; ++lm)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) Vk[lm][t] = park_load(pk, 2 * lm + t, lane);
       }
       f32x4 om1[2];
       load_rows<2>(SB, RL + 2, om1, v16t);                    // omega of this layer, l = 1 part: used after the gradient reduction
@@ -898,10 +919,15 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       const float dd = dfc_tot * (dfc_dx / rc) + gsum(dd_part) * ibs;
       const float y1 = gsum(dY1) * ibs, y2 = gsum(dY2) * ibs, y3 = gsum(dY3) * ibs;
       const float Gx = C_S3 * y3, Gy = C_S3 * y1, Gz = C_S3 * y2;
-      const float gn = Gx * nx + Gy * ny + Gz * nz;
-      const float gx = dd * nx + (Gx - gn * nx) * inv;
-      const float gy = dd * ny + (Gy - gn * ny) * inv;
-      const float gz = dd * nz + (Gz - gn * nz) * inv;
+      // unit vector and 1 / d again from the edge vector (the same expressions as at the top of the tile): four values less to hold across the whole tile
+      float rxe = rx, rye = ry, rze = rz;
+      asm volatile("" : "+v"(rxe), "+v"(rye), "+v"(rze));
+      const float inve = 1.f / sqrtf(rxe * rxe + rye * rye + rze * rze);
+      const float nxe = rxe * inve, nye = rye * inve, nze = rze * inve;
+      const float gn = Gx * nxe + Gy * nye + Gz * nze;
+      const float gx = dd * nxe + (Gx - gn * nxe) * inve;
+      const float gy = dd * nye + (Gy - gn * nye) * inve;
+      const float gz = dd * nze + (Gz - gn * nze) * inve;
       if (A.dbg && valid && g == 0) {
         float *dp = A.dbg + 8 * (size_t)e;
         dp[0] = gx; dp[1] = gy; dp[2] = gz; dp[3] = dd; dp[4] = dfc_tot; dp[5] = y1; dp[6] = y2; dp[7] = y3;
@@ -933,6 +959,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         lds.virw[wave][lane] += (double)mine;
       }
     }
+    int2 cil = make_int2(0, 0);
+    if (ca < na) cil = A.centre[a0 + ca];          // this thread's centre {atom, type}: fetched here, under the barrier, instead of held since the tile's top
     __syncthreads();
     {
       // per-centre sums of (g, eps): 16 lanes per atom = 4 columns x 4 row-parts; the atom index, scale and
@@ -945,10 +973,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       sum += __shfl_xor(sum, 4, 64);
       sum += __shfl_xor(sum, 8, 64);
       if (ca < na && part == 0) {
-        if (col < 3) atomicAdd(&A.f[3 * (size_t)c_i + col], (double)sum);
+        if (col < 3) atomicAdd(&A.f[3 * (size_t)cil.x + col], (double)sum);
         else {
-          const float ei = lds.scale[c_t] * (sum * A.cenv) + lds.shift[c_t];
-          if (A.eatom) A.eatom[c_i] = (double)ei;
+          const float ei = lds.scale[cil.y] * (sum * A.cenv) + lds.shift[cil.y];
+          if (A.eatom) A.eatom[cil.x] = (double)ei;
           lds.eacc[ca] += (double)ei;
         }
       }
@@ -988,6 +1016,10 @@ void fused_launch_f16(int nw, bool prof, int md, int grid, hipStream_t s, const 
 #define AHIP_LAUNCH_NL(NWV, PROFV, NLV, MDV) hipLaunchKernelGGL((k_fused<NWV, PROFV, 3, true, NLV, MDV>), dim3(grid), dim3(NWV * 64), 0, s, A)
 #define AHIP_LAUNCH(NWV, PROFV, MDV) do { if (A.NL == 1) AHIP_LAUNCH_NL(NWV, PROFV, 1, MDV); else if (A.NL == 2) AHIP_LAUNCH_NL(NWV, PROFV, 2, MDV); else AHIP_LAUNCH_NL(NWV, PROFV, 3, MDV); } while (0)
 #define AHIP_LAUNCH_NW(PROFV, MDV) do { if (nw == 4) AHIP_LAUNCH(4, PROFV, MDV); else AHIP_LAUNCH(8, PROFV, MDV); } while (0)
+  if (nw == 2) {          // 32-slot tiles, four workgroups per CU (depth-2 MLP, <= 2 layers: the LDS of four workgroups)
+    if (A.NL == 1) AHIP_LAUNCH_NL(2, false, 1, 2); else AHIP_LAUNCH_NL(2, false, 2, 2);
+    return;
+  }
   if (md == 1) AHIP_LAUNCH_NW(false, 1);
   else if (md == 3) AHIP_LAUNCH_NW(false, 3);
   else if (prof) AHIP_LAUNCH_NW(true, 2);
@@ -1222,10 +1254,10 @@ static void fused_prepare(Model &m) {
   A.wave_scratch = (long long)R_TOTAL(NL, MD) * ROW;
   st.scratch.reserve((size_t)st.ncu * 8 * A.wave_scratch * sizeof(float));
   A.scratch = st.scratch.as<float>();
-  st.partial.reserve((size_t)st.ncu * 2 * 7 * sizeof(double));
+  st.partial.reserve((size_t)st.ncu * 4 * 7 * sizeof(double));
   if (const char *nwe = std::getenv("AHIP_FUSED_NW")) st.force_nw = std::atoi(nwe);
   st.ntiles.reserve(64);
-  st.prof.reserve((64 + 4 * 2 * (size_t)st.ncu) * sizeof(long long));
+  st.prof.reserve((64 + 4 * 4 * (size_t)st.ncu) * sizeof(long long));
   const char *pe = std::getenv("AHIP_FUSED_PROF");
   st.prof_on = pe && pe[0] == '1';
   st.clk_on = std::getenv("AHIP_FUSED_CLK") != nullptr;
@@ -1254,11 +1286,12 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
     if (st.force_nw == 8 || (st.force_nw == 4 && m.last_max_deg <= 64)) nw = st.force_nw;
   } else if (st.force_nw == 8) nw = 8;
   else if (m.max_list_row >= 0 && m.max_list_row <= 64) nw = 4;
+  if (st.force_nw == 2 && st.arith == 3 && st.md == 2 && m.hm.num_layers <= 2) nw = 2;      // EXPERIMENT: the caller vouches for <= 32 edges per centre
   const int *maxdeg_sel = nw == 0 ? m.d_maxdeg : nullptr;
   m.last_fused_arith = st.arith;
   hipStream_t s = a.stream;
   const int inum = m.inum;
-  const int tile_slots = nw == 8 ? 128 : 64, maxa = nw == 8 ? Lds<8>::MAXA : Lds<4>::MAXA;      // nw == 0: the packing kernels widen them themselves
+  const int tile_slots = nw == 8 ? 128 : nw == 2 ? 32 : 64, maxa = nw == 8 ? Lds<8>::MAXA : nw == 2 ? Lds<2>::MAXA : Lds<4>::MAXA;      // nw == 0: the packing kernels widen them themselves
   const int nseg = (inum + SEG - 1) / SEG;
   st.seg_count.reserve((size_t)(nseg + 1) * sizeof(int));
   st.seg_base.reserve((size_t)(nseg + 2) * sizeof(int));
@@ -1306,8 +1339,8 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
   const long long nedges_est = !m.counts_pending ? m.nedges : m.nedges_hint > 0 ? m.nedges_hint : (long long)(0.58 * (double)m.nneigh);
   // persistent workgroups fill every CU; reserve_wgs leaves a few slots free so that the exchange kernels of another stream
   // (ghost pack / unpack, RCCL send / recv) can be scheduled while this kernel runs (md.py, overlapped schedule)
-  const int grid4 = std::max(1, st.ncu * 2 - m.reserve_wgs), grid8 = std::max(1, st.ncu - m.reserve_wgs);
-  const int grid = nw == 8 ? grid8 : grid4;     // rows of `partial` that are summed
+  const int grid4 = std::max(1, st.ncu * 2 - m.reserve_wgs), grid8 = std::max(1, st.ncu - m.reserve_wgs), grid2 = std::max(1, st.ncu * 4 - m.reserve_wgs);
+  const int grid = nw == 8 ? grid8 : nw == 2 ? grid2 : grid4;     // rows of `partial` that are summed
   if (nw == 0) AHIP_CHECK(hipMemsetAsync(st.partial.p, 0, (size_t)grid * 7 * sizeof(double), s));     // the shape that returns at once writes nothing
   {
     StageTimer tm(m, "model_fused", s);
@@ -1320,9 +1353,9 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
       AHIP_CHECK(hipMemsetAsync(st.prof.p, 0, (64 + 4 * (size_t)grid) * sizeof(long long), s));
       A.prof = st.prof.as<long long>();
     }
-    for (int shape = 4; shape <= 8; shape += 4) {
-      if (nw != 0 && nw != shape) continue;
-      const int g = shape == 8 ? grid8 : grid4;
+    for (int shape = 2; shape <= 8; shape *= 2) {
+      if (nw != shape && (nw != 0 || shape == 2)) continue;
+      const int g = shape == 8 ? grid8 : shape == 2 ? grid2 : grid4;
       A.wg_scratch = shape * A.wave_scratch;
       // claims of TCHUNK tiles amortise the counter's round trip; with few tiles per workgroup the last claim decides the makespan
       // (10 648 Si atoms: 4 659 tiles on 512 workgroups = 12 instead of 10 tile times with claims of 4)

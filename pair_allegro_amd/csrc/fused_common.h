@@ -142,6 +142,13 @@ struct EpiSavePark : EpiSave {  // raw rows to scratch (for the backward pass) a
     park_store(pk, prow + ot, acc, lane);
   }
 };
+struct EpiPark {                // raw rows to the LDS park only
+  static constexpr bool STORES = false;
+  float *pk; int prow, lane;
+  __device__ __forceinline__ void tile_done(int ot, const f32x4 &acc) const { park_store(pk, prow + ot, acc, lane); }
+  __device__ __forceinline__ float apply(int, int, float v) const { return v; }
+  __device__ __forceinline__ void flush(int) const {}
+};
 // out = silu(z); the rows saved for the backward pass hold silu'(z) = s + silu (1 - s) (two extra VALU ops here, no
 // exp/rcp and no z there): they are written when all 8 registers of a tile pair have gone through apply()
 struct EpiSiluSaveD {

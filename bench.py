@@ -61,6 +61,24 @@ def model_macs_per_edge(cfg, two_body_tabulated=False, readout_folded=False):
     return fwd
 
 
+def model_algorithmic_bytes_per_edge(cfg, edges_per_centre):
+    """ALGORITHMIC HBM bytes per edge of one force evaluation, layer-at-a-time formulation, float32 state -- SURVEY.md 8(d), "ALGORITHMIC bytes" row,
+    summed per kernel exactly as that row lists them (this is the figure `roofline.achieved` is priced on, whatever a fused kernel really moves):
+      gather / embed   read j 4 + x_j 24 + type_j 4; write r_e 12 + Bessel x cutoff 4 B + Y 4 D                 (92 B for l_max 1, 112 B for l_max 2)
+      tensor product   per layer, forward: read V_e 4 U D + environment weights 4 U (l_max + 1) + the centre's env 4 U D (once per ATOM, i.e. / edges per
+                       centre); write V'_e 4 U D   (1.3 KB for model S, 5.5 KB for model L);   backward = 2 x forward
+      latent           per layer: x_e read, x_e' written, its gradient read once: 3 x 4 S   (the rest of SURVEY's "4.6 KB / edge / layer, fwd + bwd" for model S)
+      force scatter    read g_e 12, one 24-byte atomic per edge, 24 bytes written per atom
+    Model S on Si (28 edges per centre, 2 layers): 9.45 KB per edge = 264.7 KB per atom-step (SURVEY 8d rounds the same sum to "about 260 KB / atom-step")."""
+    S = cfg["num_scalar_features"]; U = cfg["num_tensor_features"]; L = cfg["l_max"]; NL = cfg["num_layers"]; B = cfg["num_bessels"]
+    D = (L + 1) ** 2
+    gather = 4 + 24 + 4 + 12 + 4 * B + 4 * D
+    tp_fwd = 4 * U * D + 4 * U * (L + 1) + 4 * U * D / max(edges_per_centre, 1.0) + 4 * U * D
+    layer = 3.0 * tp_fwd + 3 * 4 * S
+    scatter = 12 + 24 + 24.0 / max(edges_per_centre, 1.0)
+    return gather + NL * layer + scatter
+
+
 # ---- BASELINE.json configs (SURVEY 8d).  configs[0] (64-atom Si on CPU libtorch) is the reference's own plumbing case
 # and appears only in the parity tests; --config 4 (1 M-atom Si, model S) is the configuration the metric is quoted on.
 def workload(config: int, ncell: int = 0):
@@ -334,6 +352,16 @@ def main():
     sim.rebuild()
     barrier()
     rebuild_ms = 1e3 * (time.perf_counter() - tr0)
+    # ... and how often the run re-neighbors: when the timed window held no re-neighboring, the cadence is MEASURED on an untimed
+    # continuation of the same trajectory (up to 96 steps, until two re-neighborings have happened) and `value_with_amortised_rebuilds` prices it in
+    cadence_steps, cadence_rebuilds = 0, 0
+    if rebuilds_timed == 0 and not args.eval_only:
+        nr0 = sim.nrebuild
+        while cadence_steps < 96 and sim.nrebuild - nr0 < 2:
+            sim.step()
+            cadence_steps += 1
+        cadence_rebuilds = sim.nrebuild - nr0
+        barrier()
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
@@ -348,6 +376,9 @@ def main():
                                 "float32-equivalent: max|dF| vs the float64 oracle as the f32 form (parity_vs_oracle; tests/test_arith_emulation.py)",
                  "fused_bf16x3": "bf16x3: exact three-way bf16 split of both operands, six bf16-MFMA products, float32 accumulate; float32-equivalent",
                  "fused_tf32eq": "two-term bf16 split, three products: TF32-class, only for model files with allow_tf32 = 1"}
+        # the arithmetic type the path computes in (not a precision claim: parity_vs_oracle carries the numbers)
+        DTYPE = {"fused_f16x2": "f32-equivalent (f16x2 split on the f16 matrix cores, f32 accumulate)", "fused_bf16x3": "f32-equivalent (bf16x3 split, f32 accumulate)",
+                 "fused_tf32eq": "tf32-class (two-term bf16 split; model file sets allow_tf32)", "generic_f64": "f64"}
         # ALGORITHMIC flops = the model's dense contractions (SURVEY 8d / DESIGN 4.2), whatever the kernel does with them;
         # the fused kernels' tabulated two-body embedding executes fewer: frac_executed is priced on those.
         flops_per_edge = 2.0 * model_macs_per_edge(cfg) * 2.0       # 2 flop per MAC x (forward + input-gradient backward)
@@ -364,18 +395,31 @@ def main():
                 traffic, traffic_src = ent["traffic_bytes_per_launch"], ent["source"]
                 traffic_hash = ent.get("kernel_hash")
         if dom is not None:
-            ach = flops_per_edge * edges_rank0 / (stage_avg[dom] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": 157.3, "unit": "TFLOP/s",
-                    "frac": round(ach / 157.3, 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": dom,
+            t_dom = stage_avg[dom] * 1e-3                       # seconds of the dominant kernel per step (all its launches: one evaluation of edges_rank0 edges)
+            ach = flops_per_edge * edges_rank0 / t_dom / 1e12
+            # Headline roof (north-star wording): the HBM roofline on SURVEY 8d's ALGORITHMIC bytes -- bytes function above x the edges one
+            # evaluation processes / the kernel's HIP-event time of this run / 8 TB/s.  A fused kernel moves fewer bytes than the layer-at-a-time
+            # formulation the figure describes (`traffic`, from PMC passes, says how many), so this fraction may exceed 1: SURVEY 8d's own caveat.
+            bytes_per_edge = model_algorithmic_bytes_per_edge(cfg, edges_rank0 / max(sim.nlocal, 1))
+            alg_bytes = bytes_per_edge * edges_rank0
+            gbs_alg = alg_bytes / t_dom / 1e9
+            # the matrix pipe the kernel's contractions really run on, and how many of its products one float32 product costs
+            PIPE = {"fused_f32": ("f32-input MFMA", 157.3, 1.0), "fused_f16x2": ("f16 MFMA (dense)", 2500.0, 3.0),
+                    "fused_bf16x3": ("bf16 MFMA (dense)", 2500.0, 6.0), "fused_tf32eq": ("bf16 MFMA (dense)", 2500.0, 3.0)}
+            pipe = PIPE.get(used_path, ("f32-input MFMA (GEMM stages only)", 157.3, 1.0))
+            ex_tf = ach * executed_flops_per_edge / flops_per_edge * pipe[2]
+            roof = {"bound": "hbm", "achieved": round(gbs_alg, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs_alg / 8000.0, 4),
+                    "traffic": traffic, "traffic_source": traffic_src, "kernel": dom,
+                    "basis": "SURVEY 8d algorithmic bytes (bench.py: model_algorithmic_bytes_per_edge) x edges_per_launch / avg_ms; may exceed 1 for a fused kernel (SURVEY 8d caveat): see hbm_measured for the bytes really moved",
+                    "algorithmic_bytes_per_edge": round(bytes_per_edge, 1), "algorithmic_bytes_per_launch": alg_bytes,
                     "avg_ms": round(stage_avg[dom], 3), "edges_per_launch": edges_rank0, "launches_per_step": launches_per_step[dom],
                     "flops_per_edge": flops_per_edge, "executed_flops_per_edge": executed_flops_per_edge,
-                    "frac_executed": round(ach / 157.3 * executed_flops_per_edge / flops_per_edge, 4),
+                    # the model's float32 contractions per second; NOT a fraction of anything for the split arithmetics (they issue no f32 MFMA)
+                    "f32_equivalent_tflops": round(ach, 3),
+                    "matrix_pipe": {"unit": pipe[0], "products_per_f32_product": pipe[2], "achieved": round(ex_tf, 1), "peak": pipe[1], "unit_of_measure": "TFLOP/s executed",
+                                    "frac": round(ex_tf / pipe[1], 4)},
                     "two_body": "table" if tb_tab else "mlp",
                     "arithmetic": ARITH.get(used_path, "float32 (layer-at-a-time kernels)"),
-                    # `peak` stays the f32-input MFMA peak for every float32-equivalent arithmetic (the yardstick of VERDICT r04 #1: the model's float32
-                    # contractions per second against what the float32 matrix path could deliver); on the f16 matrix cores (2 500 TFLOP/s dense) the f16x2
-                    # form executes three products per float32 product:
-                    "f16_matrix_core_frac": (round(3.0 * ach * executed_flops_per_edge / flops_per_edge / 2500.0, 4) if used_path == "fused_f16x2" else None),
                     # padding tax of the tile packing: edge slots that held an edge / slots of all tiles (one full evaluation)
                     "slots_used": slots_used, "slots_total": slots_total, "slot_occupancy": (round(slots_used / slots_total, 4) if slots_total else None)}
             if traffic:
@@ -414,15 +458,20 @@ def main():
         if not args.no_cpu_baseline and world == 1:       # reported baseline: rank 0 at N = 1 only
             cpu, parity = cpu_baseline_and_parity(lib, args.config, dev_index, args.cpu_sample_ncell, args.path)
             max_df = parity["max_abs_dF"]
+        # the metric counts amortised re-neighborings: a timed window that held some has paid for them; one that held none is corrected with
+        # the measured cost of one re-neighboring and the measured cadence of this trajectory
+        value_amortised = value
+        if rebuilds_timed == 0 and cadence_rebuilds > 0:
+            value_amortised = natoms / ((ms_per_step + rebuild_ms * cadence_rebuilds / cadence_steps) * 1e-3)
         out = {
             "metric": "atom_steps_per_sec" if not args.eval_only else "atom_evaluations_per_sec (ablation run, not the benchmark)", "value": round(value, 1), "unit": "atom-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE.get(used_path, "f32"), "data": "synthetic",
             "config": {"workload": f"{('BASELINE config ' + str(args.config)) if args.config <= 5 else 'extra config 6 (not in BASELINE.json)'}: {wl['name']}, r_max {cfg['r_max']} A + skin 1.0 A, NVE dt=1 fs",
                        "grid": "x".join(map(str, grid)), "kernel_path": used_path, "rebuilds": sim.nrebuild,
                        "rebuilds_in_timed_steps": rebuilds_timed, "rebuild_ms": round(rebuild_ms, 3),
                        "steps_per_rebuild": (round(args.steps / rebuilds_timed, 1) if rebuilds_timed else None),
-                       "rebuild_share_of_step_at_1_per_50": round(rebuild_ms / 50.0 / ms_per_step, 5),
+                       "rebuild_cadence_measured": ({"steps": cadence_steps, "rebuilds": cadence_rebuilds} if cadence_steps else None),
                        "comm": "overlapped" if sim.overlap else "serial", "comm_autotune": autotune,
                        "comm_transport": (("library/" + sim.comm.transport + ("/single-rank gather-scatter" if world == 1 else "")) if getattr(sim, "comm", None) is not None else "torch.distributed"),
                        "stage_ms_rank0": {k: round(v, 3) for k, v in stage_avg.items()},
@@ -430,6 +479,7 @@ def main():
                        "comm_ms": round(stage_max.get("comm", 0.0) / args.steps, 4),
                        "rccl_version": ci["rccl_version"], "comm_init_ms": ci["init_ms"],
                        "pe_per_atom": th["pe"] / natoms},
+            "value_with_amortised_rebuilds": round(value_amortised, 1),
             "max_abs_dF_vs_oracle": max_df,
             "parity_vs_oracle": parity,
             "roofline": roof,
@@ -535,8 +585,10 @@ def cpu_baseline_and_parity(lib, config, device_index, ncell, path):
             best_t, best_bind = w["threads"], (None if w["bind"] == "unset" else w["bind"])
         runs = []
         samples = [(wl["name"], rs)]
-        if config in (2, 4):                                          # SURVEY 8d sizes: 64 and 10 648 atoms
+        if config in (2, 4):                                          # SURVEY 8d sizes: 64 and 10 648 atoms; 1 728 atoms: the largest box that affords the full 3 + 10 protocol
             c64, p64, t64 = lmp_like.diamond_si(2)
+            c2k, p2k, t2k = lmp_like.diamond_si(6)
+            samples.insert(0, ("1728-atom bulk Si", lmp_like.build_rank_system(c2k, p2k, t2k, cfg["r_max"] + 1.0)))
             samples.insert(0, ("64-atom bulk Si (config 1)", lmp_like.build_rank_system(c64, p64, t64, cfg["r_max"] + 1.0)))
         for label, r in samples:
             sysf = write_sys(r)
@@ -579,20 +631,37 @@ def cpu_baseline_and_parity(lib, config, device_index, ncell, path):
         cpu = {"value": round(rs.nlocal / t_eval, 1), "unit": "atom-steps/s", "cores": torch.get_num_threads(), "kind": "port",
                "sample": f"{wl['name']}: 3 warm-up + {reps} timed force evaluations of the TorchScript oracle through torch (Python; the C++ "
                          f"harness oracle/_build/cpu_baseline was not built), {t_eval*1e3:.0f} ms each (model only)"}
-    m = capi.Model(model_path, device_index, lib)
-    m.set_option("path", path)
-    m.neigh_update_csr(rs.nall, rs.ilist, rs.offsets, rs.flat)
-    f = np.zeros_like(rs.x)
-    e = np.zeros(len(rs.x))
-    pe, vir = m.compute(rs.nlocal, rs.nghost, rs.x, rs.type, mapper, cm, f, e)
-    used = m.last_path
-    m.close()
+    def hip_eval(arith):
+        m = capi.Model(model_path, device_index, lib)
+        m.set_option("path", path)
+        if arith:
+            m.set_option("fused_arith", arith)
+        m.neigh_update_csr(rs.nall, rs.ilist, rs.offsets, rs.flat)
+        f = np.zeros_like(rs.x)
+        e = np.zeros(len(rs.x))
+        pe, vir = m.compute(rs.nlocal, rs.nghost, rs.x, rs.type, mapper, cm, f, e)
+        used = m.last_path
+        m.close()
+        return f, e, pe, vir, used
+    f, e, pe, vir, used = hip_eval(None)
     max_df = float(np.abs(f - f_ref).max())
+    # the same sample on the float32 instance of the same kernel (f32-input MFMA = exact fmaf chains): what a split arithmetic is held against is the
+    # float32 kernel's own distance from the float64 oracle on THIS sample, not an absolute number
+    max_df_f32, used_f32 = None, None
+    if used.startswith("fused_") and used != "fused_f32":
+        try:
+            f32f, _, _, _, used_f32 = hip_eval("f32")
+            max_df_f32 = float(np.abs(f32f - f_ref).max())
+        except Exception as ex:            # a model shape without a float32 instance (MLP depth 1 / 3): the layer-at-a-time float32 kernels answer
+            used_f32 = f"unavailable: {ex}"
     # the other observables of the reference's own comparison: per-atom energy, PE per atom, virial per atom
     parity = {"max_abs_dF": max_df, "max_abs_dEatom": float(np.abs(e[: rs.nlocal] - e_ref[: rs.nlocal]).max()),
               "abs_dPE_per_atom": float(abs(pe - pe_ref) / rs.nlocal),
               "max_abs_dvirial_per_atom": float(np.abs(vir - vir_ref).max() / rs.nlocal), "atoms": int(rs.nlocal),
-              "kernel_path": used, "sample": wl["name"]}
+              "kernel_path": used, "sample": wl["name"],
+              "max_abs_dF_f32_instance": max_df_f32, "f32_instance_path": used_f32,
+              "split_over_f32_instance": (round(max_df / max_df_f32, 3) if max_df_f32 else None),
+              "max_abs_F": float(np.abs(f_ref).max())}
     return cpu, parity
 
 

@@ -72,7 +72,13 @@ int ahip_model_meta(const ahip_model *m, double *r_max, int *num_types, const ch
  *                                                 fmaf chains); two float16 terms per operand, three f16-MFMA products (float32-equivalent inside float16's exponent
  *                                                 range; an evaluation that leaves it returns AHIP_ERR_STATE: host-pointer calls at once, _dev calls at the next
  *                                                 evaluation); three-term bf16 split (float32-equivalent; l_max = 1 kernel); two-term bf16 split (TF32-class; l_max = 1
- *                                                 kernel).  auto = f16x2 unless the model file says allow_tf32 = 1 (pair_nequip_allegro.cpp:267-270), then tf32eq
+ *                                                 kernel).  auto = f16x2 unless the model file says allow_tf32 = 1 (pair_nequip_allegro.cpp:267-270), then tf32eq.
+ *                                                 auto is never less robust than the reference's float32 (which only ever RELAXES precision, :267-270): a model the split
+ *                                                 cannot carry (a weight beyond float16's range, a linear inside its subnormals), a first evaluation that disagrees with
+ *                                                 the float32 instance by more than 1e-5 max|F|, or a float16-range alarm switch the model to the f32 instance for the
+ *                                                 rest of its life -- host-pointer calls re-evaluate inside the same call, _dev calls report the invalid earlier
+ *                                                 evaluation once (AHIP_ERR_STATE) and continue on f32.  ahip_arith_note says what was decided.  Only an explicit
+ *                                                 "f16x2" keeps the hard errors.
  *   "fused_tb"  = "table" | "mlp"                two-body embedding of the fused kernels: tabulated cubic splines (default) or the MLP itself
  *   "edge_schedule" = "auto" | "static" | "dynamic"   unit schedule of the single-pass edge build (dynamic: safe beside other resident kernels)
  *   "tile_pack" = "auto" | "separate" | "fused"  tile packing of the fused kernels inside the edge build or as its own kernels
@@ -205,6 +211,9 @@ int ahip_model_allow_tf32(const ahip_model *m, int *allow);
 
 /* Kernel family and arithmetic used by the last compute: "generic_f32" | "generic_f64" | "fused_f16x2" | "fused_f32" | "fused_bf16x3" | "fused_tf32eq" ("" before). */
 const char *ahip_last_path(ahip_model *m);
+/* What fused_arith=auto decided for this model and why, one line ("" before the first evaluation): "fused_arith=auto: f16x2 kept: first evaluation within
+ * ... of the float32 instance" or "fused_arith=auto: float32 instance (f32-input MFMA) selected: <reason>". */
+const char *ahip_arith_note(const ahip_model *m);
 /* Largest number of edges of any centre atom in the last compute. */
 int ahip_last_max_degree(ahip_model *m);
 

@@ -35,7 +35,7 @@ SYMBOLS = [
     "ahip_compute_dev_range", "ahip_last_list_size", "ahip_neigh_update_dev_table", "ahip_map_types_dev", "ahip_reneighbor_flag_dev",
     "ahip_last_path", "ahip_last_max_degree", "ahip_debug_fused_linear", "ahip_debug_fused_edges", "ahip_build_neighbors_dev", "ahip_nve_dev", "ahip_nve_first_dev",
     "ahip_model_allow_tf32", "ahip_comm_unique_id", "ahip_comm_create_rccl", "ahip_comm_create_hosted", "ahip_comm_rccl_version", "ahip_comm_free", "ahip_comm_set_plan", "ahip_comm_set_plan_local",
-    "ahip_comm_forward", "ahip_comm_reverse", "ahip_comm_allreduce", "ahip_comm_selftest", "ahip_fill_zero_dev", "ahip_borders_local_dev",
+    "ahip_comm_forward", "ahip_comm_reverse", "ahip_comm_allreduce", "ahip_comm_selftest", "ahip_fill_zero_dev", "ahip_borders_local_dev", "ahip_arith_note",
 ]
 
 
@@ -70,6 +70,8 @@ class Library:
         L.ahip_last_error.restype = C.c_char_p
         L.ahip_last_path.restype = C.c_char_p
         L.ahip_last_path.argtypes = [C.c_void_p]
+        L.ahip_arith_note.restype = C.c_char_p
+        L.ahip_arith_note.argtypes = [C.c_void_p]
         L.ahip_last_max_degree.argtypes = [C.c_void_p]
         L.ahip_output_register.argtypes = [C.c_void_p, C.c_char_p]
         L.ahip_output_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.c_longlong, C.POINTER(C.c_longlong)]
@@ -340,6 +342,11 @@ class Model:
     @property
     def last_path(self) -> str:
         return self.L.lib.ahip_last_path(self.h).decode()
+
+    @property
+    def arith_note(self) -> str:
+        """What fused_arith=auto decided for this model and why (empty before the first evaluation)."""
+        return self.L.lib.ahip_arith_note(self.h).decode()
 
     @property
     def last_max_degree(self) -> int:

@@ -144,12 +144,29 @@ int *alarm_word(Model &m) {
   AHIP_CHECK(hipHostGetDevicePointer((void **)&d, m.h_alarm, 0));
   return d;
 }
+bool alarm_take(Model &m) {
+  if (m.h_alarm && *(volatile int *)m.h_alarm != 0) { *m.h_alarm = 0; return true; }
+  return false;
+}
+// fused_arith=auto falls back to the f32-input MFMA instances for the rest of this model's life (engine.h): the prepared f16x2 weight streams go, the next
+// dispatch prepares the f32 ones; said once on stderr and kept for ahip_arith_note
+static void arith_degrade(Model &m, const std::string &why) {
+  m.arith_degraded = true;
+  m.arith_note = "fused_arith=auto: float32 instance (f32-input MFMA) selected: " + why;
+  fused_free(m); fusedlx_free(m); fusedlx2_free(m);
+  std::fprintf(stderr, "[allegro-hip] %s\n", m.arith_note.c_str());
+}
+// An alarm found at the START of an evaluation, or by an accessor, was raised by an EARLIER device-resident evaluation that nobody waited for: its forces were
+// not finite and have been handed out.  That is reported either way; under auto the model also switches to the f32 instance, so the error is reported once.
 void fused_poll_alarm(Model &m) {
-  if (m.h_alarm && *(volatile int *)m.h_alarm != 0) {
-    *m.h_alarm = 0;
-    throw StateError("fused_arith=f16x2: an edge gradient was not finite (an activation left float16's range, or the input was not finite): the forces of that "
-                     "evaluation are invalid; set option fused_arith=f32 for this model");
+  if (!alarm_take(m)) return;
+  if (arith_option(m) == "auto" && !m.arith_degraded) {
+    arith_degrade(m, "an earlier evaluation produced a non-finite edge gradient on the f16x2 arithmetic (an activation left float16's range)");
+    throw StateError("fused_arith=auto: an EARLIER evaluation produced non-finite forces on the f16x2 arithmetic (an activation left float16's range, or the input was "
+                     "not finite); this model now runs on the float32 instance -- re-evaluate from the last valid state");
   }
+  throw StateError("fused_arith=f16x2: an edge gradient was not finite (an activation left float16's range, or the input was not finite): the forces of that "
+                   "evaluation are invalid; set option fused_arith=f32 (or auto) for this model");
 }
 }  // namespace ahip
 
@@ -157,7 +174,12 @@ void ahip_model_free(ahip_model *m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
-  if (m->h_alarm) { (void)hipHostFree(m->h_alarm); m->h_alarm = nullptr; }
+  if (m->h_alarm) {
+    // an alarm of the LAST evaluation of a run is not lost either (void function: said on stderr)
+    if (alarm_take(*m)) std::fprintf(stderr, "[allegro-hip] WARNING: the last device-resident evaluation of this model produced non-finite forces on the f16x2 arithmetic "
+                                             "(float16 range exceeded); set fused_arith=f32\n");
+    (void)hipHostFree(m->h_alarm); m->h_alarm = nullptr;
+  }
   fused_free(*m);
   fusedlx_free(*m);
   fusedlx2_free(*m);
@@ -170,7 +192,7 @@ void ahip_model_free(ahip_model *m) {
   if (m->rcut_model_dev) (void)hipFree(m->rcut_model_dev);
   for (DevBuf *b : {&m->b_flagwork, &m->b_ilist, &m->b_nloff, &m->b_nlj, &m->b_x, &m->b_ftype, &m->b_mtype, &m->b_f, &m->b_eatom,
                     &m->b_engvir, &m->b_cutsq, &m->b_cnt, &m->b_eoff, &m->b_eii, &m->b_ej, &m->b_rvec, &m->b_ett, &m->b_partial,
-                    &m->b_ws, &m->b_misc, &m->hv_eoff, &m->hv_eii, &m->hv_ej, &m->hv_rvec, &m->hv_ilist, &m->hv_engvir, &m->b_tile_a0, &m->b_tile_e0, &m->b_centre, &m->b_ntiles})
+                    &m->b_ws, &m->b_misc, &m->b_chk, &m->hv_eoff, &m->hv_eii, &m->hv_ej, &m->hv_rvec, &m->hv_ilist, &m->hv_engvir, &m->b_tile_a0, &m->b_tile_e0, &m->b_centre, &m->b_ntiles})
     b->release();
   for (auto &t : m->slots) for (auto &e : t.ring) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (hipEvent_t e : m->f_events) (void)hipEventDestroy(e);
@@ -535,7 +557,92 @@ static void heavy_generic(ahip_model *m, const ComputeArgs &a) {
   hipLaunchKernelGGL(k_add7, dim3(1), dim3(64), 0, a.stream, a.engvir, a2.engvir);
 }
 
+static void run_model_once(ahip_model *m, const ComputeArgs &a);
+// dispatch with the auto fallback: a prepare step that finds the model outside the f16x2 split's reach (ArithDegraded) costs one more dispatch, on f32
+static void run_model_dispatch(ahip_model *m, const ComputeArgs &a) {
+  try { run_model_once(m, a); }
+  catch (const ArithDegraded &d) {
+    arith_degrade(*m, d.why);
+    run_model_once(m, a);
+  }
+}
+static __global__ void k_chk_reduce(long long n, const double *a, const double *b, unsigned long long *out) {
+  // out[0] = max |a - b|, out[1] = max |a| as bit patterns (non-negative doubles order like their bits); a non-finite difference maps to +inf
+  double d = 0.0, f = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    double di = fabs(a[i] - b[i]);
+    if (!(di < 1.0e300)) di = 1.0e300;
+    d = fmax(d, di); f = fmax(f, fabs(a[i]));
+  }
+  for (int off = 32; off > 0; off >>= 1) { d = fmax(d, __shfl_xor(d, off, 64)); f = fmax(f, __shfl_xor(f, off, 64)); }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(out, (unsigned long long)__double_as_longlong(d));
+    atomicMax(out + 1, (unsigned long long)__double_as_longlong(f));
+  }
+}
+// First evaluation of a model whose fused_arith=auto resolves to f16x2 (VERDICT r05 #3c): the same centres once on the f32 instance, once on f16x2, forces
+// compared; f16x2 stays only if max|dF| <= 1e-5 max|F| (float32-equivalence on THIS model and THIS configuration, not on the builder's samples) and no
+// alarm was raised.  Cost: two extra evaluations and two weight-stream builds, once per model (per pair_coeff).  Energies / virial / per-atom energies are the
+// second pass's (or the fallback's); f gets the chosen pass added, as always.
+static void run_model_selfcheck(ahip_model *m, const ComputeArgs &a) {
+  m->arith_checked = true;
+  const long long nf = 3LL * (a.nlocal + a.nghost);
+  m->b_chk.reserve((size_t)(2 * nf + 16) * sizeof(double));
+  double *f32f = m->b_chk.as<double>(), *f16f = f32f + nf, *ev = f16f + nf;
+  unsigned long long *red = (unsigned long long *)(ev + 8);
+  hipStream_t s = a.stream;
+  AHIP_CHECK(hipMemsetAsync(m->b_chk.p, 0, (size_t)(2 * nf + 16) * sizeof(double), s));
+  ComputeArgs a1 = a;
+  a1.f = f32f; a1.eatom = nullptr; a1.engvir = ev;
+  m->arith_force = 0;
+  fused_free(*m); fusedlx_free(*m); fusedlx2_free(*m);
+  try { run_model_dispatch(m, a1); } catch (...) { m->arith_force = -1; fused_free(*m); fusedlx_free(*m); fusedlx2_free(*m); throw; }
+  m->arith_force = -1;                       // (a shape without a float32 fused instance -- MLP depth 1 / 3 -- was just evaluated by the layer-at-a-time float32 kernels)
+  fused_free(*m); fusedlx_free(*m); fusedlx2_free(*m);
+  ComputeArgs a2 = a;
+  a2.f = f16f;
+  run_model_dispatch(m, a2);                 // (a prepare-time fallback inside lands on f32 as well: the comparison below is then trivially green)
+  if (m->last_path != "fused_f16x2" && !m->arith_degraded) {
+    // this LIST went down the layer-at-a-time path (a centre with more edges than a tile holds): nothing was checked; a later list gets its chance, three times at most
+    if (++m->arith_check_attempts < 3) m->arith_checked = false;
+    if (nf > 0) hipLaunchKernelGGL(k_add_n, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, s, nf, a.f, f16f);
+    return;
+  }
+  hipLaunchKernelGGL(k_chk_reduce, dim3(1024), dim3(256), 0, s, nf, f32f, f16f, red);
+  unsigned long long hred[2] = {0, 0};
+  AHIP_CHECK(hipMemcpyAsync(hred, red, sizeof(hred), hipMemcpyDeviceToHost, s));
+  AHIP_CHECK(hipStreamSynchronize(s));
+  double dmax, fmax_;
+  std::memcpy(&dmax, &hred[0], 8); std::memcpy(&fmax_, &hred[1], 8);
+  const bool alarm = alarm_take(*m);
+  const bool ok = !alarm && dmax <= 1.0e-5 * fmax_ + 1.0e-30;
+  char buf[256];
+  if (m->arith_degraded) {                   // fell back while preparing: f16f holds the float32 result
+    if (nf > 0) hipLaunchKernelGGL(k_add_n, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, s, nf, a.f, f16f);
+    return;
+  }
+  if (ok) {
+    std::snprintf(buf, sizeof(buf), "fused_arith=auto: f16x2 kept: first evaluation within %.2e max|F| of the float32 instance (max|dF| %.3e, max|F| %.3e; bar 1e-5)",
+                  fmax_ > 0 ? dmax / fmax_ : 0.0, dmax, fmax_);
+    m->arith_note = buf;
+    if (nf > 0) hipLaunchKernelGGL(k_add_n, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, s, nf, a.f, f16f);
+    return;
+  }
+  std::snprintf(buf, sizeof(buf), "first-evaluation self-check: f16x2 %s (max|dF| %.3e vs the float32 instance, max|F| %.3e; bar 1e-5 max|F|)",
+                alarm ? "raised the float16-range alarm" : "disagrees with the float32 instance", dmax, fmax_);
+  arith_degrade(*m, buf);
+  run_model_dispatch(m, a);                  // float32, straight into the caller's arrays
+}
 static void run_model(ahip_model *m, const ComputeArgs &a) {
+  fused_poll_alarm(*m);                      // raised by an EARLIER device-resident evaluation (nobody waits for those kernels)
+  const bool f64 = (m->opt_precision == "float64") || (m->hm.model_dtype == "float64");
+  const bool wants_check = !m->arith_checked && !m->arith_degraded && m->inum > 0 && !f64 && m->opt_path != "generic" && arith_option(*m) == "auto" &&
+                           !m->hm.allow_tf32 && (fused_model_supported(*m, nullptr) || fusedlx_model_supported(*m, nullptr)) &&
+                           std::getenv("AHIP_NO_ARITH_SELFCHECK") == nullptr;
+  if (wants_check) run_model_selfcheck(m, a);
+  else run_model_dispatch(m, a);
+}
+static void run_model_once(ahip_model *m, const ComputeArgs &a) {
   m->nedges = 0;
   const bool f64 = (m->opt_precision == "float64") || (m->hm.model_dtype == "float64");
   // the 7 energy / virial sums start from zero: the single-pass edge build clears them in its first kernel, every other way here
@@ -686,6 +793,15 @@ int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const i
     AHIP_CHECK(hipMemcpyAsync(m->b_mtype.p, m->h_mtype.data(), (size_t)nall * sizeof(int), hipMemcpyHostToDevice, s));
     AHIP_CHECK(hipMemcpyAsync(m->b_cutsq.p, cutsq.data(), cutsq.size() * sizeof(double), hipMemcpyHostToDevice, s));
     m->h_cutsq_dev.clear();
+    unpin_if_growing(m, m->h_f, (size_t)nall * 3);
+    m->h_f.resize((size_t)nall * 3);
+    pin_host(m, m->h_f);
+    double ev[7];
+    constexpr size_t FCH = 8u << 20;
+    const size_t ftot = (size_t)nall * 3 * sizeof(double), nfch = (ftot + FCH - 1) / FCH;
+    while (m->f_events.size() < nfch + 1) { hipEvent_t e; AHIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m->f_events.push_back(e); }
+    // (twice at most: an evaluation whose f16x2 kernels raise the float16-range alarm under fused_arith=auto is repeated on the float32 instance)
+    for (int attempt = 0;; ++attempt) {
     AHIP_CHECK(hipMemsetAsync(m->b_f.p, 0, (size_t)nall * 3 * sizeof(double), s));
     if (want_eatom) AHIP_CHECK(hipMemsetAsync(m->b_eatom.p, 0, (size_t)nall * sizeof(double), s));
 
@@ -694,16 +810,9 @@ int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const i
                   m->b_engvir.as<double>(), s};
     run_model(m, a);
 
-    unpin_if_growing(m, m->h_f, (size_t)nall * 3);
-    m->h_f.resize((size_t)nall * 3);
-    pin_host(m, m->h_f);
-    double ev[7];
     // Order on the stream: the 7 energy / virial sums and an event (the kernel has finished once it fires: the float16-range alarm of THIS evaluation is
     // valid and is reported by this call, before f is touched), then the forces in chunks, each behind an event: the host adds chunk c into f while
     // the DMA of chunk c + 1 runs; the per-atom energies last.
-    constexpr size_t FCH = 8u << 20;
-    const size_t ftot = (size_t)nall * 3 * sizeof(double), nfch = (ftot + FCH - 1) / FCH;
-    while (m->f_events.size() < nfch + 1) { hipEvent_t e; AHIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m->f_events.push_back(e); }
     AHIP_CHECK(hipMemcpyAsync(ev, m->b_engvir.p, 7 * sizeof(double), hipMemcpyDeviceToHost, s));
     AHIP_CHECK(hipEventRecord(m->f_events[nfch], s));
     for (size_t c = 0; c < nfch; ++c) {
@@ -718,7 +827,17 @@ int ahip_compute(ahip_model *m, int nlocal, int nghost, const double *x, const i
       AHIP_CHECK(hipMemcpyAsync(m->h_eatom.data(), m->b_eatom.p, (size_t)nall * sizeof(double), hipMemcpyDeviceToHost, s));
     }
     AHIP_CHECK(hipEventSynchronize(m->f_events[nfch]));
-    try { fused_poll_alarm(*m); } catch (...) { (void)hipStreamSynchronize(s); throw; }      // (the copies into the page-locked vectors finish before anybody may free them)
+    if (alarm_take(*m)) {                    // raised by THIS evaluation: nothing of it has touched the caller's arrays yet
+      (void)hipStreamSynchronize(s);         // (the copies into the page-locked vectors finish before anybody may free or refill them)
+      if (arith_option(*m) == "auto" && !m->arith_degraded && attempt == 0) {
+        arith_degrade(*m, "an activation left float16's range (non-finite edge gradient on the f16x2 arithmetic); the evaluation was repeated");
+        continue;
+      }
+      throw StateError("fused_arith=f16x2: an edge gradient was not finite (an activation left float16's range, or the input was not finite): the forces of this "
+                       "evaluation are invalid and were not added to f; set option fused_arith=f32 (or auto) for this model");
+    }
+    break;
+    }
     // scatter: f[i] += forces[i] for locals AND ghosts (pair_nequip_allegro.cpp:370-377)
     {
       const double *const hf = m->h_f.data();
@@ -877,6 +996,7 @@ int ahip_get_edges(ahip_model *m, long long *nedges, long long *edge_index, doub
     require_model(m);
     if (!nedges) throw ArgError("ahip_get_edges: nedges is NULL");
     edges_counts(*m);
+    fused_poll_alarm(*m);                    // (an accessor that waits for the device also reports an alarm nobody has collected)
     *nedges = m->nedges;
     if (!edge_index && !rij) return;
     const size_t E = (size_t)m->nedges;
@@ -932,6 +1052,7 @@ int ahip_get_timings(ahip_model *m, const char **names, const double **ms, int *
     require_model(m);
     AHIP_CHECK(hipSetDevice(m->device));
     collect_timings(m);
+    fused_poll_alarm(*m);
     if (names) *names = m->timing_names.c_str();
     if (ms) *ms = m->timing_ms.data();
     if (n) *n = (int)m->timing_ms.size();
@@ -965,6 +1086,8 @@ extern "C" int ahip_last_tile_occupancy(ahip_model *m, long long *slots_used, lo
 
 // last kernel family used ("generic_f32" | "generic_f64" | "fused_f32" | "fused_tf32eq")
 extern "C" const char *ahip_last_path(ahip_model *m) { return m ? m->last_path.c_str() : ""; }
+// what fused_arith=auto decided for this model and why (empty until the first evaluation): "f16x2 kept: ..." or "float32 instance selected: ..."
+extern "C" const char *ahip_arith_note(const ahip_model *m) { return m ? m->arith_note.c_str() : ""; }
 extern "C" int ahip_last_max_degree(ahip_model *m) {
   if (!m) return 0;
   if (guarded([&] { edges_counts(*m); }) != 0) return -1;

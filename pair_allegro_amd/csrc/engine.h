@@ -102,8 +102,18 @@ struct Model {
   std::string opt_path = "auto";            // auto | fused | generic
   std::string opt_precision = "model";      // model | float64
   std::string opt_fused_tb = "table";       // table | mlp: two-body embedding of the fused kernel from the spline table or as an MLP
-  std::string opt_fused_arith = "auto";     // auto | f32 | bf16x3 | tf32eq: arithmetic of the fused kernel's linears (fused.hip); auto = tf32eq iff the model file sets allow_tf32
-  int last_fused_arith = 0;                 // what the last fused (model S) evaluation used: 0 f32, 1 bf16x3, 2 tf32eq
+  std::string opt_fused_arith = "auto";     // auto | f32 | f16x2 | bf16x3 | tf32eq: arithmetic of the fused kernels' linears.  auto = f16x2 (float32-equivalent, fused_h.h); tf32eq iff the
+                                            // model file sets allow_tf32; f32 once auto has degraded (below)
+  int last_fused_arith = 0;                 // what the last fused evaluation used: 0 f32, 1 bf16x3, 2 tf32eq, 3 f16x2
+  // fused_arith=auto must never be less robust than the reference's float32: a model the f16x2 split cannot carry -- a weight beyond float16's
+  // range, a linear whose weights sit in float16's subnormals, an activation that overflows, a first evaluation that disagrees with the f32 instance -- runs on the
+  // f32-input MFMA instance for the rest of this model's life instead of failing.  Only an EXPLICIT fused_arith=f16x2 still reports those as errors.
+  bool arith_degraded = false;              // auto has fallen back to f32 (sticky)
+  bool arith_checked = false;               // the first-evaluation self-check of auto's f16x2 against the f32 instance has run (allegro_hip.hip: run_model)
+  int arith_force = -1;                     // self-check only: -1 none, 0 = resolve auto to f32 for this dispatch
+  int arith_check_attempts = 0;
+  std::string arith_note;                   // what auto decided and why, one line (ahip_arith_note)
+  DevBuf b_chk;                             // self-check: two force arrays + the 2-word reduction
   long long chunk_edges = 2000000;
   int reserve_wgs = 0;                      // workgroup slots the persistent fused kernels leave free (for kernels of other streams)
   bool timing = false;
@@ -232,21 +242,54 @@ void fused_free(Model &m);
 // f16x2 arithmetic (fused_h.h): device address of the model's alarm word (allocated on first use); fused_poll_alarm throws StateError when a kernel has
 // raised it -- the host-pointer call polls behind its own synchronisation, device-resident callers meet it at their next evaluation
 int *alarm_word(Model &m);
-void fused_poll_alarm(Model &m);
+bool alarm_take(Model &m);                  // true (and cleared) when a kernel has raised the word since the last call
+void fused_poll_alarm(Model &m);            // alarm_take + the policy: auto -> degrade to f32 and report once; explicit f16x2 -> StateError
+// option fused_arith as it applies (the environment variable of the A/B tools wins)
+inline std::string arith_option(const Model &m) {
+  const char *ar = std::getenv("AHIP_FUSED_ARITH");
+  return ar ? std::string(ar) : m.opt_fused_arith;
+}
+// auto -> f16x2 unless it has degraded (or the self-check is running its f32 pass)
+inline bool arith_auto_is_f16x2(const Model &m) { return !m.arith_degraded && m.arith_force != 0; }
 // arithmetic of the wide fused kernels' linears from option fused_arith: 3 = f16x2 (auto, f16x2), 0 = f32-input MFMA (f32; the bf16 splits exist in k_fused only)
 inline int lx_arith_of(const Model &m) {
-  const char *ar = std::getenv("AHIP_FUSED_ARITH");
-  const std::string a = ar ? ar : m.opt_fused_arith;
-  return (a == "auto" || a == "f16x2") ? 3 : 0;
+  const std::string a = arith_option(m);
+  return (a == "f16x2" || (a == "auto" && arith_auto_is_f16x2(m))) ? 3 : 0;
 }
-// power of two that brings the backward pass's upstream gradient scale[type] / sqrt(avg_num_neighbors) to O(1) (f16x2 arithmetic)
-inline int backward_scale_exponent(const HostModel &h) {
-  double smax = 0.0;
-  for (int t = 0; t < h.num_types; ++t) smax = std::max(smax, std::fabs(h.get("scale").data[t]));
-  const double up = smax / std::sqrt(h.avg_num_neighbors);
-  const int ex = up > 0.0 ? -(int)std::lround(std::log2(up)) : 0;
-  return std::max(-24, std::min(24, ex));
+// thrown by a fused kernel's prepare step when fused_arith=auto meets a model the f16x2 split cannot carry; run_model degrades the model and dispatches again
+struct ArithDegraded {
+  std::string why;
+};
+// range findings of append_frag_h (fused_h.h) over a model's weight stream
+enum { H_RANGE_OVERFLOW = 1, H_RANGE_TINY = 2 };
+// H_RANGE_TINY over a whole model: any [K][N] block of a dense-layer tensor whose largest weight is non-zero and below 2^-10 (fused_lx2.hip lays its stream
+// out in sub-blocks of the matrices and asks here instead of per block)
+inline int model_tiny_linear(const HostModel &h) {
+  for (const auto &kv : h.tensors) {
+    const HostTensor &t = kv.second;
+    const std::string &n = kv.first;
+    const bool dense = n.find(".lat.w") != std::string::npos || n.find(".env") != std::string::npos || n.find(".mix") != std::string::npos || n == "emb.w" || n == "out.w0" ||
+                       (n.rfind("tb.w", 0) == 0);
+    if (!dense || t.shape.size() < 2) continue;
+    const long long blk = (long long)t.shape[t.shape.size() - 2] * t.shape[t.shape.size() - 1], nb = blk > 0 ? t.numel() / blk : 0;
+    for (long long b = 0; b < nb; ++b) {
+      double wmax = 0.0;
+      for (long long i = 0; i < blk; ++i) wmax = std::max(wmax, std::fabs(t.data[(size_t)(b * blk + i)]));
+      if (wmax > 0.0 && wmax < 0x1p-10) return H_RANGE_TINY;
+    }
+  }
+  return 0;
 }
+// what a prepare step does with them: explicit f16x2 -> the overflow is an error (the tiny linear is the caller's choice); auto -> ArithDegraded
+inline void arith_range_verdict(const Model &m, int flags) {
+  if (!flags) return;
+  const char *what = (flags & H_RANGE_OVERFLOW) ? "a weight of this model exceeds float16's range" : "a linear of this model has all its weights below 2^-10 (float16 subnormal territory for the split)";
+  if (arith_option(m) == "auto") throw ArithDegraded{what};
+  if (flags & H_RANGE_OVERFLOW) throw UnsupportedError(std::string("fused_arith=f16x2: ") + what + "; use fused_arith=f32 (or auto)");
+}
+// f16x2 arithmetic: the backward pass is linear in its upstream gradient scale[type] / sqrt(avg_num_neighbors) and runs scaled by the power of two that brings that
+// gradient into [0.5, 1) -- PER CENTRE TYPE since round 6 (the kernels derive it from scale[t_i] with frexp: energy scales that differ by orders of magnitude
+// between species each get their own; one global power of two from the largest left the small species in float16's subnormals)
 // the same three for the wide shapes (l_max = 2; fused_lx.hip)
 bool fusedlx_model_supported(const Model &m, std::string *why);
 bool fusedlx_run(Model &m, const ComputeArgs &a, std::string *why);

@@ -46,6 +46,9 @@
 #ifndef AHIP_X_PARKV
 #define AHIP_X_PARKV 1
 #endif
+#ifndef AHIP_X_STGROWS
+#define AHIP_X_STGROWS 1
+#endif
 #include "fused_common.h"
 #include "fused_h.h"
 #include "prims.h"
@@ -98,7 +101,8 @@ struct FusedArgs {
   double *f, *eatom, *partial;            // partial [gridDim.x][7]
   long long *prof;                        // [PH_N] or unused
   float *dbg;                             // [E][8] per-edge diagnostics or null
-  float bscale, ibscale;                  // f16x2 arithmetic: the backward pass runs scaled by this power of two (fused_h.h), undone on the edge gradient
+  float cp[6];                            // cutoff polynomial: a, b, c of f = 1 - a x^p + b x^(p+1) - c x^(p+2) and a p, b (p + 1), c (p + 2) of its derivative (scalar registers, not per-lane values held over a tile)
+  float bscale, ibscale;                  // (unused since round 6: the backward scale of the f16x2 arithmetic is per centre type, derived in the kernel)
   int *err;                               // host-mapped word: set when an edge gradient comes out non-finite (float16 range exceeded)
 };
 
@@ -336,13 +340,12 @@ struct TileIn {
   int a0, a1, e0, e1;
   float rx, ry, rz;
   int eii, jat, tt;
-  int2 ci;
   int eoff;
 };
-__device__ __forceinline__ void tile_fetch(const FusedArgs &A, int tile, int ntiles, int s, int ca, int tid, TileIn &n) {
+__device__ __forceinline__ void tile_fetch(const FusedArgs &A, int tile, int ntiles, int s, int tid, TileIn &n) {
   n.a0 = n.a1 = n.e0 = n.e1 = 0;
   n.rx = 1.f; n.ry = 0.f; n.rz = 0.f;
-  n.eii = 0; n.jat = 0; n.tt = 0; n.ci = make_int2(0, 0); n.eoff = 0;
+  n.eii = 0; n.jat = 0; n.tt = 0; n.eoff = 0;
   if (tile >= ntiles) return;                      // (uniform)
   n.a0 = A.tile_a0[tile]; n.a1 = A.tile_a0[tile + 1]; n.e0 = A.tile_e0[tile]; n.e1 = A.tile_e0[tile + 1];
   const int e = n.e0 + s, na = n.a1 - n.a0;
@@ -352,7 +355,6 @@ __device__ __forceinline__ void tile_fetch(const FusedArgs &A, int tile, int nti
     n.jat = A.e_j[e];
     n.tt = A.e_tt[e];
   }
-  if (ca < na) n.ci = A.centre[n.a0 + ca];
   if (tid <= na) n.eoff = A.eoff[n.a0 + tid];
 }
 
@@ -364,6 +366,9 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
   // from z -- 6 row stores and 6 row loads fewer per wave-tile of a two-layer model for ~10 VALU operations per value there: 45.8 -> 44.4 ms at 1 M Si atoms.
   constexpr bool SAVEZ = AR == 3;
   constexpr bool PARKV = AHIP_X_PARKV != 0;
+  // The LAST layer's activation rows (silu' / pre-activations of its last two hidden layers) live in the wave's own slots of the staging tile instead of scratch rows:
+  // the tile is idle from that layer's environment sum to its backward tensor product (EpiSiluSaveDL / EpiSiluSaveZL): 8 row stores and 8 row loads fewer per wave-tile.
+  constexpr bool STGROWS = AHIP_X_STGROWS != 0;
   constexpr int OZL = 4 + 4 * (MD - 1), OU = 4 + 4 * MD, OVIN = 8 + 4 * MD;      // row offsets inside a layer: silu' of the LAST hidden layer, u, V_in (MD = 2: 8, 12, 16)
   static_assert(MD >= 1 && MD <= 3 && (MD == 2 || (AR == 3 && TBT)), "latent MLP depth 1 / 3: f16x2 instances with the two-body table only");
   __shared__ Lds<NW, NLT> lds;
@@ -409,7 +414,6 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
   if (tid < 2 * A.NL) lds.res[tid >> 1][tid & 1] = Wb[A.o_res[tid >> 1] + (tid & 1)];
 
   const int s = wave * 16 + j;                 // this lane's edge slot
-  const int ca = tid >> 4;                     // centre slot served by this thread in the per-centre output step
   float *const st = lds.stage + s * STG_LD;
   // Dynamic tile schedule: workgroups claim chunks of TCHUNK consecutive tiles from a global counter (workgroup
   // speeds differ by +-12 % across the chip, a static round-robin leaves the slowest one 13 % behind the average).
@@ -420,7 +424,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
   int cbase = __builtin_amdgcn_readfirstlane(lds.chunk[0]);
 
   TileIn nx_;
-  tile_fetch(A, cbase, ntiles, s, ca, tid, nx_);
+  tile_fetch(A, cbase, ntiles, s, tid, nx_);
 
   for (;;) {
     const int tile = cbase + ck;
@@ -449,7 +453,6 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     const bool valid = e < e1;
     const float rx = nx_.rx, ry = nx_.ry, rz = nx_.rz;
     const int aloc = valid ? nx_.eii - a0 : 0, jat = nx_.jat, ti = nx_.tt >> 4, tj = nx_.tt & 15;
-    const int c_i = nx_.ci.x, c_t = nx_.ci.y;                                     // per-centre output step: atom index, type
     if (tid <= na) aoffp[tid] = nx_.eoff - e0;
     // ---------------- geometry ----------------
     const float d = sqrtf(rx * rx + ry * ry + rz * rz);
@@ -458,7 +461,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     const float rc = A.T <= 4 ? lds.rc[ti * A.T + tj] : (float)A.rcut[ti * A.T + tj];
     const float xx = d / rc;
     float fc, dfc_dx;
-    cutoff_poly(A.p, xx, fc, dfc_dx);
+    cutoff_poly_c(A.p, A.cp, xx, fc, dfc_dx);
     if (!valid) { fc = 0.f; dfc_dx = 0.f; }
     const float Y1 = C_S3 * ny, Y2 = C_S3 * nz, Y3 = C_S3 * nx;
     const float pref = 2.f / rc;
@@ -470,7 +473,6 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     // ---------------- two-body embedding x0(d; type pair) ----------------
     f32x4 x[4];
     float tb_t = 0.f, tb_invh = 0.f;
-    const float *tb_ent = nullptr;
     if constexpr (TBT) {
       // x0 depends on the edge only through (d, t_i, t_j): the MLP [one-hots, Bessel * cutoff] -> 64 -> 64 -> 64, times the
       // cutoff, is tabulated per type pair as piecewise cubics in d (Hermite data from the float64 MLP and its exact
@@ -480,16 +482,17 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       const float sft = d * tb_invh;
       const int kq = min((int)sft, A.tb_nk - 1);
       tb_t = sft - (float)kq;
+      // the entry's byte offset inside the weight buffer (32 bits per lane; the 16 gathers differ in the instruction's immediate offset)
 #ifdef ABL_NOTBGATHER   // timing experiment only (results are wrong): every edge reads the same table entry
-      tb_ent = Wb + A.o_tbtab + 4 * g;
+      const int tb_off = (A.o_tbtab + 4 * g) * 4;
 #else
-      tb_ent = Wb + A.o_tbtab + ((size_t)(ti * A.T + tj) * A.tb_nk + kq) * 256 + 4 * g;
+      const int tb_off = (A.o_tbtab + ((ti * A.T + tj) * A.tb_nk + kq) * 256 + 4 * g) * 4;
 #endif
       const float vm = (valid && xx < 1.f) ? 1.f : 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const f32x4 c0 = *(const f32x4 *)(tb_ent + (t * 4 + 0) * 16), c1 = *(const f32x4 *)(tb_ent + (t * 4 + 1) * 16);
-        const f32x4 c2 = *(const f32x4 *)(tb_ent + (t * 4 + 2) * 16), c3 = *(const f32x4 *)(tb_ent + (t * 4 + 3) * 16);
+        const f32x4 c0 = bload_w(WB, tb_off + (t * 4 + 0) * 64, 0), c1 = bload_w(WB, tb_off + (t * 4 + 1) * 64, 0);
+        const f32x4 c2 = bload_w(WB, tb_off + (t * 4 + 2) * 64, 0), c3 = bload_w(WB, tb_off + (t * 4 + 3) * 64, 0);
         x[t] = (c0 + tb_t * (c1 + tb_t * (c2 + tb_t * c3))) * vm;
         // d x0 / dd for the backward pass: one coalesced row now instead of three per-edge gathers then
         bstore(SB, v16t, (R_Z1TB() + t) * ROW * 4, (c1 + tb_t * (2.f * c2 + (3.f * tb_t) * c3)) * (vm * tb_invh));
@@ -609,16 +612,20 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       {
         f32x4 cat[6], z[4], z2[4];
         cat[0] = x[0]; cat[1] = x[1]; cat[2] = x[2]; cat[3] = x[3]; cat[4] = Vp[0][0]; cat[5] = Vp[0][1];
-        if constexpr (SAVEZ && MD == 1) lin<AR, 6, 4, false, 0>(WB, wp, cat, z, v16t, ring, EpiSiluSaveZ{SB, RL + 4, v16t});
-        else lin<AR, 6, 4, false, 0>(WB, wp, cat, z, v16t, ring, EpiSiluSaveD{SB, RL + 4, v16t});
-        if constexpr (MD >= 2) {
-          if constexpr (SAVEZ && MD == 2) lin<AR, 4, 4, false, 0>(WB, wp, z, z2, v16t, ring, EpiSiluSaveZ{SB, RL + 8, v16t});
-          else lin<AR, 4, 4, false, 0>(WB, wp, z, z2, v16t, ring, EpiSiluSaveD{SB, RL + 8, v16t});
-        }
-        if constexpr (MD >= 3) {
-          if constexpr (SAVEZ) lin<AR, 4, 4, false, 0>(WB, wp, z2, z, v16t, ring, EpiSiluSaveZ{SB, RL + 12, v16t});
-          else lin<AR, 4, 4, false, 0>(WB, wp, z2, z, v16t, ring, EpiSiluSaveD{SB, RL + 12, v16t});
-        }
+        // hidden layer h (1..MD) saves silu'(z), the last one its raw z on the f16x2 instances (SAVEZ); in the last layer of the model the rows of hidden layers
+        // MD - 1 and MD go to the staging tile (images 0..3 and 4..7) instead of scratch
+        const bool stg = STGROWS && last;
+        float *const sq = st + 4 * g;
+#define AHIP_HIDDEN(KT, IN, OUT, H) do { \
+          if (stg && (H) >= MD - 1) { \
+            if (SAVEZ && (H) == MD) lin<AR, KT, 4, false, 0>(WB, wp, IN, OUT, v16t, ring, EpiSiluSaveZL{sq, 4}); \
+            else lin<AR, KT, 4, false, 0>(WB, wp, IN, OUT, v16t, ring, EpiSiluSaveDL{sq, (H) == MD ? 4 : 0}); \
+          } else if (SAVEZ && (H) == MD) lin<AR, KT, 4, false, 0>(WB, wp, IN, OUT, v16t, ring, EpiSiluSaveZ{SB, RL + 4 * (H), v16t}); \
+          else lin<AR, KT, 4, false, 0>(WB, wp, IN, OUT, v16t, ring, EpiSiluSaveD{SB, RL + 4 * (H), v16t}); } while (0)
+        AHIP_HIDDEN(6, cat, z, 1);
+        if constexpr (MD >= 2) AHIP_HIDDEN(4, z, z2, 2);
+        if constexpr (MD >= 3) AHIP_HIDDEN(4, z2, z, 3);
+#undef AHIP_HIDDEN
         f32x4 (&zl)[4] = MD == 2 ? z2 : z;              // output of the last hidden layer
         const float ra = lds.res[kk][0], rbf = lds.res[kk][1] * fc;
         if (!last) {
@@ -647,7 +654,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     f32x4 upre[4], zt[4], w0h[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) if (!SAVEZ) upre[t] = bload(SB, v16t, (R_LAYER(NL - 1, MD) + OU + t) * ROW * 4);       // the last layer saved two rows: z2 (W3 Wr)
-    load_rows<4>(SB, R_LAYER(NL - 1, MD) + OZL, zt, v16t);
+    if (!STGROWS) load_rows<4>(SB, R_LAYER(NL - 1, MD) + OZL, zt, v16t);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 wo1[2];
 #pragma unroll
@@ -662,7 +669,17 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
 
     // =========================== backward ===========================
     // f16x2: the backward pass is linear in this upstream gradient and runs scaled by a power of two that brings it to O(1) (float16 has no exponent range to spare)
-    const float deps = valid ? lds.scale[ti] * A.cenv * (AR == 3 ? A.bscale : 1.f) : 0.f;
+    // ... PER CENTRE TYPE (round 6): the exponent of this centre type's own upstream gradient, so that species whose energy scales differ by orders of
+    // magnitude each run at O(1); every edge of a centre shares it, which is all the per-centre sums need.  Its inverse waits in the slot's pad floats of
+    // the staging tile (st[128]: never staged, never reduced) instead of a register held to the end of the tile.
+    float bsc = 1.f;
+    if constexpr (AR == 3) {
+      int bex;
+      (void)frexpf(lds.scale[ti] * A.cenv, &bex);
+      bsc = ldexpf(1.f, -bex);
+      if (g == 0) st[128] = ldexpf(1.f, bex);
+    }
+    const float deps = valid ? lds.scale[ti] * A.cenv * bsc : 0.f;
     f32x4 dx[4];
     f32x4 dzr[2];
 #pragma unroll
@@ -670,6 +687,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) dzr[t][r] = deps * wo1[t][r] * dsilu1(zr[t][r]);
     lin<AR, 2, 4, false, 0>(WB, wp, dzr, dx, v16t, ring, EpiNone{});               // dzr Wr^T = the gradient w.r.t. x' of the last layer
+    if (STGROWS) {                                                                 // the last layer's rows of its last hidden layer, from the staging tile
+#pragma unroll
+      for (int t = 0; t < 4; ++t) zt[t] = stg_load(st + 4 * g, 4 + t);
+    }
     float dfc_part = 0.f, dY1 = 0.f, dY2 = 0.f, dY3 = 0.f;
     PHASE(PH_OUT);
 
@@ -693,7 +714,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
           for (int t = 0; t < 4; ++t) dx[t] = ra * dx[t];
         } else if (last && SAVEZ) {
           const float ra = lds.res[kk][0], rb = lds.res[kk][1];
-          if constexpr (MD >= 2) load_rows<4>(SB, RL + OZL - 4, zt1, v16t);
+          if constexpr (MD >= 2) { if (!STGROWS) load_rows<4>(SB, RL + OZL - 4, zt1, v16t); }
           __builtin_amdgcn_sched_barrier(0);
           float ug = 0.f;
           lin<AR, 2, 4, false, 0>(WB, wp, dzr, dh, v16t, ring, EpiMulSiluZ<4>{zt, rb * fc, ug});
@@ -724,9 +745,15 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) dx[t] = ra * dx[t];
           dfc_part += rb * ((accv[0] + accv[1]) + (accv[2] + accv[3]));
-          if constexpr (MD >= 2) load_rows<4>(SB, RL + OZL - 4, zt1, v16t);
+          if constexpr (MD >= 2) { if (!STGROWS) load_rows<4>(SB, RL + OZL - 4, zt1, v16t); }
           __builtin_amdgcn_sched_barrier(0);
           lin<AR, 2, 4, false, 0>(WB, wp, du2, dh, v16t, ring, EpiMulRows<4>{zt});
+        }
+        if constexpr (MD >= 2) {
+          if (STGROWS && last) {                                 // silu' of the hidden layer below the last, from the staging tile
+#pragma unroll
+            for (int t = 0; t < 4; ++t) zt1[t] = stg_load(st + 4 * g, t);
+          }
         }
         // prefetch V^{kk} (input of this layer's tensor product) under the MFMAs that follow
         if (kk > 0) {
@@ -837,6 +864,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
           dY1 += (p1[0] + p1[1]) + (p1[2] + p1[3]); dY2 += (p2[0] + p2[1]) + (p2[2] + p2[3]); dY3 += (p3[0] + p3[1]) + (p3[2] + p3[3]);
           __builtin_amdgcn_sched_barrier(0);
         }
+        asm volatile("" : "+v"(dY1), "+v"(dY2), "+v"(dY3));      // summed HERE: sunk to their use at the end of the tile, the sums keep a gradient row alive (in scratch) across the linear below
         if (kk > 0) {                                                      // next iteration's u and z2 rows
           if (!SAVEZ) load_rows<4>(SB, R_LAYER(kk - 1, MD) + OU, upre, v16t);
           load_rows<4>(SB, R_LAYER(kk - 1, MD) + OZL, zt, v16t);
@@ -858,7 +886,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     // (The next chunk's first tile was published in lds.chunk by thread 0 during the chunk's first tile, several barriers ago.)
     {
       const int ntile = (ck + 1 == A.tchunk) ? __builtin_amdgcn_readfirstlane(lds.chunk[cpar ^ 1]) : tile + 1;
-      tile_fetch(A, ntile, ntiles, s, ca, tid, nx_);
+      tile_fetch(A, ntile, ntiles, s, tid, nx_);
     }
     f32x4 zt1b[4];
     if constexpr (!TBT) load_rows<4>(SB, R_Z1TB(), zt1b, v16t);
@@ -873,6 +901,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { dY1 += d1[r] * w0h[t][r]; dY2 += d2[r] * w0h[t][r]; dY3 += d3[r] * w0h[t][r]; }
       }
+      asm volatile("" : "+v"(dY1), "+v"(dY2), "+v"(dY3));
       lin<AR, 4, 4, true, 0>(WB, wp, dw0, dx, v16t, ring, EpiNone{});
       if constexpr (TBT) wp = A.o_stream;                                 // last linear of the tile
     }
@@ -914,7 +943,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
     PHASE(PH_BTB);
     // ---------------- geometry backward, outputs ----------------
     {
-      const float ibs = AR == 3 ? A.ibscale : 1.f;
+      const float ibs = AR == 3 ? st[128] : 1.f;
       const float dfc_tot = gsum(dfc_part) * ibs;
       const float dd = dfc_tot * (dfc_dx / rc) + gsum(dd_part) * ibs;
       const float y1 = gsum(dY1) * ibs, y2 = gsum(dY2) * ibs, y3 = gsum(dY3) * ibs;
@@ -959,25 +988,30 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         lds.virw[wave][lane] += (double)mine;
       }
     }
+    // everything the finish derives from the thread index is formed here, from an opaque copy: computed once at kernel entry, those addresses lived
+    // the whole tile in scratch and their reloads drained the in-order load queue
+    int tidf = tid;
+    asm volatile("" : "+v"(tidf));
+    const int caf = tidf >> 4;
     int2 cil = make_int2(0, 0);
-    if (ca < na) cil = A.centre[a0 + ca];          // this thread's centre {atom, type}: fetched here, under the barrier, instead of held since the tile's top
+    if (caf < na) cil = A.centre[a0 + caf];          // this thread's centre {atom, type}: fetched here, under the barrier, instead of held since the tile's top
     __syncthreads();
     {
       // per-centre sums of (g, eps): 16 lanes per atom = 4 columns x 4 row-parts; the atom index, scale and
       // shift of this thread's centre were prefetched with the tile.  No trailing barrier: the next tile's first
       // staging write sits behind its own barrier, and its slot offsets go to the other parity buffer.
-      const int col = tid & 3, part = (tid >> 2) & 3;
+      const int col = tidf & 3, part = (tidf >> 2) & 3;
       float sum = 0.f;
-      if (ca < na)
-        for (int sl = aoffp[ca] + part; sl < aoffp[ca + 1]; sl += 4) sum += lds.stage[sl * STG_LD + col];
+      if (caf < na)
+        for (int sl = aoffp[caf] + part; sl < aoffp[caf + 1]; sl += 4) sum += lds.stage[sl * STG_LD + col];
       sum += __shfl_xor(sum, 4, 64);
       sum += __shfl_xor(sum, 8, 64);
-      if (ca < na && part == 0) {
+      if (caf < na && part == 0) {
         if (col < 3) atomicAdd(&A.f[3 * (size_t)cil.x + col], (double)sum);
         else {
           const float ei = lds.scale[cil.y] * (sum * A.cenv) + lds.shift[cil.y];
           if (A.eatom) A.eatom[cil.x] = (double)ei;
-          lds.eacc[ca] += (double)ei;
+          lds.eacc[caf] += (double)ei;
         }
       }
     }
@@ -1013,6 +1047,9 @@ void fused_launch_f16(int nw, bool prof, int md, int grid, hipStream_t s, const 
 #if AHIP_FUSED_PART == 2
 // the f16x2 instances (fused_h.o): two-body table only; latent MLP depth 1..3 (profiling build for depth 2 only)
 void fused_launch_f16(int nw, bool prof, int md, int grid, hipStream_t s, const FusedArgs &A) {
+#ifdef AHIP_ASM_ONLY      // tools/asm_k_fused.sh: the headline instance alone, for a quick look at its code (static census, spills)
+  hipLaunchKernelGGL((k_fused<4, false, 3, true, 2, 2>), dim3(grid), dim3(256), 0, s, A);
+#else
 #define AHIP_LAUNCH_NL(NWV, PROFV, NLV, MDV) hipLaunchKernelGGL((k_fused<NWV, PROFV, 3, true, NLV, MDV>), dim3(grid), dim3(NWV * 64), 0, s, A)
 #define AHIP_LAUNCH(NWV, PROFV, MDV) do { if (A.NL == 1) AHIP_LAUNCH_NL(NWV, PROFV, 1, MDV); else if (A.NL == 2) AHIP_LAUNCH_NL(NWV, PROFV, 2, MDV); else AHIP_LAUNCH_NL(NWV, PROFV, 3, MDV); } while (0)
 #define AHIP_LAUNCH_NW(PROFV, MDV) do { if (nw == 4) AHIP_LAUNCH(4, PROFV, MDV); else AHIP_LAUNCH(8, PROFV, MDV); } while (0)
@@ -1027,6 +1064,7 @@ void fused_launch_f16(int nw, bool prof, int md, int grid, hipStream_t s, const 
 #undef AHIP_LAUNCH_NW
 #undef AHIP_LAUNCH
 #undef AHIP_LAUNCH_NL
+#endif
 }
 #endif
 #if AHIP_FUSED_PART == 1
@@ -1097,9 +1135,10 @@ static int fused_resolve_arith(const Model &m, bool &tbt) {
   const HostModel &h = m.hm;
   const char *tb = std::getenv("AHIP_FUSED_TB");
   tbt = (tb ? std::string(tb) : m.opt_fused_tb) != "mlp";
-  const char *ar = std::getenv("AHIP_FUSED_ARITH");
-  const std::string arith = ar ? ar : m.opt_fused_arith;
-  int a = (arith == "b3" || arith == "bf16x3") ? 1 : (arith == "tf32eq" || (arith == "auto" && h.allow_tf32)) ? 2 : (arith == "f16x2" || arith == "auto") ? 3 : 0;
+  const std::string arith = arith_option(m);
+  // auto: tf32eq iff the model file licenses it; else f16x2 -- unless the model has degraded to f32 (engine.h) or the self-check is running its f32 pass
+  int a = (arith == "b3" || arith == "bf16x3") ? 1 : (arith == "tf32eq" || (arith == "auto" && h.allow_tf32 && m.arith_force != 0)) ? 2
+          : (arith == "f16x2" || (arith == "auto" && arith_auto_is_f16x2(m))) ? 3 : 0;
   if (a == 3 && !tbt) a = 0;        // the f16x2 instances exist with the tabulated two-body embedding only
   return a;
 }
@@ -1149,14 +1188,14 @@ static void fused_prepare(Model &m) {
   const int MD = st.md;
   const bool b3 = st.arith == 1 || st.arith == 2, tbt = st.tbt;
   const int nterm = st.arith == 1 ? 3 : 2;
-  bool h_range_ok = true;
+  int h_flags = 0;        // float16 range findings over the weight stream (engine.h: H_RANGE_*)
   auto fwd = [&](const double *W, int K, int N) {
-    if (st.arith == 3) h_range_ok = append_frag_h(w, W, K, N, N) && h_range_ok;
+    if (st.arith == 3) h_flags |= append_frag_h(w, W, K, N, N);
     else if (b3) append_frag_b(w, W, K, N, N, nterm); else append_frag(w, W, K, N, N);
   };
   auto bwd = [&](const double *W, int K, int N) {
     auto t = transpose(W, K, N);
-    if (st.arith == 3) h_range_ok = append_frag_h(w, t.data(), N, K, K) && h_range_ok;
+    if (st.arith == 3) h_flags |= append_frag_h(w, t.data(), N, K, K);
     else if (b3) append_frag_b(w, t.data(), N, K, K, nterm); else append_frag(w, t.data(), N, K, K);
   };
   auto T_ = [&](const std::string &name) -> const double * { return h.get(name).data.data(); };
@@ -1240,11 +1279,13 @@ static void fused_prepare(Model &m) {
   A.wbytes = (int)(w.size() * sizeof(float));
   A.T = T; A.NL = NL; A.p = h.poly_p;
   A.cenv = (float)(1.0 / std::sqrt(h.avg_num_neighbors));
+  {
+    const float pf = (float)h.poly_p, ca = 0.5f * (pf + 1) * (pf + 2), cb = pf * (pf + 2), cc = 0.5f * pf * (pf + 1);      // the expressions of cutoff_poly
+    A.cp[0] = ca; A.cp[1] = cb; A.cp[2] = cc; A.cp[3] = ca * pf; A.cp[4] = cb * (pf + 1); A.cp[5] = cc * (pf + 2);
+  }
   A.bscale = A.ibscale = 1.f;
   if (st.arith == 3) {
-    if (!h_range_ok) throw UnsupportedError("fused_arith=f16x2: a weight of this model exceeds float16's range; use fused_arith=f32");
-    const int ex = backward_scale_exponent(h);       // the upstream gradient of the backward pass is scale[type] / sqrt(avg_num_neighbors)
-    A.bscale = (float)std::ldexp(1.0, ex); A.ibscale = (float)std::ldexp(1.0, -ex);
+    arith_range_verdict(m, h_flags);                 // auto: ArithDegraded (run_model falls back to the f32 instance); explicit f16x2: an overflow is an error
     A.err = alarm_word(m);
   }
   hipDeviceProp_t prop;
@@ -1274,7 +1315,6 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
   if (m.edges_T_size != 4) { if (why) *why = "edge vectors are not float32"; return false; }
   fused_prepare(m);
   FusedState &st = *(FusedState *)m.fused_state;
-  fused_poll_alarm(m);       // raised by an EARLIER evaluation (nobody waits for the kernel): its forces were not finite
   if (st.prof_on || st.clk_on || st.dbg_on) edges_counts(m);      // instrumented runs size their buffers / reports from the counts
   int nw = 0;                                   // 0: decided on the device
   if (!m.counts_pending) {

@@ -109,6 +109,15 @@ __device__ __forceinline__ void cutoff_poly(int p, float x, float &f, float &df)
   df = -a * p * xp1 + b * (p + 1) * xp - c * (p + 2) * xp * x;
 }
 
+// the same polynomial with its six coefficients precomputed by the host (FusedArgs::cp: wave-uniform kernel arguments instead of per-lane values kept over a tile)
+__device__ __forceinline__ void cutoff_poly_c(int p, const float (&c)[6], float x, float &f, float &df) {
+  if (x >= 1.f) { f = 0.f; df = 0.f; return; }
+  float xp1 = 1.f;
+  for (int k = 0; k < p - 1; ++k) xp1 *= x;
+  const float xp = xp1 * x;
+  f = 1.f - c[0] * xp + c[1] * xp * x - c[2] * xp * x * x;
+  df = -c[3] * xp1 + c[4] * xp - c[5] * xp * x;
+}
 
 // ---- streamed linear: running weight-fragment ring + epilogue under the next tile pair's MFMAs ----
 // The sequence of linears of a tile is static and the host lays the fragments out in consumption order, so
@@ -169,6 +178,30 @@ struct EpiSiluSaveD {
 struct EpiSaveScale : EpiSave {  // raw rows to scratch, out = c * v
   float c;
   __device__ __forceinline__ float apply(int, int, float v) const { return c * v; }
+};
+// The same two, with the rows going to register images inside the wave's own slots of the LDS staging tile (image q of lane (j, g) = floats 16 q + 4 g .. + 3 of
+// slot row j: 8 images fit the 128 staged features).  The staging tile is idle between the last layer's environment sum and its backward tensor product, which
+// is exactly the life of that layer's activation rows: they never travel to memory (k_fused).
+__device__ __forceinline__ void stg_store(float *sq, int q, f32x4 v) { *(f32x4 *)(sq + 16 * q) = v; }
+__device__ __forceinline__ f32x4 stg_load(const float *sq, int q) { return *(const f32x4 *)(sq + 16 * q); }
+struct EpiSiluSaveDL {
+  static constexpr bool STORES = false;
+  float *sq; int q0;
+  f32x4 d[2];
+  __device__ __forceinline__ void tile_done(int, const f32x4 &) const {}
+  __device__ __forceinline__ float apply(int ot, int r, float z) {
+    const float sg = sigmoidf_fast(z), y = z * sg;
+    d[ot & 1][r] = fmaf(y, 1.f - sg, sg);
+    return y;
+  }
+  __device__ __forceinline__ void flush(int ot0) const { stg_store(sq, q0 + ot0, d[0]); stg_store(sq, q0 + ot0 + 1, d[1]); }
+};
+struct EpiSiluSaveZL {
+  static constexpr bool STORES = false;
+  float *sq; int q0;
+  __device__ __forceinline__ void tile_done(int ot, const f32x4 &acc) const { stg_store(sq, q0 + ot, acc); }
+  __device__ __forceinline__ float apply(int, int, float z) const { return z * sigmoidf_fast(z); }
+  __device__ __forceinline__ void flush(int) const {}
 };
 template <int NT> struct EpiMulRows {        // out = v * d (d = the saved silu' rows)
   static constexpr bool STORES = false;

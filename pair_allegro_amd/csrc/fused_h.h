@@ -190,11 +190,16 @@ static void frag_dims_b(int K, int N, int &KS, int &NT) {
   NT += NT & 1;
 }
 // f16x2 fragments of W [K][N] (fused_h.h): per (tile pair p, K-step ks) four 1 KiB entries hi0 hi1 lo0 lo1 in append_frag_b's lane layout;
-// hi = f16(w), lo' = f16((w - hi) * 2^11), both round-to-nearest-even.  Returns false when a weight exceeds float16's range.
-static bool append_frag_h(std::vector<float> &out, const double *W, int K, int N, int ldw) {
+// hi = f16(w), lo' = f16((w - hi) * 2^11), both round-to-nearest-even.  Returns range findings (engine.h): H_RANGE_OVERFLOW when a weight exceeds float16's
+// range, H_RANGE_TINY when the whole matrix sits below 2^-10 (hi terms near or inside float16's subnormals: the split keeps an absolute 2^-36, i.e. fewer
+// than 26 relative bits of such a matrix).
+static int append_frag_h(std::vector<float> &out, const double *W, int K, int N, int ldw) {
   int KS, NT;
   frag_dims_b(K, N, KS, NT);
   bool ok = true;
+  double wmax = 0.0;
+  for (int k = 0; k < K; ++k)
+    for (int n = 0; n < N; ++n) wmax = std::max(wmax, std::fabs(W[(size_t)k * ldw + n]));
   for (int p = 0; p < NT / 2; ++p)
     for (int ks = 0; ks < KS; ++ks)
       for (int term = 0; term < 2; ++term)
@@ -219,6 +224,6 @@ static bool append_frag_h(std::vector<float> &out, const double *W, int K, int N
               std::memcpy(&f, &word, 4);
               out.push_back(f);
             }
-  return ok;
+  return (ok ? 0 : H_RANGE_OVERFLOW) | ((wmax > 0.0 && wmax < 0x1p-10) ? H_RANGE_TINY : 0);
 }
 }  // namespace ahip

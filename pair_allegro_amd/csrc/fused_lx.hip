@@ -383,7 +383,16 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
     pin(eps);
 
     // =========================== backward ===========================
-    const float deps = valid ? lds.scale[ti] * A.cenv * (AR == 3 ? A.bscale : 1.f) : 0.f;      // f16x2: the backward pass runs scaled by a power of two (fused_h.h)
+    // f16x2: the backward pass runs scaled by a power of two (fused_h.h) -- per CENTRE TYPE since round 6: the exponent of this centre type's own upstream
+    // gradient (every edge of a centre shares it); its inverse waits in the slot's pad floats of the staging tile (never staged, never reduced)
+    float bsc = 1.f;
+    if constexpr (AR == 3) {
+      int bex;
+      (void)frexpf(lds.scale[ti] * A.cenv, &bex);
+      bsc = ldexpf(1.f, -bex);
+      if (g == 0) lds.stage[0][s * STG_LD + D * 16] = ldexpf(1.f, bex);
+    }
+    const float deps = valid ? lds.scale[ti] * A.cenv * bsc : 0.f;
     f32x4 dx[4];
     {
       f32x4 dzr[2];
@@ -592,7 +601,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
     }
     // ---------------- geometry backward, outputs ----------------
     {
-      const float ibs = AR == 3 ? A.ibscale : 1.f;
+      const float ibs = AR == 3 ? lds.stage[0][s * STG_LD + D * 16] : 1.f;      // this slot's inverse backward scale (per centre type, written at the start of the backward pass)
       const float dfc_tot = gsum(dfc_part) * ibs;
       const float dd = dfc_tot * (dfc_dx / rc) + gsum(dd_part) * ibs;
       float yv[D];
@@ -692,9 +701,9 @@ template <int L, int UT> static void fusedlx_prepare_t(Model &m, FusedLxState &s
   auto mark = [&]() { while (w.size() % 64) w.push_back(0.f); return (int)w.size(); };
   auto T_ = [&](const std::string &name) -> const double * { return h.get(name).data.data(); };
   st.arith = lx_arith_of(m);
-  bool h_range_ok = true;
+  int h_flags = 0;        // float16 range findings over the weight stream (engine.h: H_RANGE_*)
   auto frag = [&](const double *W, int K, int N, int ldw) {
-    if (st.arith == 3) h_range_ok = append_frag_h(w, W, K, N, ldw) && h_range_ok;
+    if (st.arith == 3) h_flags |= append_frag_h(w, W, K, N, ldw);
     else append_frag(w, W, K, N, ldw);
   };
   auto fwd = [&](const double *W, int K, int N) { frag(W, K, N, N); };
@@ -768,9 +777,7 @@ template <int L, int UT> static void fusedlx_prepare_t(Model &m, FusedLxState &s
   A.cenv = (float)(1.0 / std::sqrt(h.avg_num_neighbors));
   A.bscale = A.ibscale = 1.f;
   if (st.arith == 3) {
-    if (!h_range_ok) throw UnsupportedError("fused_arith=f16x2: a weight of this model exceeds float16's range; use fused_arith=f32");
-    const int ex = backward_scale_exponent(h);
-    A.bscale = (float)std::ldexp(1.0, ex); A.ibscale = (float)std::ldexp(1.0, -ex);
+    arith_range_verdict(m, h_flags);                 // auto: ArithDegraded (run_model falls back to the f32 instance); explicit f16x2: an overflow is an error
     A.err = alarm_word(m);
   }
   A.wave_scratch = (long long)S::R_TOTAL(NL) * ROW;
@@ -811,7 +818,6 @@ bool fusedlx_run(Model &m, const ComputeArgs &a, std::string *why) {
   }
   fusedlx_prepare(m);
   FusedLxState &st = *(FusedLxState *)m.fusedlx_state;
-  fused_poll_alarm(m);       // raised by an EARLIER evaluation (nobody waits for the kernel): its forces were not finite
   m.last_fused_arith = st.arith;
   hipStream_t s = a.stream;
   const int inum = m.inum;

@@ -458,7 +458,16 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
     pin(eps);
 
     // =========================== backward ===========================
-    const float deps = valid ? lds.scale[ti] * A.cenv * (AR == 3 ? A.bscale : 1.f) : 0.f;      // f16x2: the backward pass runs scaled by a power of two (fused_h.h)
+    // f16x2: the backward pass runs scaled by a power of two (fused_h.h) -- per CENTRE TYPE since round 6: the exponent of this centre type's own upstream
+    // gradient (every edge of a centre shares it); its inverse waits in the slot's pad floats of the staging tile (never staged, never reduced)
+    float bsc = 1.f;
+    if constexpr (AR == 3) {
+      int bex;
+      (void)frexpf(lds.scale[ti] * A.cenv, &bex);
+      bsc = ldexpf(1.f, -bex);
+      if (g == 0) lds.stage[0][s * STG_LD + D * 16] = ldexpf(1.f, bex);
+    }
+    const float deps = valid ? lds.scale[ti] * A.cenv * bsc : 0.f;
     f32x4 dx[4];             // dE/dx, all 64 features, own tiles first (replicated in the pair)
     {
       f32x4 dzr[2];
@@ -707,7 +716,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
         yv[5] += y1[0]; yv[6] += y1[1]; yv[7] += y1[2]; yv[8] += y1[3];
         dfc_tot += y2[0]; dd_tot += y2[1];
         if (AR == 3) {
-          const float ibs = A.ibscale;
+          const float ibs = lds.stage[0][s * STG_LD + D * 16];      // this slot's inverse backward scale (per centre type, written at the start of the backward pass)
           dfc_tot *= ibs; dd_tot *= ibs;
 #pragma unroll
           for (int lm = 1; lm < D; ++lm) yv[lm] *= ibs;
@@ -807,7 +816,7 @@ static void fusedlx2_prepare(Model &m) {
   auto mark = [&]() { while (w.size() % 64) w.push_back(0.f); return (int)w.size(); };
   auto T_ = [&](const std::string &name) -> const double * { return h.get(name).data.data(); };
   st.arith = lx_arith_of(m);
-  bool h_range_ok = true;
+  int h_flags = 0;        // float16 range findings over the weight stream (engine.h: H_RANGE_*)
   // ---- one weight stream per wave half, in the order a tile consumes it (see k_fused_lx2) ----
   for (int hf = 0; hf < 2; ++hf) {
     auto own = [&](int t) { return 2 * hf + t; };
@@ -823,7 +832,7 @@ static void fusedlx2_prepare(Model &m) {
     const std::vector<int> cat_cols = {own(0), own(1), 4 + own(0), 4 + own(1)};
     auto put = [&](const double *W, int ldw, const std::vector<int> &rt, const std::vector<int> &ct) {
       auto sub = gather_tiles(W, ldw, rt, ct);
-      if (st.arith == 3) h_range_ok = append_frag_h(w, sub.data(), 16 * (int)rt.size(), 16 * (int)ct.size(), 16 * (int)ct.size()) && h_range_ok;
+      if (st.arith == 3) h_flags |= append_frag_h(w, sub.data(), 16 * (int)rt.size(), 16 * (int)ct.size(), 16 * (int)ct.size()) & H_RANGE_OVERFLOW;      // (sub-blocks: the tiny-linear finding is taken per matrix below)
       else append_frag(w, sub.data(), 16 * (int)rt.size(), 16 * (int)ct.size(), 16 * (int)ct.size());
     };
     auto putT = [&](const double *W, int K, int N, const std::vector<int> &rt, const std::vector<int> &ct) {    // tiles of W^T ([N][K])
@@ -888,9 +897,7 @@ static void fusedlx2_prepare(Model &m) {
   A.cenv = (float)(1.0 / std::sqrt(h.avg_num_neighbors));
   A.bscale = A.ibscale = 1.f;
   if (st.arith == 3) {
-    if (!h_range_ok) throw UnsupportedError("fused_arith=f16x2: a weight of this model exceeds float16's range; use fused_arith=f32");
-    const int ex = backward_scale_exponent(h);
-    A.bscale = (float)std::ldexp(1.0, ex); A.ibscale = (float)std::ldexp(1.0, -ex);
+    arith_range_verdict(m, h_flags | model_tiny_linear(h));      // auto: ArithDegraded (run_model falls back to the f32 instance); explicit f16x2: an overflow is an error
     A.err = alarm_word(m);
   }
   A.wave_scratch = (long long)S::R_TOTAL(NL) * ROW;
@@ -912,7 +919,6 @@ bool fusedlx2_run(Model &m, const ComputeArgs &a, std::string *why) {
   constexpr int NW = S::NW, SLOTS = S::SLOTS;
   fusedlx2_prepare(m);
   FusedLxState &st = *(FusedLxState *)m.fusedlx2_state;
-  fused_poll_alarm(m);       // raised by an EARLIER evaluation (nobody waits for the kernel): its forces were not finite
   m.last_fused_arith = st.arith;
   hipStream_t s = a.stream;
   const int inum = m.inum;

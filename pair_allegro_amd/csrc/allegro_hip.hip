@@ -6,7 +6,11 @@
 // No libtorch, no Kokkos, no CPU fallback: every compute entry point needs a HIP device.
 #include "../../include/allegro_hip.h"
 
+#include <pthread.h>
+#include <sched.h>
+
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -14,7 +18,9 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <map>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -273,13 +279,22 @@ namespace {
 struct Staging {
   std::mutex mu;
   void *p = nullptr;
-  hipEvent_t ev[2] = {nullptr, nullptr};
+  // One event pair PER DEVICE: an event belongs to the device that was current when it was created and hipEventRecord refuses a stream of another
+  // device; a process that loads models on two devices (ahip_model_load takes the device) copies through the same page-locked buffer with that device's pair.
+  std::map<int, std::array<hipEvent_t, 2>> evs;
+  hipEvent_t *ev = nullptr;                 // the current device's pair, valid while `mu` is held (set by get())
   static constexpr size_t BYTES = 8u << 20, HALF = BYTES / 2;
   void *get() {
-    if (!p) {
-      AHIP_CHECK(hipHostMalloc(&p, BYTES, hipHostMallocDefault));
-      for (int k = 0; k < 2; ++k) AHIP_CHECK(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+    if (!p) AHIP_CHECK(hipHostMalloc(&p, BYTES, hipHostMallocPortable));
+    int dev = 0;
+    AHIP_CHECK(hipGetDevice(&dev));
+    auto it = evs.find(dev);
+    if (it == evs.end()) {
+      std::array<hipEvent_t, 2> e{nullptr, nullptr};
+      for (int k = 0; k < 2; ++k) AHIP_CHECK(hipEventCreateWithFlags(&e[k], hipEventDisableTiming));
+      it = evs.emplace(dev, e).first;
     }
+    ev = it->second.data();
     return p;
   }
 };
@@ -293,7 +308,14 @@ Staging g_staging;      // process-wide, never freed (the runtime may be gone wh
 int host_threads() {
   static const int n = [] {
     if (const char *e = std::getenv("AHIP_HOST_THREADS")) return std::max(1, std::atoi(e));
-    const unsigned hw = std::thread::hardware_concurrency();
+    // the CPUs this process may run on, not the machine's: under `mpirun --bind-to core` a rank owns one core, and sixteen workers
+    // taking turns on it are slower than one memcpy
+    unsigned hw = std::thread::hardware_concurrency();
+#ifdef __linux__
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) hw = (unsigned)CPU_COUNT(&set);
+#endif
     return (int)std::max(1u, std::min(16u, hw ? hw : 1u));
   }();
   return n;
@@ -343,6 +365,10 @@ struct HostPool {
 };
 std::mutex g_pool_run_mu;
 HostPool *g_pool = nullptr;
+// a forked child has none of the parent's worker threads: it starts a pool of its own at its first large loop instead of waiting for ever on the parent's
+// (the old pool object is leaked on purpose: its mutex may be held by a thread that does not exist in the child)
+void pool_atfork_child() { g_pool = nullptr; new (&g_pool_run_mu) std::mutex(); }
+const int g_pool_atfork = pthread_atfork(nullptr, nullptr, pool_atfork_child);
 }  // namespace
 template <class F> static void parallel_for(size_t n, F fn) {
   const int nt = n < 65536 ? 1 : host_threads();
@@ -574,11 +600,8 @@ static __global__ void k_chk_reduce(long long n, const double *a, const double *
     if (!(di < 1.0e300)) di = 1.0e300;
     d = fmax(d, di); f = fmax(f, fabs(a[i]));
   }
-  for (int off = 32; off > 0; off >>= 1) { d = fmax(d, __shfl_xor(d, off, 64)); f = fmax(f, __shfl_xor(f, off, 64)); }
-  if ((threadIdx.x & 63) == 0) {
-    atomicMax(out, (unsigned long long)__double_as_longlong(d));
-    atomicMax(out + 1, (unsigned long long)__double_as_longlong(f));
-  }
+  atomicMax(out, __builtin_bit_cast(unsigned long long, d));          // one pair of atomics per thread of a 1024 x 256 grid, once per model: no wave reduction needed
+  atomicMax(out + 1, __builtin_bit_cast(unsigned long long, f));
 }
 // First evaluation of a model whose fused_arith=auto resolves to f16x2 (VERDICT r05 #3c): the same centres once on the f32 instance, once on f16x2, forces
 // compared; f16x2 stays only if max|dF| <= 1e-5 max|F| (float32-equivalence on THIS model and THIS configuration, not on the builder's samples) and no

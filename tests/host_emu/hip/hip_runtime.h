@@ -46,6 +46,7 @@ template <typename T> inline hipError_t hipMalloc(T **p, size_t n) { return hipM
 inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 #define hipHostMallocDefault 0
 #define hipHostMallocMapped 2
+#define hipHostMallocPortable 1
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
 inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h; return hipSuccess; }

@@ -1,5 +1,7 @@
 """GPU tests of the fused MFMA path: the register-chain primitive, then the whole kernel against
 the float64 oracle goldens, the float32 generic path and size-independent properties."""
+import os
+
 import numpy as np
 import pytest
 
@@ -192,20 +194,25 @@ def test_fused_arith_auto_selection(hip_lib, model_dir):
     assert run({"path": "generic"}) == "generic_f32"
 
 
-def test_f16x2_range_alarm(hip_lib, model_dir):
-    """float16 has no exponent range to spare: when an operand leaves it the edge gradient comes out non-finite, the kernel raises a flag in
-    host-mapped memory and the evaluation reports AHIP_ERR_STATE naming the remedy (fused_arith=f32): the host-pointer call, which waits for the
-    kernel anyway, in the same call and before it touches f; a device-resident caller at its next evaluation.  Here: two latent linears blown up by 1e3 each;
-    fused_arith=f32 evaluates the same file."""
+def _blown_up_model(model_dir):
+    """two latent linears blown up by 1e3 each: hidden activations ~1e3 and ~1e6, the second exceeds float16's 65504"""
     g = util.load_golden("CuPd-cubic-big_r5")
     cfg = model_file.model_S(type_names=["Cu", "Pd"], avg_num_neighbors=40.0)
     w = model_file.init_weights(cfg)
-    w["l1.lat.w0"] = np.asarray(w["l1.lat.w0"]) * 1e3          # hidden activations ~1e3 and ~1e6: the second exceeds 65504
+    w["l1.lat.w0"] = np.asarray(w["l1.lat.w0"]) * 1e3
     w["l1.lat.w1"] = np.asarray(w["l1.lat.w1"]) * 1e3
     path = f"{model_dir}/h2_overflow.nequip.pth"
     allegro_torch.export_nequip_pth(path, cfg, w)
     names = ["Cu", "Pd"]
     types = np.array([names.index(s_) + 1 for s_ in g["symbols"]], dtype=np.int32)
+    return g, cfg, w, path, names, types
+
+
+def test_f16x2_range_alarm(hip_lib, model_dir):
+    """float16 has no exponent range to spare: when an operand leaves it the edge gradient comes out non-finite and the kernel raises a flag in
+    host-mapped memory.  With an EXPLICIT fused_arith=f16x2 the evaluation reports AHIP_ERR_STATE naming the remedy: the host-pointer call, which waits for the
+    kernel anyway, in the same call and before it touches f.  fused_arith=f32 evaluates the same file."""
+    g, cfg, w, path, names, types = _blown_up_model(model_dir)
     from pair_allegro_amd.pair import PairAllegro, atom_from_rank_system, list_from_rank_system
     rs = lmp_like.build_rank_system(g["cell"], g["pos"], types, cfg["r_max"] + 1.0)
     pair = PairAllegro(lib=hip_lib, quiet=True)
@@ -224,6 +231,78 @@ def test_f16x2_range_alarm(hip_lib, model_dir):
     pair.compute(atom, lst)
     assert pair.model.last_path == "fused_f32" and np.isfinite(atom.f).all()
     pair.model.close()
+
+
+def test_auto_is_never_less_robust_than_float32(hip_lib, model_dir):
+    """VERDICT r05 #3 / ADVICE r05: the reference only ever RELAXES precision when the file says so (/root/reference/pair_nequip_allegro.cpp:267-270); the default
+    arithmetic must therefore evaluate every model float32 evaluates.  Under fused_arith=auto (the default)
+      (a) an activation that leaves float16's range      -> the same call re-evaluates on the f32 instance: correct forces, path fused_f32, nothing raised;
+      (b) a weight beyond 32768                           -> the f32 weight stream is built instead (explicit f16x2: UnsupportedError);
+      (c) a linear whose weights all sit below 2^-10      -> f32 as well (the split would keep < 26 bits of it);
+    and the decision is readable (ahip_arith_note)."""
+    g, cfg, w, path, names, types = _blown_up_model(model_dir)
+    ref32 = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused", "fused_arith": "f32"})
+    for opts in ({}, {"AHIP_NO_ARITH_SELFCHECK": "1"}):            # (a) found by the first-evaluation self-check, and -- without it -- by the alarm of the evaluation itself
+        if opts:
+            os.environ["AHIP_NO_ARITH_SELFCHECK"] = "1"
+        try:
+            auto = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused"})
+        finally:
+            os.environ.pop("AHIP_NO_ARITH_SELFCHECK", None)
+        assert auto["info"]["path"] == "fused_f32" and "float32 instance" in auto["info"]["arith_note"], auto["info"]
+        np.testing.assert_allclose(auto["forces"], ref32["forces"], rtol=1e-6, atol=1e-6 * np.abs(ref32["forces"]).max())
+        np.testing.assert_allclose(auto["pe"], ref32["pe"], rtol=1e-6)
+    # (b), (c): a sane model whose one linear is scaled up by 1e6 and the next one down by 1e6
+    g2 = util.load_golden("CuPd-cubic-big_r5")
+    cfg2 = model_file.model_S(type_names=["Cu", "Pd"], avg_num_neighbors=40.0)
+    for what, edit in (("weight beyond float16", {"l2.env": 1e6}), ("tiny linear", {"l2.env": 1e-5})):
+        w2 = model_file.init_weights(cfg2)
+        for k, fct in edit.items():
+            w2[k] = np.asarray(w2[k]) * fct
+        p2 = f"{model_dir}/h2_{what.split()[0]}.nequip.pth"
+        allegro_torch.export_nequip_pth(p2, cfg2, w2)
+        r64 = util.oracle_run(dict(cfg2, model_dtype="float64"), w2, g2["cell"], g2["pos"], types, names)
+        auto = util.run_pair(hip_lib, p2, g2["cell"], g2["pos"], types, names, options={"path": "fused"})
+        assert auto["info"]["path"] == "fused_f32" and "float32 instance" in auto["info"]["arith_note"], (what, auto["info"])
+        fm = np.abs(r64["forces"]).max()
+        assert np.abs(auto["forces"] - r64["forces"]).max() < 2e-5 * fm, what
+        if "beyond" in what:
+            with pytest.raises(Exception, match="float16"):
+                util.run_pair(hip_lib, p2, g2["cell"], g2["pos"], types, names, options={"path": "fused", "fused_arith": "f16x2"})
+    # a sane model keeps f16x2 and says so
+    path3, cfg3, types3, names3, ref3 = _model_S_case(model_dir, "cupd_S_note", ["Cu", "Pd"], g2["symbols"], g2["cell"], g2["pos"])
+    ok = util.run_pair(hip_lib, path3, g2["cell"], g2["pos"], types3, names3)
+    assert ok["info"]["path"] == "fused_f16x2" and "f16x2 kept" in ok["info"]["arith_note"], ok["info"]
+
+
+def test_f16x2_backward_scale_is_per_centre_type(hip_lib, model_dir):
+    """Energy scales that differ by six orders of magnitude between species (VERDICT r05 #3b): the backward pass of the f16x2 arithmetic runs scaled by a power of
+    two PER CENTRE TYPE.  One Pd atom (scale 1e+3) in a Cu box (scale 1e-3): the forces on the Cu atoms farther than r_max from it come from Cu-centred edges
+    only, and must be as close to the float64 oracle -- relative to THEIR size -- as the f32 instance's (one global power of two taken from the largest scale left
+    those gradients in float16's subnormals: ~1e-2 relative)."""
+    g = util.load_golden("CuPd-cubic-big_r5")
+    symbols = ["Cu"] * len(g["symbols"]); symbols[0] = "Pd"
+    cfg = model_file.model_S(type_names=["Cu", "Pd"], avg_num_neighbors=40.0)
+    w = model_file.init_weights(cfg)
+    w["scale"] = np.array([1e-3, 1e3])
+    path = f"{model_dir}/h2_hetero_scale.nequip.pth"
+    allegro_torch.export_nequip_pth(path, cfg, w)
+    names = ["Cu", "Pd"]
+    types = np.array([names.index(s_) + 1 for s_ in symbols], dtype=np.int32)
+    r64 = util.oracle_run(dict(cfg, model_dtype="float64"), w, g["cell"], g["pos"], types, names)
+    cell = np.diag(np.asarray(g["cell"])) if np.asarray(g["cell"]).ndim == 2 else np.asarray(g["cell"])
+    d = np.asarray(g["pos"]) - np.asarray(g["pos"])[0]
+    d -= cell * np.round(d / cell)
+    far = np.linalg.norm(d, axis=1) > cfg["r_max"] + 0.1
+    assert far.sum() > 50
+    a = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused", "fused_arith": "f32"})
+    b = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused", "fused_arith": "f16x2"})
+    fm = np.abs(r64["forces"][far]).max()
+    ea, eb = np.abs(a["forces"][far] - r64["forces"][far]).max() / fm, np.abs(b["forces"][far] - r64["forces"][far]).max() / fm
+    print(f"Cu atoms beyond r_max of the Pd atom: max|dF| / max|F| f32 {ea:.3e}, f16x2 {eb:.3e} (max|F| there {fm:.3e}, overall {np.abs(r64['forces']).max():.3e})")
+    assert eb < max(1.5 * ea, 2e-5), (ea, eb)
+    c = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names)          # and auto keeps f16x2 on it
+    assert c["info"]["path"] == "fused_f16x2", c["info"]
 
 
 @pytest.mark.parametrize("depth", [1, 3])

@@ -81,6 +81,7 @@ def run_pair(lib, model_path, cell, pos, types, lmp_names, skin=1.0, grid=(1, 1,
             ei, rij = pair.model.get_edges()
             edges.append((rs.tag[ei[0]] - 1, rs.tag[ei[1]] - 1, rij))
             info["path"] = pair.model.last_path
+            info["arith_note"] = pair.model.arith_note
             info["max_degree"] = max(info.get("max_degree", 0), pair.model.last_max_degree)
         pair.model.close()
     i = np.concatenate([e[0] for e in edges]); j = np.concatenate([e[1] for e in edges]); d = np.concatenate([e[2] for e in edges])

@@ -292,6 +292,21 @@ int ahip_comm_set_plan(ahip_comm *c, int nswaps, const int *dim, const int *send
                        const int *nsend, const int *nrecv, const int *first_recv, const long long *const *send_idx_dev);
 /* One rank: ghost g (row nlocal + g) is the image of local row src_dev[g] displaced by shift_dev[g][3]. */
 int ahip_comm_set_plan_local(ahip_comm *c, int nlocal, int nghost, const long long *src_dev, const double *shift_dev);
+/* Re-neighboring inside the library (round 6) -- what LAMMPS' Comm::exchange and Comm::borders give the reference at every re-neighboring
+ * (pair_nequip_allegro.cpp:366-368 relies on the ghost shell and the reverse communication they set up).  Brick decomposition: `grid` ranks per dimension,
+ * this rank at `coord`, rank = (cx * gy + cy) * gz + cz, brick [lo, hi), periodic `box`.  Both calls are collective over the communicator, synchronise `stream`
+ * a few times (counts travel to the host) and agree on overflow TOGETHER (no rank is left waiting in an exchange).
+ * ahip_comm_migrate: wraps the nlocal owned positions into the box and hands the atoms that left the brick (at most one brick per re-neighboring) to the
+ *   neighbour brick with their velocity, tag and model type; the arrays have room for `capacity` rows; *nlocal_new is the new owned count, or -(rows needed)
+ *   on every rank when some brick would overflow (the arrays are then partly migrated: treat as fatal, start with more room).
+ * ahip_comm_borders: rebuilds the ghost shell of thickness rc behind the owned rows of x_dev / mtype_dev (capacity rows) by the six directed swaps of
+ *   ahip_comm_set_plan -- send lists in ascending row order, later dimensions forwarding what earlier ones received -- and INSTALLS that plan in the communicator
+ *   (the lists live in the library until the next call).  *nall = owned + ghost rows; a value above `capacity` means nothing may be used and every rank got that
+ *   answer: call again with larger arrays (the owned rows are untouched). */
+int ahip_comm_migrate(ahip_comm *c, int nlocal, double *x_dev, double *v_dev, long long *tag_dev, int *mtype_dev, int capacity, const double *box,
+                      const int *grid, const int *coord, int *nlocal_new, void *stream);
+int ahip_comm_borders(ahip_comm *c, int nlocal, double *x_dev, int *mtype_dev, int capacity, const double *lo, const double *hi, const double *box,
+                      double rc, const int *grid, const int *coord, int *nall, void *stream);
 /* x_dev [nall][3]: ghost rows refreshed from their owners (forward);  f_dev [nall][3]: ghost rows added to their owners (reverse). */
 int ahip_comm_forward(ahip_comm *c, double *x_dev, void *stream);
 int ahip_comm_reverse(ahip_comm *c, double *f_dev, void *stream);

@@ -137,6 +137,11 @@ class AllegroOracle(torch.nn.Module):
             s5 = math.sqrt(5.0)
             cols += [s15 * x * y, s15 * y * z, 0.5 * s5 * (2 * z * z - x * x - y * y),
                      s15 * x * z, 0.5 * s15 * (x * x - y * y)]
+        if self.L >= 3:                     # the l = 3 block of pair_allegro_amd/cg.py: real_sh (homogeneous cubics, component normalisation)
+            s70, s105, s42, s7 = math.sqrt(70.0), math.sqrt(105.0), math.sqrt(42.0), math.sqrt(7.0)
+            cols += [0.25 * s70 * y * (3 * x * x - y * y), s105 * x * y * z, 0.25 * s42 * y * (4 * z * z - x * x - y * y),
+                     0.5 * s7 * z * (2 * z * z - 3 * x * x - 3 * y * y), 0.25 * s42 * x * (4 * z * z - x * x - y * y),
+                     0.5 * s105 * z * (x * x - y * y), 0.25 * s70 * x * (x * x - 3 * y * y)]
         return torch.stack(cols, dim=1)
 
     def _tp(self, V: torch.Tensor, env_e: torch.Tensor, pw: torch.Tensor, scalar_only: bool) -> torch.Tensor:

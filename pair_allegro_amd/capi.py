@@ -35,7 +35,7 @@ SYMBOLS = [
     "ahip_compute_dev_range", "ahip_last_list_size", "ahip_neigh_update_dev_table", "ahip_map_types_dev", "ahip_reneighbor_flag_dev",
     "ahip_last_path", "ahip_last_max_degree", "ahip_debug_fused_linear", "ahip_debug_fused_edges", "ahip_build_neighbors_dev", "ahip_nve_dev", "ahip_nve_first_dev",
     "ahip_model_allow_tf32", "ahip_comm_unique_id", "ahip_comm_create_rccl", "ahip_comm_create_hosted", "ahip_comm_rccl_version", "ahip_comm_free", "ahip_comm_set_plan", "ahip_comm_set_plan_local",
-    "ahip_comm_forward", "ahip_comm_reverse", "ahip_comm_allreduce", "ahip_comm_selftest", "ahip_fill_zero_dev", "ahip_borders_local_dev", "ahip_arith_note",
+    "ahip_comm_forward", "ahip_comm_reverse", "ahip_comm_allreduce", "ahip_comm_selftest", "ahip_fill_zero_dev", "ahip_borders_local_dev", "ahip_arith_note", "ahip_comm_borders", "ahip_comm_migrate",
 ]
 
 
@@ -123,6 +123,10 @@ class Library:
         L.ahip_comm_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ahip_comm_reverse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ahip_comm_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.ahip_comm_migrate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]
+        L.ahip_comm_borders.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                        C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]
         L.ahip_comm_selftest.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.ahip_fill_zero_dev.argtypes = [C.c_void_p, C.c_longlong, C.c_void_p]
 
@@ -428,6 +432,23 @@ class Comm:
 
     def reverse(self, f_ptr: int, stream: int = 0) -> None:
         self.L.check(self.L.lib.ahip_comm_reverse(self.h, f_ptr, stream or None))
+
+    def migrate(self, nlocal: int, x_ptr: int, v_ptr: int, tag_ptr: int, mtype_ptr: int, capacity: int, box, grid, coord, stream: int = 0) -> int:
+        """Comm::exchange inside the library (csrc/comm.hip: comm_migrate); returns the new owned count, negative = rows some brick would need."""
+        b = np.ascontiguousarray(box, dtype=np.float64); g = np.ascontiguousarray(grid, dtype=np.int32); c = np.ascontiguousarray(coord, dtype=np.int32)
+        out = C.c_int(0)
+        self.L.check(self.L.lib.ahip_comm_migrate(self.h, nlocal, C.c_void_p(x_ptr), C.c_void_p(v_ptr), C.c_void_p(tag_ptr), C.c_void_p(mtype_ptr), capacity,
+                                                  _p(b, C.c_double), _p(g, C.c_int), _p(c, C.c_int), C.byref(out), stream or None))
+        return out.value
+
+    def borders(self, nlocal: int, x_ptr: int, mtype_ptr: int, capacity: int, lo, hi, box, rc: float, grid, coord, stream: int = 0) -> int:
+        """Comm::borders inside the library (comm_borders): ghosts behind the owned rows, the exchange plan installed; returns owned + ghost rows (> capacity: retry)."""
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (lo, hi, box)]
+        g = np.ascontiguousarray(grid, dtype=np.int32); c = np.ascontiguousarray(coord, dtype=np.int32)
+        out = C.c_int(0)
+        self.L.check(self.L.lib.ahip_comm_borders(self.h, nlocal, C.c_void_p(x_ptr), C.c_void_p(mtype_ptr), capacity, _p(a[0], C.c_double), _p(a[1], C.c_double),
+                                                  _p(a[2], C.c_double), float(rc), _p(g, C.c_int), _p(c, C.c_int), C.byref(out), stream or None))
+        return out.value
 
     def allreduce(self, ptr: int, count: int, kind: int, stream: int = 0) -> None:
         self.L.check(self.L.lib.ahip_comm_allreduce(self.h, ptr, count, kind, stream or None))

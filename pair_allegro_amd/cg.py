@@ -36,7 +36,12 @@ SQ3 = np.sqrt(3.0)
 SQ5 = np.sqrt(5.0)
 SQ15 = np.sqrt(15.0)
 
-LMAX_SUPPORTED = 2
+SQ7 = np.sqrt(7.0)
+SQ42 = np.sqrt(42.0)
+SQ70 = np.sqrt(70.0)
+SQ105 = np.sqrt(105.0)
+
+LMAX_SUPPORTED = 3
 
 
 def sh_dim(lmax: int) -> int:
@@ -65,6 +70,18 @@ def real_sh(n: np.ndarray, lmax: int) -> np.ndarray:
             0.5 * SQ5 * (2 * z * z - x * x - y * y),
             SQ15 * x * z,
             0.5 * SQ15 * (x * x - y * y),
+        ]
+    if lmax >= 3:
+        # l = 3, m = -3 .. 3, same conventions (z the polar axis, component normalisation: the mean square of every component over the sphere is 1);
+        # written as homogeneous cubics (r = 1), which is the form the kernels differentiate (generic_kernels.h: sh_grad_dot)
+        cols += [
+            0.25 * SQ70 * y * (3 * x * x - y * y),
+            SQ105 * x * y * z,
+            0.25 * SQ42 * y * (4 * z * z - x * x - y * y),
+            0.5 * SQ7 * z * (2 * z * z - 3 * x * x - 3 * y * y),
+            0.25 * SQ42 * x * (4 * z * z - x * x - y * y),
+            0.5 * SQ105 * z * (x * x - y * y),
+            0.25 * SQ70 * x * (x * x - 3 * y * y),
         ]
     return np.stack(cols, axis=-1)
 

@@ -66,7 +66,7 @@ int ahip_device_count(int *count) {
 static void require_model(const ahip_model *m) { if (!m) throw ArgError("model handle is NULL"); }
 
 static void validate_shape(const HostModel &h) {
-  if (h.l_max < 0 || h.l_max > 2) throw UnsupportedError("l_max must be 0, 1 or 2 (got " + std::to_string(h.l_max) + ")");
+  if (h.l_max < 0 || h.l_max > 3) throw UnsupportedError("l_max must be 0 .. 3 (got " + std::to_string(h.l_max) + ")");      // 3: layer-at-a-time kernels only
   if (h.num_layers < 1) throw UnsupportedError("num_layers must be >= 1");
   if (h.num_bessels < 1 || h.S < 1 || h.U < 1 || h.mlp_width < 1) throw UnsupportedError("bad model dimensions");
   if (h.mlp_depth < 0 || h.readout_depth < 0) throw UnsupportedError("bad MLP depth");
@@ -84,8 +84,8 @@ static void validate_shape(const HostModel &h) {
     dims.push_back(dout);
     for (size_t k = 0; k + 1 < dims.size(); ++k) need(pre + ".w" + std::to_string(k), {dims[k], dims[k + 1]});
   };
-  const int npf = L == 0 ? AHIP_CG_L0_NPATHS : (L == 1 ? AHIP_CG_L1_NPATHS : AHIP_CG_L2_NPATHS);
-  const int nps = L == 0 ? AHIP_CG_L0_NPATHS_SCALAR : (L == 1 ? AHIP_CG_L1_NPATHS_SCALAR : AHIP_CG_L2_NPATHS_SCALAR);
+  const int npf = L == 0 ? AHIP_CG_L0_NPATHS : (L == 1 ? AHIP_CG_L1_NPATHS : (L == 2 ? AHIP_CG_L2_NPATHS : AHIP_CG_L3_NPATHS));
+  const int nps = L == 0 ? AHIP_CG_L0_NPATHS_SCALAR : (L == 1 ? AHIP_CG_L1_NPATHS_SCALAR : (L == 2 ? AHIP_CG_L2_NPATHS_SCALAR : AHIP_CG_L3_NPATHS_SCALAR));
   need_mlp("tb", 2 * T + B, h.mlp_depth, W, S);
   need("emb.w", {S, U * (L + 1)});
   for (int k = 1; k <= h.num_layers; ++k) {
@@ -128,9 +128,10 @@ int ahip_model_load(const char *path, int device, ahip_model **out) {
       if (!m->hm.per_edge_type_cutoff.empty()) m->rcut_model_host = m->hm.per_edge_type_cutoff;
       AHIP_CHECK(hipMalloc((void **)&m->rcut_model_dev, (size_t)T * T * sizeof(double)));
       AHIP_CHECK(hipMemcpy(m->rcut_model_dev, m->rcut_model_host.data(), (size_t)T * T * sizeof(double), hipMemcpyHostToDevice));
-      const AhipCgEntry *tab = m->hm.l_max == 0 ? ahip_cg_l0 : (m->hm.l_max == 1 ? ahip_cg_l1 : ahip_cg_l2);
-      m->ncg_full = m->hm.l_max == 0 ? AHIP_CG_L0_N : (m->hm.l_max == 1 ? AHIP_CG_L1_N : AHIP_CG_L2_N);
-      m->ncg_scalar = m->hm.l_max == 0 ? AHIP_CG_L0_NSCALAR : (m->hm.l_max == 1 ? AHIP_CG_L1_NSCALAR : AHIP_CG_L2_NSCALAR);
+      const int lm_ = m->hm.l_max;
+      const AhipCgEntry *tab = lm_ == 0 ? ahip_cg_l0 : (lm_ == 1 ? ahip_cg_l1 : (lm_ == 2 ? ahip_cg_l2 : ahip_cg_l3));
+      m->ncg_full = lm_ == 0 ? AHIP_CG_L0_N : (lm_ == 1 ? AHIP_CG_L1_N : (lm_ == 2 ? AHIP_CG_L2_N : AHIP_CG_L3_N));
+      m->ncg_scalar = lm_ == 0 ? AHIP_CG_L0_NSCALAR : (lm_ == 1 ? AHIP_CG_L1_NSCALAR : (lm_ == 2 ? AHIP_CG_L2_NSCALAR : AHIP_CG_L3_NSCALAR));
       AHIP_CHECK(hipMalloc(&m->cg_dev, (size_t)m->ncg_full * sizeof(AhipCgEntry)));
       AHIP_CHECK(hipMemcpy(m->cg_dev, tab, (size_t)m->ncg_full * sizeof(AhipCgEntry), hipMemcpyHostToDevice));
     } catch (...) { ahip_model_free(m); throw; }

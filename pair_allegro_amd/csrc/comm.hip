@@ -29,6 +29,9 @@
 
 #include "../../include/allegro_hip.h"
 #include "engine.h"
+#include "prims.h"
+
+extern "C" int ahip_comm_allreduce(ahip_comm *h, void *buf_dev, int count, int kind, void *stream);
 
 namespace ahip {
 
@@ -126,6 +129,10 @@ struct Comm {
   const double *loc_shift = nullptr;
   bool local_plan = false;
   DevBuf sendbuf[2], recvbuf[2];        // per swap of a dimension pair
+  // re-neighboring inside the library (ahip_comm_borders / ahip_comm_migrate): the plan's index arrays and the work space of the ordered compactions
+  DevBuf own_idx[6];                    // send lists of the six swaps (the plan built by ahip_comm_borders points here)
+  DevBuf cnt, off, words, mbuf[2], keep[4];
+  PrimScratch prim;
 };
 
 #define AHIP_NCCL(expr)                                                                                   \
@@ -245,6 +252,294 @@ static void comm_reverse(Comm &c, double *f, hipStream_t s) {
   }
 }
 
+
+// ---------------------------------------------------------------------------- re-neighboring: borders and migration (round 6)
+// What LAMMPS gives the reference for free at every re-neighboring -- Comm::exchange (atoms that left the brick go to the neighbour brick) and
+// Comm::borders (the ghost shell is rebuilt and the swap lists of the per-step communication with it; pair_nequip_allegro.cpp:366-368 relies on
+// both) -- was six rounds of torch mask / nonzero / index / cat per dimension in the stand-alone driver (md.py).  Here: ordered compactions as
+// count-per-chunk, exclusive scan, fill (three small launches; the lists come out in ascending row order, so the ghost rows, and with them the
+// neighbor lists and the summation orders, are reproducible), the counts exchanged as 8-byte messages, the slabs as one message per peer.
+// All kernels are free of cross-lane operations: the host-emulation build runs them for the gloo tests.
+static constexpr int CH = 32;                 // rows per chunk of the ordered compaction
+
+struct SlabCut { int dim; double lo_cut, hi_cut; };
+// class of row i: 1 = goes into the lower slab / list 0, 2 = upper slab / list 1, 3 = both (a brick thinner than two halos), 0 = neither
+__device__ inline int row_class(const double *x, int i, const SlabCut c) {
+  const double v = x[3 * (size_t)i + c.dim];
+  return (v < c.lo_cut ? 1 : 0) | (v >= c.hi_cut ? 2 : 0);
+}
+// migration: 1 = leaves downwards, 2 = leaves upwards, 0 = stays (atoms move at most one brick between two re-neighborings; with two bricks along
+// the dimension both directions reach the same rank: "below" wins, as in md.py)
+struct MigCut { int dim, g, coord; double width; };
+__device__ inline int row_class(const double *x, int i, const MigCut c) {
+  int cell = (int)floor(x[3 * (size_t)i + c.dim] / c.width);
+  cell = cell < 0 ? 0 : (cell > c.g - 1 ? c.g - 1 : cell);
+  const int delta = ((cell - c.coord) % c.g + c.g) % c.g;
+  return delta == c.g - 1 ? 1 : (delta == 1 ? 2 : 0);
+}
+template <class Cut, bool MIG> static __global__ void k_cls_count(int n, const double *x, Cut c, int nchunk, int *cnt) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nchunk) return;
+  int c0 = 0, c1 = 0, c2 = 0;
+  for (int i = t * CH; i < ((t + 1) * CH < n ? (t + 1) * CH : n); ++i) {
+    const int k = row_class(x, i, c);
+    if (MIG) { c0 += k == 1; c1 += k == 2; c2 += k == 0; } else { c0 += k & 1; c1 += (k >> 1) & 1; }
+  }
+  cnt[t] = c0; cnt[nchunk + t] = c1;
+  if (MIG) cnt[2 * nchunk + t] = c2;
+}
+// lists 0 / 1 (/ 2: the rows that stay) in ascending row order; off = exclusive scan of cnt over [list][chunk]
+template <class Cut, bool MIG> static __global__ void k_cls_fill(int n, const double *x, Cut c, int nchunk, const int *off, long long *l0, long long *l1, long long *l2) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nchunk) return;
+  int o0 = off[t], o1 = off[nchunk + t] - off[nchunk], o2 = MIG ? off[2 * nchunk + t] - off[2 * nchunk] : 0;
+  for (int i = t * CH; i < ((t + 1) * CH < n ? (t + 1) * CH : n); ++i) {
+    const int k = row_class(x, i, c);
+    if (MIG) { if (k == 1) l0[o0++] = i; else if (k == 2) l1[o1++] = i; else l2[o2++] = i; }
+    else { if (k & 1) l0[o0++] = i; if (k & 2) l1[o1++] = i; }
+  }
+}
+static __global__ void k_gather_i32(int n, const long long *idx, const int *src, int *dst) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) dst[k] = src[idx[k]];
+}
+static __global__ void k_copy_f64(long long n, const double *src, double *dst) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) dst[k] = src[k];
+}
+static __global__ void k_copy_i32(long long n, const int *src, int *dst) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) dst[k] = src[k];
+}
+static __global__ void k_wrap(int n, double *x, double bx, double by, double bz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  x[3 * (size_t)i] -= floor(x[3 * (size_t)i] / bx) * bx;
+  x[3 * (size_t)i + 1] -= floor(x[3 * (size_t)i + 1] / by) * by;
+  x[3 * (size_t)i + 2] -= floor(x[3 * (size_t)i + 2] / bz) * bz;
+}
+// migration record of one atom: x[3], v[3], tag, model type as 8 doubles (md.py's layout)
+static __global__ void k_mig_pack(int n, const long long *idx, const double *x, const double *v, const long long *tag, const int *mt, double *buf) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const long long i = idx[k];
+  double *b = buf + 8 * (size_t)k;
+  b[0] = x[3 * i]; b[1] = x[3 * i + 1]; b[2] = x[3 * i + 2]; b[3] = v[3 * i]; b[4] = v[3 * i + 1]; b[5] = v[3 * i + 2];
+  b[6] = (double)tag[i]; b[7] = (double)mt[i];
+}
+static __global__ void k_mig_unpack(int n, const double *buf, int first, double *x, double *v, long long *tag, int *mt) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const double *b = buf + 8 * (size_t)k;
+  const size_t i = (size_t)first + k;
+  x[3 * i] = b[0]; x[3 * i + 1] = b[1]; x[3 * i + 2] = b[2]; v[3 * i] = b[3]; v[3 * i + 1] = b[4]; v[3 * i + 2] = b[5];
+  tag[i] = (long long)b[6]; mt[i] = (int)b[7];
+}
+static __global__ void k_mig_keep(int n, const long long *idx, const double *x, const double *v, const long long *tag, const int *mt,
+                                  double *xk, double *vk, long long *tk, int *mk) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const long long i = idx[k];
+  for (int c = 0; c < 3; ++c) { xk[3 * (size_t)k + c] = x[3 * i + c]; vk[3 * (size_t)k + c] = v[3 * i + c]; }
+  tk[k] = tag[i]; mk[k] = mt[i];
+}
+static __global__ void k_copy_i64(long long n, const long long *src, long long *dst) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) dst[k] = src[k];
+}
+
+static inline unsigned gridfor(long long n, unsigned B = 256) { return (unsigned)std::max<long long>(1, (n + B - 1) / B); }
+static int rank_of(const int *grid, int cx, int cy, int cz) { return (cx * grid[1] + cy) * grid[2] + cz; }
+// rank of the neighbour brick `step` along `dim` and the periodic shift applied to positions sent there (md.py: _neighbor)
+static int neighbour(const int *grid, const int *coord, const double *box, int dim, int step, double *shift) {
+  int c[3] = {coord[0], coord[1], coord[2]};
+  c[dim] += step;
+  *shift = 0.0;
+  if (c[dim] < 0) { c[dim] += grid[dim]; *shift = +box[dim]; }
+  else if (c[dim] >= grid[dim]) { c[dim] -= grid[dim]; *shift = -box[dim]; }
+  return rank_of(grid, c[0], c[1], c[2]);
+}
+// my two counts go to the two neighbours, theirs come back (8 bytes per peer; one message when both neighbours are the same rank)
+static void exchange_counts(Comm &c, hipStream_t s, const int nsend[2], const int to[2], const int from[2], int nrecv[2]) {
+  c.words.reserve(64);
+  int *w = c.words.as<int>();                     // [0..1] mine, [4..5] received
+  const bool self0 = to[0] == c.rank && from[0] == c.rank, self1 = to[1] == c.rank && from[1] == c.rank;
+  nrecv[0] = nsend[0]; nrecv[1] = nsend[1];
+  if (self0 && self1) return;
+  AHIP_CHECK(hipMemcpyAsync(w, nsend, 8, hipMemcpyHostToDevice, s));
+  Xfer X{c, s, {}};
+  if (!self0 && !self1 && to[0] == to[1] && from[0] == from[1] && to[0] == from[0]) {          // two bricks along the dimension: one peer
+    X.send(w, 8, to[0]); X.recv(w + 4, 8, from[0]);
+  } else {
+    if (!self0) { X.send(w, 4, to[0]); X.recv(w + 4, 4, from[0]); }
+    if (!self1) { X.send(w + 1, 4, to[1]); X.recv(w + 5, 4, from[1]); }
+  }
+  X.run();
+  int got[2] = {0, 0};
+  AHIP_CHECK(hipMemcpyAsync(got, w + 4, 8, hipMemcpyDeviceToHost, s));
+  AHIP_CHECK(hipStreamSynchronize(s));
+  if (!self0) nrecv[0] = got[0];
+  if (!self1) nrecv[1] = got[1];
+}
+// in-place max over the ranks of one host integer (the "does anybody overflow" agreement)
+static int agree_max(Comm &c, hipStream_t s, int v) {
+  if (c.nranks == 1) return v;
+  c.words.reserve(64);
+  int *w = c.words.as<int>() + 8;
+  AHIP_CHECK(hipMemcpyAsync(w, &v, 4, hipMemcpyHostToDevice, s));
+  if (ahip_comm_allreduce((ahip_comm *)&c, w, 1, 1, s) != AHIP_OK) throw StateError("all-reduce of the overflow flag failed");
+  AHIP_CHECK(hipMemcpyAsync(&v, w, 4, hipMemcpyDeviceToHost, s));
+  AHIP_CHECK(hipStreamSynchronize(s));
+  return v;
+}
+
+// Comm::borders.  x / mtype hold the nlocal owned atoms in rows [0, nlocal) and have room for `capacity` rows.  Returns the number of rows the brick
+// needs (owned + ghosts); > capacity means NOTHING may be used: every rank gets that answer together and the caller repeats the call with larger arrays.
+static int comm_borders(Comm &c, int nlocal, double *x, int *mtype, int capacity, const double *lo, const double *hi, const double *box, double rc,
+                        const int *grid, const int *coord, hipStream_t s) {
+  c.swaps.clear();
+  c.local_plan = false;
+  int ncur = nlocal, need = nlocal;
+  bool overflow = nlocal > capacity;
+  for (int d = 0; d < 3; ++d) {
+    const int nprev = overflow ? 0 : ncur;                       // rows known before this dimension (after an overflow the lists no longer matter, only the message sizes do)
+    const int nchunk = (nprev + CH - 1) / CH;
+    int nsend[2] = {0, 0};
+    long long *lst[2] = {nullptr, nullptr};
+    if (nprev > 0) {
+      c.cnt.reserve((size_t)2 * nchunk * sizeof(int)); c.off.reserve(((size_t)2 * nchunk + 1) * sizeof(int));
+      const SlabCut cut{d, lo[d] + rc, hi[d] - rc};
+      hipLaunchKernelGGL((k_cls_count<SlabCut, false>), dim3(gridfor(nchunk)), dim3(256), 0, s, nprev, x, cut, nchunk, c.cnt.as<int>());
+      AHIP_CHECK(prim_exclusive_scan_i32(c.prim, c.cnt.as<int>(), c.off.as<int>(), 2 * nchunk, s));
+      int tot[2] = {0, 0};
+      AHIP_CHECK(hipMemcpyAsync(&tot[0], c.off.as<int>() + nchunk, 4, hipMemcpyDeviceToHost, s));
+      AHIP_CHECK(hipMemcpyAsync(&tot[1], c.off.as<int>() + 2 * nchunk, 4, hipMemcpyDeviceToHost, s));
+      AHIP_CHECK(hipStreamSynchronize(s));
+      nsend[0] = tot[0]; nsend[1] = tot[1] - tot[0];
+      for (int q = 0; q < 2; ++q) { c.own_idx[2 * d + q].reserve((size_t)std::max(nsend[q], 1) * sizeof(long long)); lst[q] = c.own_idx[2 * d + q].as<long long>(); }
+      hipLaunchKernelGGL((k_cls_fill<SlabCut, false>), dim3(gridfor(nchunk)), dim3(256), 0, s, nprev, x, cut, nchunk, c.off.as<int>(), lst[0], lst[1], (long long *)nullptr);
+    }
+    int to[2], from[2], nrecv[2];
+    double shift[2], dummy;
+    for (int q = 0; q < 2; ++q) { const int step = q == 0 ? -1 : +1; to[q] = neighbour(grid, coord, box, d, step, &shift[q]); from[q] = neighbour(grid, coord, box, d, -step, &dummy); }
+    exchange_counts(c, s, nsend, to, from, nrecv);
+    need += nrecv[0] + nrecv[1];
+    const bool fits = !overflow && (long long)ncur + nrecv[0] + nrecv[1] <= capacity;
+    // messages: [x rows (24 B each) | model types (4 B each)] per swap; both swaps of a dimension in one message when they share the peer.  A rank that has
+    // overflowed still sends and receives messages of the announced sizes (into scratch), so that no peer waits for ever.
+    const bool self0 = to[0] == c.rank && from[0] == c.rank, self1 = to[1] == c.rank && from[1] == c.rank;
+    const bool one_peer = !self0 && !self1 && to[0] == to[1] && from[0] == from[1] && to[0] == from[0];
+    const int first[2] = {ncur, ncur + nrecv[0]};
+    auto msg_bytes = [](int n) { return (long long)n * 28; };
+    for (int q = 0; q < 2; ++q) { c.sendbuf[q].reserve((size_t)std::max<long long>(msg_bytes(nsend[0]) + msg_bytes(nsend[1]), 64)); c.recvbuf[q].reserve((size_t)std::max<long long>(msg_bytes(nrecv[0]) + msg_bytes(nrecv[1]), 64)); }
+    Xfer X{c, s, {}};
+    for (int q = 0; q < 2; ++q) {
+      const bool self = q == 0 ? self0 : self1;
+      if (self) {                                                  // one brick along this dimension: my own periodic images, straight into their rows
+        if (fits && nsend[q] > 0) {
+          hipLaunchKernelGGL(k_comm_pack, dim3(gridfor(nsend[q])), dim3(256), 0, s, nsend[q], lst[q], x, d, shift[q], x + 3 * (size_t)first[q]);
+          hipLaunchKernelGGL(k_gather_i32, dim3(gridfor(nsend[q])), dim3(256), 0, s, nsend[q], lst[q], mtype, mtype + first[q]);
+        }
+        continue;
+      }
+      // layout of a (possibly merged) message: [x of swap 0][x of swap 1][types of swap 0][types of swap 1]
+      char *sb = (char *)c.sendbuf[one_peer ? 0 : q].p;
+      const int n0 = one_peer ? nsend[0] : (q == 0 ? nsend[0] : 0), n1 = one_peer ? nsend[1] : (q == 1 ? nsend[1] : 0);
+      double *xs = (double *)sb + (q == 1 && one_peer ? 3 * (size_t)n0 : 0);
+      int *ts = (int *)(sb + 24 * ((size_t)n0 + n1)) + (q == 1 && one_peer ? n0 : 0);
+      if (nsend[q] > 0 && nprev > 0) {
+        hipLaunchKernelGGL(k_comm_pack, dim3(gridfor(nsend[q])), dim3(256), 0, s, nsend[q], lst[q], x, d, shift[q], xs);
+        hipLaunchKernelGGL(k_gather_i32, dim3(gridfor(nsend[q])), dim3(256), 0, s, nsend[q], lst[q], mtype, ts);
+      }
+      if (!one_peer) { X.send(sb, msg_bytes(nsend[q]), to[q]); X.recv(c.recvbuf[q].p, msg_bytes(nrecv[q]), from[q]); }
+    }
+    if (one_peer) { X.send(c.sendbuf[0].p, msg_bytes(nsend[0]) + msg_bytes(nsend[1]), to[0]); X.recv(c.recvbuf[0].p, msg_bytes(nrecv[0]) + msg_bytes(nrecv[1]), from[0]); }
+    X.run();
+    if (fits) {
+      for (int q = 0; q < 2; ++q) {
+        const bool self = q == 0 ? self0 : self1;
+        if (self || nrecv[q] == 0) continue;
+        const char *rb = (const char *)c.recvbuf[one_peer ? 0 : q].p;
+        const int n0 = one_peer ? nrecv[0] : (q == 0 ? nrecv[0] : 0), n1 = one_peer ? nrecv[1] : (q == 1 ? nrecv[1] : 0);
+        const double *xr = (const double *)rb + (q == 1 && one_peer ? 3 * (size_t)n0 : 0);
+        const int *tr = (const int *)(rb + 24 * ((size_t)n0 + n1)) + (q == 1 && one_peer ? n0 : 0);
+        hipLaunchKernelGGL(k_copy_f64, dim3(gridfor(3LL * nrecv[q])), dim3(256), 0, s, 3LL * nrecv[q], xr, x + 3 * (size_t)first[q]);
+        hipLaunchKernelGGL(k_copy_i32, dim3(gridfor(nrecv[q])), dim3(256), 0, s, (long long)nrecv[q], tr, mtype + first[q]);
+      }
+      for (int q = 0; q < 2; ++q)
+        c.swaps.push_back(Swap{d, to[q], from[q], nsend[q], nrecv[q], first[q], shift[q], lst[q]});
+      ncur += nrecv[0] + nrecv[1];
+    } else overflow = true;
+  }
+  AHIP_CHECK(hipGetLastError());
+  // one answer for everybody: the largest need, or capacity + 1 at least where somebody overflowed
+  const int worst = agree_max(c, s, overflow ? std::max(need, capacity + 1) : 0);
+  if (worst > 0) { c.swaps.clear(); return std::max(worst, need); }
+  return ncur;
+}
+
+// Comm::exchange.  Arrays x, v [capacity][3], tag, mtype [capacity] hold nlocal owned atoms; positions are wrapped into the periodic box and the atoms that
+// left this brick go to the neighbour brick, dimension by dimension (at most one brick per re-neighboring).  Returns the new number of owned atoms, or -need
+// (for every rank together) when a brick would exceed `capacity`.
+static int comm_migrate(Comm &c, int nlocal, double *x, double *v, long long *tag, int *mtype, int capacity, const double *box, const int *grid,
+                        const int *coord, hipStream_t s) {
+  if (nlocal > 0) hipLaunchKernelGGL(k_wrap, dim3(gridfor(nlocal)), dim3(256), 0, s, nlocal, x, box[0], box[1], box[2]);
+  int n = nlocal, worst_need = 0;
+  bool overflow = false;
+  for (int d = 0; d < 3; ++d) {
+    if (grid[d] == 1) continue;
+    const int nchunk = (n + CH - 1) / CH;
+    int cntv[3] = {0, 0, n};
+    long long *lst[3] = {nullptr, nullptr, nullptr};
+    const MigCut cut{d, grid[d], coord[d], box[d] / grid[d]};
+    if (n > 0 && !overflow) {
+      c.cnt.reserve((size_t)3 * nchunk * sizeof(int)); c.off.reserve(((size_t)3 * nchunk + 1) * sizeof(int));
+      hipLaunchKernelGGL((k_cls_count<MigCut, true>), dim3(gridfor(nchunk)), dim3(256), 0, s, n, x, cut, nchunk, c.cnt.as<int>());
+      AHIP_CHECK(prim_exclusive_scan_i32(c.prim, c.cnt.as<int>(), c.off.as<int>(), 3 * nchunk, s));
+      int tot[3];
+      for (int q = 0; q < 3; ++q) AHIP_CHECK(hipMemcpyAsync(&tot[q], c.off.as<int>() + (q + 1) * nchunk, 4, hipMemcpyDeviceToHost, s));
+      AHIP_CHECK(hipStreamSynchronize(s));
+      cntv[0] = tot[0]; cntv[1] = tot[1] - tot[0]; cntv[2] = tot[2] - tot[1];
+      for (int q = 0; q < 3; ++q) { c.own_idx[q].reserve((size_t)std::max(cntv[q], 1) * sizeof(long long)); lst[q] = c.own_idx[q].as<long long>(); }
+      hipLaunchKernelGGL((k_cls_fill<MigCut, true>), dim3(gridfor(nchunk)), dim3(256), 0, s, n, x, cut, nchunk, c.off.as<int>(), lst[0], lst[1], lst[2]);
+    } else if (overflow) { cntv[0] = cntv[1] = 0; cntv[2] = 0; }
+    int to[2], from[2], nrecv[2];
+    double dummy;
+    for (int q = 0; q < 2; ++q) { const int step = q == 0 ? -1 : +1; to[q] = neighbour(grid, coord, box, d, step, &dummy); from[q] = neighbour(grid, coord, box, d, -step, &dummy); }
+    const int nsend[2] = {cntv[0], cntv[1]};
+    exchange_counts(c, s, nsend, to, from, nrecv);
+    const bool one_peer = to[0] == to[1] && from[0] == from[1] && to[0] == from[0];
+    for (int q = 0; q < 2; ++q) { c.mbuf[0].reserve((size_t)std::max(nsend[0] + nsend[1], 1) * 64); c.mbuf[1].reserve((size_t)std::max(nrecv[0] + nrecv[1], 1) * 64); }
+    double *sb = c.mbuf[0].as<double>(), *rb = c.mbuf[1].as<double>();
+    for (int q = 0; q < 2; ++q)
+      if (nsend[q] > 0) hipLaunchKernelGGL(k_mig_pack, dim3(gridfor(nsend[q])), dim3(256), 0, s, nsend[q], lst[q], x, v, tag, mtype, sb + (q == 1 ? 8 * (size_t)nsend[0] : 0));
+    Xfer X{c, s, {}};
+    if (one_peer) { X.send(sb, 64LL * (nsend[0] + nsend[1]), to[0]); X.recv(rb, 64LL * (nrecv[0] + nrecv[1]), from[0]); }
+    else for (int q = 0; q < 2; ++q) { X.send(sb + (q == 1 ? 8 * (size_t)nsend[0] : 0), 64LL * nsend[q], to[q]); X.recv(rb + (q == 1 ? 8 * (size_t)nrecv[0] : 0), 64LL * nrecv[q], from[q]); }
+    X.run();
+    const int nnew = cntv[2] + nrecv[0] + nrecv[1];
+    worst_need = std::max(worst_need, nnew);
+    if (overflow || nnew > capacity) { overflow = true; continue; }
+    // the rows that stay, in order, then what arrived from below, then from above (md.py's order): through the keep buffers, back into the arrays
+    const int nk = cntv[2];
+    c.keep[0].reserve((size_t)std::max(nk, 1) * 24); c.keep[1].reserve((size_t)std::max(nk, 1) * 24); c.keep[2].reserve((size_t)std::max(nk, 1) * 8); c.keep[3].reserve((size_t)std::max(nk, 1) * 4);
+    if (nk > 0) {
+      hipLaunchKernelGGL(k_mig_keep, dim3(gridfor(nk)), dim3(256), 0, s, nk, lst[2], x, v, tag, mtype, c.keep[0].as<double>(), c.keep[1].as<double>(), c.keep[2].as<long long>(), c.keep[3].as<int>());
+      hipLaunchKernelGGL(k_copy_f64, dim3(gridfor(3LL * nk)), dim3(256), 0, s, 3LL * nk, c.keep[0].as<double>(), x);
+      hipLaunchKernelGGL(k_copy_f64, dim3(gridfor(3LL * nk)), dim3(256), 0, s, 3LL * nk, c.keep[1].as<double>(), v);
+      hipLaunchKernelGGL(k_copy_i64, dim3(gridfor(nk)), dim3(256), 0, s, (long long)nk, c.keep[2].as<long long>(), tag);
+      hipLaunchKernelGGL(k_copy_i32, dim3(gridfor(nk)), dim3(256), 0, s, (long long)nk, c.keep[3].as<int>(), mtype);
+    }
+    if (nrecv[0] + nrecv[1] > 0)
+      hipLaunchKernelGGL(k_mig_unpack, dim3(gridfor(nrecv[0] + nrecv[1])), dim3(256), 0, s, nrecv[0] + nrecv[1], rb, nk, x, v, tag, mtype);
+    n = nnew;
+  }
+  AHIP_CHECK(hipGetLastError());
+  const int worst = agree_max(c, s, overflow ? std::max(worst_need, capacity + 1) : 0);
+  AHIP_CHECK(hipStreamSynchronize(s));
+  return worst > 0 ? -worst : n;
+}
+
 }  // namespace ahip
 
 using namespace ahip;
@@ -305,7 +600,10 @@ extern "C" void ahip_comm_free(ahip_comm *h) {
   Comm *c = (Comm *)h;
   if (!c) return;
   if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
-  for (DevBuf *b : {&c->sendbuf[0], &c->sendbuf[1], &c->recvbuf[0], &c->recvbuf[1]}) b->release();
+  for (DevBuf *b : {&c->sendbuf[0], &c->sendbuf[1], &c->recvbuf[0], &c->recvbuf[1], &c->cnt, &c->off, &c->words, &c->mbuf[0], &c->mbuf[1], &c->keep[0], &c->keep[1], &c->keep[2], &c->keep[3],
+                    &c->own_idx[0], &c->own_idx[1], &c->own_idx[2], &c->own_idx[3], &c->own_idx[4], &c->own_idx[5]})
+    b->release();
+  c->prim.release();
   delete c;
 }
 
@@ -399,6 +697,32 @@ extern "C" int ahip_comm_selftest(ahip_comm *h, int n, void *stream) {
   const double nr = c->nranks;
   ok = ok && red[0] == nr * (nr + 1) / 2 && red[1] == 0.5 * nr && imax == 7 + c->nranks - 1;
   if (!ok) throw StateError("ahip_comm_selftest: a value came back wrong");
+  COMM_CATCH
+}
+
+extern "C" int ahip_comm_borders(ahip_comm *h, int nlocal, double *x_dev, int *mtype_dev, int capacity, const double *lo, const double *hi, const double *box,
+                                 double rc, const int *grid, const int *coord, int *nall, void *stream) {
+  COMM_TRY
+  Comm *c = (Comm *)h;
+  if (!c || nlocal < 0 || capacity < 0 || !lo || !hi || !box || !grid || !coord || !nall || !(rc > 0.0) || (capacity > 0 && (!x_dev || !mtype_dev)))
+    throw ArgError("ahip_comm_borders: bad argument");
+  if (grid[0] * grid[1] * grid[2] != c->nranks) throw ArgError("ahip_comm_borders: the rank grid does not match the communicator");
+  for (int d = 0; d < 3; ++d) {
+    if (grid[d] < 1 || coord[d] < 0 || coord[d] >= grid[d]) throw ArgError("ahip_comm_borders: bad grid / coordinate");
+    if (!(hi[d] - lo[d] >= rc)) throw UnsupportedError("ahip_comm_borders: a brick thinner than the halo needs ghosts from beyond the nearest neighbour brick (one swap per direction only)");
+  }
+  *nall = comm_borders(*c, nlocal, x_dev, mtype_dev, capacity, lo, hi, box, rc, grid, coord, (hipStream_t)stream);
+  COMM_CATCH
+}
+
+extern "C" int ahip_comm_migrate(ahip_comm *h, int nlocal, double *x_dev, double *v_dev, long long *tag_dev, int *mtype_dev, int capacity, const double *box,
+                                 const int *grid, const int *coord, int *nlocal_new, void *stream) {
+  COMM_TRY
+  Comm *c = (Comm *)h;
+  if (!c || nlocal < 0 || capacity < nlocal || !box || !grid || !coord || !nlocal_new || (capacity > 0 && (!x_dev || !v_dev || !tag_dev || !mtype_dev)))
+    throw ArgError("ahip_comm_migrate: bad argument");
+  if (grid[0] * grid[1] * grid[2] != c->nranks) throw ArgError("ahip_comm_migrate: the rank grid does not match the communicator");
+  *nlocal_new = comm_migrate(*c, nlocal, x_dev, v_dev, tag_dev, mtype_dev, capacity, box, grid, coord, (hipStream_t)stream);
   COMM_CATCH
 }
 

@@ -310,16 +310,8 @@ __device__ __forceinline__ void lin(__amdgpu_buffer_rsrc_t W, int &wp, const f32
     Hop b[1][KT / 2], unused[1][NT / 2];
 #pragma unroll
     for (int ks = 0; ks < KT / 2; ++ks) b[0][ks] = split_pair_h(in[2 * ks], in[2 * ks + 1]);
-#ifdef AHIP_H_PKSILU        // A/B: the SiLU epilogue on register pairs (packed f32 operations)
-    if constexpr (std::is_same<Epi, EpiSiluSaveD>::value) {
-      EpiSiluSaveD2 ep[1] = {EpiSiluSaveD2{epi.S, epi.row0, epi.v16}};
-      linear_h<1, KT / 2, NT, ACC, false, (4 * RPI) % RINGH, EpiSiluSaveD2>(W, wp, b, reinterpret_cast<f32x4 (&)[1][NT]>(out), unused, v16, ring.b, ep);
-    } else
-#endif
-    {
-      Epi ep[1] = {epi};
-      linear_h<1, KT / 2, NT, ACC, false, (4 * RPI) % RINGH, Epi>(W, wp, b, reinterpret_cast<f32x4 (&)[1][NT]>(out), unused, v16, ring.b, ep);
-    }
+    Epi ep[1] = {epi};
+    linear_h<1, KT / 2, NT, ACC, false, (4 * RPI) % RINGH, Epi>(W, wp, b, reinterpret_cast<f32x4 (&)[1][NT]>(out), unused, v16, ring.b, ep);
   } else if constexpr (AR != 0) {
     static_assert(KT % 2 == 0, "K-steps are pairs of 16-feature tiles");
     constexpr int NTERM = AR == 1 ? 3 : 2;

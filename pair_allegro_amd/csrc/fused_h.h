@@ -63,32 +63,7 @@ __device__ __forceinline__ void ring_prime_h(__amdgpu_buffer_rsrc_t W, int wp, i
 // Epilogue functors may process the two values of a register pair at once (apply2: packed f32 VALU operations); the others go value by value.
 template <class E> __device__ __forceinline__ auto epi_apply2(E &e, int ot, int r, f32x2 v, int) -> decltype(e.apply2(ot, r, v)) { return e.apply2(ot, r, v); }
 template <class E> __device__ __forceinline__ f32x2 epi_apply2(E &e, int ot, int r, f32x2 v, long) { return f32x2{e.apply(ot, r, v[0]), e.apply(ot, r + 1, v[1])}; }
-// out = silu(z) and the saved rows silu'(z) as EpiSiluSaveD, on register pairs: five packed operations and four transcendentals per two values instead of
-// seven plain operations per value (the f16x2 linears are VALU-bound: their MFMAs take a fifth of the f32-input form's time)
-struct EpiSiluSaveD2 {
-  static constexpr bool STORES = false;
-  __amdgpu_buffer_rsrc_t S; int row0, v16;
-  f32x4 d[2];
-  __device__ __forceinline__ void tile_done(int, const f32x4 &) const {}
-  __device__ __forceinline__ f32x2 apply2(int ot, int r, f32x2 z) {
-    const f32x2 t = z * -1.4426950408889634f;
-    const f32x2 o = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.f;
-    const f32x2 sg = {__builtin_amdgcn_rcpf(o[0]), __builtin_amdgcn_rcpf(o[1])};
-    const f32x2 y = z * sg;
-    const f32x2 dd = y * (1.f - sg) + sg;
-    d[ot & 1][r] = dd[0]; d[ot & 1][r + 1] = dd[1];
-    return y;
-  }
-  __device__ __forceinline__ float apply(int ot, int r, float z) {
-    const float sg = sigmoidf_fast(z), y = z * sg;
-    d[ot & 1][r] = fmaf(y, 1.f - sg, sg);
-    return y;
-  }
-  __device__ __forceinline__ void flush(int ot0) const {
-    bstore(S, v16, (row0 + ot0) * ROW * 4, d[0]);
-    bstore(S, v16, (row0 + ot0 + 1) * ROW * 4, d[1]);
-  }
-};
+// (a packed-f32 SiLU epilogue, EpiSiluSaveD2, was measured equal to the scalar one in round 5 -- 47.6 vs 47.7 ms -- and is gone)
 
 // Streamed linear, f16x2.  in[g][ks]: KS K-steps (pairs of 16-feature tiles, split) per group; out[g][t]: NT f32 tiles through the epilogue functors of
 // fused_common.h (one functor per group); SPLIT additionally emits the outputs as the next linear's B operands.  Fragments per (tile pair p, K-step):
@@ -129,15 +104,9 @@ __device__ __forceinline__ void linear_h(__amdgpu_buffer_rsrc_t W, int &wp, cons
       for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-#ifdef AHIP_H_ORDER          // A/B: cross / main / cross, so that the two MFMAs on one cross accumulator are 4 G instead of 2 G issues apart
-          if (m == 0) ac[g][hh] = mfma_h(a[2 + hh], in[g][ks].hi, ac[g][hh]);
-          else if (m == 2) ac[g][hh] = mfma_h(a[hh], in[g][ks].lo, ac[g][hh]);
-          else ah[g][hh] = mfma_h(a[hh], in[g][ks].hi, ah[g][hh]);
-#else
           if (m == 0) ac[g][hh] = mfma_h(a[2 + hh], in[g][ks].hi, ac[g][hh]);
           else if (m == 1) ac[g][hh] = mfma_h(a[hh], in[g][ks].lo, ac[g][hh]);
           else ah[g][hh] = mfma_h(a[hh], in[g][ks].hi, ah[g][hh]);
-#endif
           if (p > 0) {
             // the 4 G register pairs of the previous tile pair, spread over this pair's MFMAs
             const int idx = ks * MF + (m * 2 + hh) * G + g, tot = KS * MF, NE = 4 * G;

@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(256) k_latent_update_bwd_rows(long long E, int
 __global__ void __launch_bounds__(256) k_embed_bwd_Y_rows(long long E, int D, int U, const float *dV, const float *w, float *dY) {
   const int lane = threadIdx.x & 63;
   const long long nw = (long long)gridDim.x * 4;
-  const int nl = (D == 1) ? 1 : (D == 4 ? 2 : 3);
+  const int nl = D == 1 ? 1 : (D == 4 ? 2 : (D == 9 ? 3 : 4));
   for (long long e = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); e < E; e += nw) {
     for (int lm = 0; lm < D; ++lm) {
       const int l = lm == 0 ? 0 : (lm < 4 ? 1 : 2);
@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256) k_env_bwd_Y_rows(long long E, int D, int 
                                                          const float *om, float *dY) {
   const int lane = threadIdx.x & 63;
   const long long nw = (long long)gridDim.x * 4;
-  const int nl = (D == 1) ? 1 : (D == 4 ? 2 : 3);
+  const int nl = D == 1 ? 1 : (D == 4 ? 2 : (D == 9 ? 3 : 4));
   for (long long e = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); e < E; e += nw) {
     const float *de = denv + (long long)(e_ii[e] - c0) * D * U;
     for (int lm = 0; lm < D; ++lm) {

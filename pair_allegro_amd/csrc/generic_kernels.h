@@ -1,7 +1,7 @@
 // Generic (layer-at-a-time) HIP kernels of the Allegro model: forward and hand-derived backward.
 //
 // These are the correctness-first kernels: one thread per output element, activations in HBM,
-// no LDS, no cross-lane traffic.  They run any model shape (any l_max <= 2, any widths, any
+// no LDS, no cross-lane traffic.  They run any model shape (any l_max <= 3, any widths, any
 // number of edges per atom) in float32 or float64 and are the on-device cross-check of the fused
 // MFMA kernel (fused_kernels.h).  The arithmetic is the model spec of DESIGN.md; the reference
 // executes the same graph inside libtorch (/root/reference/pair_nequip_allegro.cpp:409-430).
@@ -24,7 +24,8 @@ template <typename T> __device__ inline T silu_df(T z) {
 }
 
 // l of a flattened (l,m) index, l <= 2
-__device__ inline int l_of_lm(int lm) { return lm == 0 ? 0 : (lm < 4 ? 1 : 2); }
+__device__ inline int l_of_lm(int lm) { return lm == 0 ? 0 : (lm < 4 ? 1 : (lm < 9 ? 2 : 3)); }
+__device__ inline int nl_of_D(int D) { return D == 1 ? 1 : (D == 4 ? 2 : (D == 9 ? 3 : 4)); }      // l_max + 1 from (l_max + 1)^2
 
 // ---------------------------------------------------------------------------- edge build
 // Pass 1 of preprocess() (pair_nequip_allegro.cpp:488-512): count neighbours within the
@@ -93,6 +94,17 @@ template <typename T> __device__ inline void sh_eval(int L, T nx, T ny, T nz, T 
     Y[7] = s15 * nx * nz;
     Y[8] = T(0.5) * s15 * (nx * nx - ny * ny);
   }
+  if (L >= 3) {            // homogeneous cubics of pair_allegro_amd/cg.py: real_sh (the layer-at-a-time kernels only: no fused kernel has l_max = 3)
+    const T c70 = T(2.091650066335189), c105 = T(10.246950765959598), c42 = T(1.620185174601965), c7 = T(1.3228756555322954);
+    const T x2 = nx * nx, y2 = ny * ny, z2 = nz * nz;
+    Y[9] = c70 * ny * (T(3) * x2 - y2);
+    Y[10] = c105 * nx * ny * nz;
+    Y[11] = c42 * ny * (T(4) * z2 - x2 - y2);
+    Y[12] = c7 * nz * (T(2) * z2 - T(3) * x2 - T(3) * y2);
+    Y[13] = c42 * nx * (T(4) * z2 - x2 - y2);
+    Y[14] = T(0.5) * c105 * nz * (x2 - y2);
+    Y[15] = c70 * nx * (x2 - T(3) * y2);
+  }
 }
 
 // G = sum_lm dY[lm] * grad_n Y_lm(n)  (homogeneous-polynomial gradients)
@@ -109,6 +121,17 @@ template <typename T> __device__ inline void sh_grad_dot(int L, T nx, T ny, T nz
     gx += -T(2) * s5h * nx * dY[6]; gy += -T(2) * s5h * ny * dY[6]; gz += T(4) * s5h * nz * dY[6];
     gx += s15 * nz * dY[7]; gz += s15 * nx * dY[7];
     gx += s15 * nx * dY[8]; gy += -s15 * ny * dY[8];
+  }
+  if (L >= 3) {
+    const T c70 = T(2.091650066335189), c105 = T(10.246950765959598), c42 = T(1.620185174601965), c7 = T(1.3228756555322954);
+    const T x2 = nx * nx, y2 = ny * ny, z2 = nz * nz, xy = nx * ny, xz = nx * nz, yz = ny * nz;
+    gx += c70 * T(6) * xy * dY[9];                  gy += c70 * (T(3) * x2 - T(3) * y2) * dY[9];
+    gx += c105 * yz * dY[10];                       gy += c105 * xz * dY[10];                        gz += c105 * xy * dY[10];
+    gx += -c42 * T(2) * xy * dY[11];                gy += c42 * (T(4) * z2 - x2 - T(3) * y2) * dY[11]; gz += c42 * T(8) * yz * dY[11];
+    gx += -c7 * T(6) * xz * dY[12];                 gy += -c7 * T(6) * yz * dY[12];                  gz += c7 * (T(6) * z2 - T(3) * x2 - T(3) * y2) * dY[12];
+    gx += c42 * (T(4) * z2 - T(3) * x2 - y2) * dY[13]; gy += -c42 * T(2) * xy * dY[13];              gz += c42 * T(8) * xz * dY[13];
+    gx += c105 * xz * dY[14];                       gy += -c105 * yz * dY[14];                       gz += T(0.5) * c105 * (x2 - y2) * dY[14];
+    gx += c70 * (T(3) * x2 - T(3) * y2) * dY[15];   gy += -c70 * T(6) * xy * dY[15];
   }
   G[0] = gx; G[1] = gy; G[2] = gz;
 }
@@ -140,7 +163,7 @@ __global__ void k_geom_fwd(long long E, GeomParams gp, const T *rvec, const int 
   T f, df;
   cutoff_eval<T>(gp.p, xx, f, df);
   fc[e] = f;
-  T Yl[9];
+  T Yl[16];
   sh_eval<T>(gp.L, rx * inv, ry * inv, rz * inv, Yl);
   for (int k = 0; k < gp.D; ++k) Y[e * gp.D + k] = Yl[k];
   const int Ka = 2 * gp.Tn + gp.B;
@@ -275,14 +298,14 @@ __global__ void k_embed(long long E, int D, int U, const T *w, const T *Y, T *V)
   long long e = t / (D * U);
   int r = (int)(t - e * (long long)D * U);
   int lm = r / U, u = r - lm * U;
-  int nl = (D == 1) ? 1 : (D == 4 ? 2 : 3);
+  int nl = nl_of_D(D);
   V[t] = w[e * nl * U + l_of_lm(lm) * U + u] * Y[e * D + lm];
 }
 // dw[e][l][u] = sum_{m in l} dV[e][lm][u] Y[e][lm]
 template <typename T>
 __global__ void k_embed_bwd_w(long long E, int D, int U, const T *dV, const T *Y, T *dw) {
   long long t = AHIP_GID();
-  int nl = (D == 1) ? 1 : (D == 4 ? 2 : 3);
+  int nl = nl_of_D(D);
   if (t >= E * nl * U) return;
   long long e = t / (nl * U);
   int r = (int)(t - e * (long long)nl * U);
@@ -298,7 +321,7 @@ __global__ void k_embed_bwd_Y(long long E, int D, int U, const T *dV, const T *w
   if (t >= E * D) return;
   long long e = t / D;
   int lm = (int)(t - e * D);
-  int nl = (D == 1) ? 1 : (D == 4 ? 2 : 3);
+  int nl = nl_of_D(D);
   const T *wr = w + e * nl * U + l_of_lm(lm) * U;
   const T *dv = dV + (e * D + lm) * U;
   T acc = 0;
@@ -315,7 +338,7 @@ __global__ void k_env_reduce(int nc, int c0, const int *eoff, long long e0, int 
   int c = (int)(t / (D * U));
   int r = (int)(t - (long long)c * D * U);
   int lm = r / U, u = r - lm * U;
-  int nl = (D == 1) ? 1 : (D == 4 ? 2 : 3);
+  int nl = nl_of_D(D);
   int l = l_of_lm(lm);
   T acc = 0;
   for (long long e = eoff[c0 + c] - e0; e < eoff[c0 + c + 1] - e0; ++e) acc += om[e * nl * U + l * U + u] * Y[e * D + lm];
@@ -345,7 +368,7 @@ __global__ void k_tp_fwd(long long E, int D, int Dout, int U, const AhipCgEntry 
   int u = (int)(t - e * U);
   const T *v = V + e * D * U + u;
   const T *en = env + (long long)(e_ii[e] - c0) * D * U + u;
-  T out[9];
+  T out[16];
   for (int k = 0; k < Dout; ++k) out[k] = 0;
   for (int q = 0; q < ncg; ++q) {
     AhipCgEntry c = cg[q];
@@ -364,7 +387,7 @@ __global__ void k_tp_bwd(long long E, int D, int Dout, int U, const AhipCgEntry 
   int u = (int)(t - e * U);
   const T *v = V + e * D * U + u;
   const T *en = env + (long long)(e_ii[e] - c0) * D * U + u;
-  T a[9], b[9];
+  T a[16], b[16];
   for (int k = 0; k < D; ++k) { a[k] = 0; b[k] = 0; }
   for (int q = 0; q < ncg; ++q) {
     AhipCgEntry c = cg[q];
@@ -379,7 +402,7 @@ __global__ void k_tp_bwd(long long E, int D, int Dout, int U, const AhipCgEntry 
 template <typename T>
 __global__ void k_env_bwd_om(long long E, int D, int U, const T *denv, const int *e_ii, int c0, const T *Y, T *dom) {
   long long t = AHIP_GID();
-  int nl = (D == 1) ? 1 : (D == 4 ? 2 : 3);
+  int nl = nl_of_D(D);
   if (t >= E * nl * U) return;
   long long e = t / (nl * U);
   int r = (int)(t - e * (long long)nl * U);
@@ -395,7 +418,7 @@ __global__ void k_env_bwd_Y(long long E, int D, int U, const T *denv, const int 
   if (t >= E * D) return;
   long long e = t / D;
   int lm = (int)(t - e * D);
-  int nl = (D == 1) ? 1 : (D == 4 ? 2 : 3);
+  int nl = nl_of_D(D);
   const T *de = denv + (long long)(e_ii[e] - c0) * D * U + lm * U;
   const T *o = om + e * nl * U + l_of_lm(lm) * U;
   T acc = 0;

@@ -287,7 +287,7 @@ class Simulation:
         return capi.Comm(model.L, self.rank, self.nranks, xfer=self._hosted_xfer)
 
     def _set_comm_plan(self) -> None:
-        if self.comm is None:
+        if self.comm is None or getattr(self, "_lib_plan", False):      # (ahip_comm_borders has installed its own plan)
             return
         # the single-rank plan (image chains resolved locally) only on ONE rank: with several ranks a brick that received no ghosts may still
         # have slabs to send (a cluster or slab next to an empty neighbour brick) and its peer posts the matching receive
@@ -360,7 +360,47 @@ class Simulation:
         return int(r.item())
 
     # ---- re-neighboring: wrap, migrate, borders, neighbor build -----------------------------------
+    def _lib_reneighbor(self) -> bool:
+        """Several ranks with the library's communicator: Comm::exchange / Comm::borders run inside the library (csrc/comm.hip, round 6) instead of the torch swap
+        chain below.  AHIP_LIB_BORDERS=0 keeps the torch path (A/B, and the reference the tests compare the library path with)."""
+        return (self.nranks > 1 and self.comm is not None and hasattr(self.comm, "borders") and hasattr(self.comm.L.lib, "ahip_comm_borders")
+                and os.environ.get("AHIP_LIB_BORDERS", "1") != "0")
+
+    def _migrate_lib(self) -> None:
+        n = self.nlocal
+        cap = n + max(4096, n // 4)
+        x = torch.empty((cap, 3), dtype=torch.float64, device=self.dev); x[:n] = self.x[:n]
+        v = torch.empty((cap, 3), dtype=torch.float64, device=self.dev); v[:n] = self.v[:n]
+        tag = torch.empty(cap, dtype=torch.int64, device=self.dev); tag[:n] = self.tag[:n]
+        mt = torch.empty(cap, dtype=torch.int32, device=self.dev); mt[:n] = self.mtype[:n]
+        nn = self.comm.migrate(n, x.data_ptr(), v.data_ptr(), tag.data_ptr(), mt.data_ptr(), cap, self.box, self.grid, self.coord, self._stream())
+        if nn < 0:
+            raise RuntimeError(f"migration: a brick would hold {-nn} atoms, more than the {cap} rows provided (rank {self.rank})")
+        self.nlocal = nn
+        self.x, self.v, self.tag, self.mtype = x[:nn], v[:nn], tag[:nn], mt[:nn]
+
+    def _borders_lib(self) -> None:
+        nl = self.nlocal
+        brick = np.maximum(np.asarray(self.hi) - np.asarray(self.lo), 1e-9)
+        est = int(nl * (np.prod(1.0 + 2.0 * self.rc / brick) - 1.0) * 1.3) + 2048
+        cap = nl + max(est, int(1.25 * getattr(self, "_nghost_last", 0)))
+        while True:
+            xa = torch.empty((cap, 3), dtype=torch.float64, device=self.dev); xa[:nl] = self.x[:nl]
+            mta = torch.empty(cap, dtype=torch.int32, device=self.dev); mta[:nl] = self.mtype[:nl]
+            nall = self.comm.borders(nl, xa.data_ptr(), mta.data_ptr(), cap, self.lo, self.hi, self.box, self.rc, self.grid, self.coord, self._stream())
+            if nall <= cap:
+                break
+            cap = int(1.1 * nall) + 1024
+        self._nghost_last = nall - nl
+        self.swaps = []
+        self._lib_plan = True
+        self.x, self.mtype = xa[:nall], mta[:nall]
+        self.nall = nall
+        self._ghost_src = self._ghost_shift = None
+
     def _migrate(self) -> None:
+        if self._lib_reneighbor():
+            return self._migrate_lib()
         n = self.nlocal
         x, v, tag, mt = self.x[:n], self.v[:n], self.tag[:n], self.mtype[:n]
         if getattr(self, "_box_t", None) is None:
@@ -420,8 +460,11 @@ class Simulation:
         return True
 
     def _borders(self) -> None:
+        self._lib_plan = False
         if self._borders_local():
             return
+        if self._lib_reneighbor():
+            return self._borders_lib()
         self.swaps = []
         x, mt = self.x, self.mtype
         for d in range(3):

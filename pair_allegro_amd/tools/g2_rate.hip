@@ -6,6 +6,36 @@
 // 3. rates: cycles per 64x64 linear with the SiLU + save + split epilogue, one and two groups per fragment, one and two waves per SIMD
 #include "../csrc/fused.hip"
 #include "../csrc/fused_h.h"
+namespace ahip {
+// (micro-benchmark only: the packed-f32 SiLU epilogue measured in round 5; the kernels use the scalar one)
+// out = silu(z) and the saved rows silu'(z) as EpiSiluSaveD, on register pairs: five packed operations and four transcendentals per two values instead of
+// seven plain operations per value (the f16x2 linears are VALU-bound: their MFMAs take a fifth of the f32-input form's time)
+struct EpiSiluSaveD2 {
+  static constexpr bool STORES = false;
+  __amdgpu_buffer_rsrc_t S; int row0, v16;
+  f32x4 d[2];
+  __device__ __forceinline__ void tile_done(int, const f32x4 &) const {}
+  __device__ __forceinline__ f32x2 apply2(int ot, int r, f32x2 z) {
+    const f32x2 t = z * -1.4426950408889634f;
+    const f32x2 o = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.f;
+    const f32x2 sg = {__builtin_amdgcn_rcpf(o[0]), __builtin_amdgcn_rcpf(o[1])};
+    const f32x2 y = z * sg;
+    const f32x2 dd = y * (1.f - sg) + sg;
+    d[ot & 1][r] = dd[0]; d[ot & 1][r + 1] = dd[1];
+    return y;
+  }
+  __device__ __forceinline__ float apply(int ot, int r, float z) {
+    const float sg = sigmoidf_fast(z), y = z * sg;
+    d[ot & 1][r] = fmaf(y, 1.f - sg, sg);
+    return y;
+  }
+  __device__ __forceinline__ void flush(int ot0) const {
+    bstore(S, v16, (row0 + ot0) * ROW * 4, d[0]);
+    bstore(S, v16, (row0 + ot0 + 1) * ROW * 4, d[1]);
+  }
+};
+
+}  // namespace ahip
 
 using namespace ahip;
 

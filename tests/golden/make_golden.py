@@ -92,7 +92,19 @@ def run_case(name, cell, pos, symbols, model_types, r_max, cfg_over, tag):
     print(f"{tag}: N={n} E={inp['edge_index'].shape[1]} pe={eng:.6f} |F|max={np.abs(forces).max():.4f} -> {out}")
 
 
+def main_l3():
+    """Round 6: l_max = 3 and widths off every fused shape (free hyper-parameters of /root/reference/tests/test_data/test_repro_allegro.yaml:89-99): the
+    layer-at-a-time kernels.  Two of the reference's geometries: the 7-atom triclinic Cu2AgO4 cell (3 types) and the 4-atom Cu cell at 5 A."""
+    odd = dict(l_max=3, num_layers=2, num_scalar_features=48, num_tensor_features=16, mlp_width=40, readout_width=24)
+    for fname, model_types, r_max in (("Cu2AgO4.xyz", ["Cu", "Ag", "O"], 5.0), ("Cu-cubic.xyz", ["Cu"], 5.0)):
+        sym, pos, cell, periodic = read_first_frame(os.path.join(REF, fname))
+        cell, pos = prepare(sym, pos, cell, periodic)
+        run_case(fname, cell, pos, sym, model_types, r_max, odd, f"{fname.split('.')[0]}_r{int(r_max)}_l3")
+
+
 def main():
+    if "--l3" in sys.argv:          # only the round-6 additions (the older vectors stay byte for byte)
+        return main_l3()
     yaml_model = dict(l_max=2, num_layers=3, num_scalar_features=64, num_tensor_features=32)
     for fname, model_types, r_max in CASES:
         sym, pos, cell, periodic = read_first_frame(os.path.join(REF, fname))

@@ -26,6 +26,8 @@ def run(lib, path, cell, pos, vel, cfg, grid, rank, d, nsteps, skin=1.0, toggle=
     e = sim.thermo([28.0855])["pe"]
     nreb = sim.nrebuild
     nloc = sim.nlocal
+    run.lib_plan = bool(getattr(sim, "_lib_plan", False))          # the last re-neighboring went through ahip_comm_migrate / ahip_comm_borders
+    run.ghosts = (sim.x[sim.nlocal: sim.nall].clone().numpy(), sim.mtype[sim.nlocal: sim.nall].clone().numpy(), sim.tag[: sim.nlocal].clone().numpy())
     model.close()
     return f, x.numpy(), e, nreb, nloc
 
@@ -57,6 +59,20 @@ def main():
     f2, x2, e2, nreb, nloc = run(lib, path, cell, pos, vel, cfg, grid, rank, dist, nsteps, skin, toggle)
     nl = torch.tensor([nloc]); dist.all_reduce(nl)
     assert int(nl.item()) == len(pos), "atoms lost or duplicated in migration"
+    lib_plan = run.lib_plan
+    want_lib = os.environ.get("AHIP_LIB_BORDERS", "1") != "0" and world > 1
+    assert lib_plan == want_lib, f"re-neighboring path: library={lib_plan}, expected {want_lib}"
+    if os.environ.get("AHIP_TEST_COMPARE_BORDERS") == "1":
+        # the same run once more with the torch swap chain (md.py: _migrate / _borders): every rank must end with the same owned atoms in the same order and
+        # the same ghost rows -- positions bit for bit, types, ORDER included (both build their send lists in ascending row order)
+        g_lib = run.ghosts
+        os.environ["AHIP_LIB_BORDERS"] = "0"
+        run(lib, path, cell, pos, vel, cfg, grid, rank, dist, nsteps, skin, toggle)
+        os.environ["AHIP_LIB_BORDERS"] = "1"
+        g_ref = run.ghosts
+        assert not run.lib_plan
+        assert g_lib[0].shape == g_ref[0].shape and np.array_equal(g_lib[2], g_ref[2]), (rank, g_lib[0].shape, g_ref[0].shape)
+        assert np.array_equal(g_lib[0], g_ref[0]) and np.array_equal(g_lib[1], g_ref[1]), f"rank {rank}: ghost rows differ"
     if rank == 0:
         f1, x1, e1, nreb1, _ = run(lib, path, cell, pos, vel, cfg, (1, 1, 1), 0, None, nsteps, skin)
         box = np.diag(cell)

@@ -9,8 +9,8 @@ def test_sh_component_normalisation():
     rng = np.random.default_rng(0)
     n = rng.normal(size=(200, 3))
     n /= np.linalg.norm(n, axis=1, keepdims=True)
-    Y = cg.real_sh(n, 2)
-    for l in range(3):
+    Y = cg.real_sh(n, 3)
+    for l in range(4):
         np.testing.assert_allclose((Y[:, l * l:(l + 1) ** 2] ** 2).sum(1), 2 * l + 1, rtol=1e-12)
 
 
@@ -27,7 +27,7 @@ def _complex_to_real(l):
     return M
 
 
-@pytest.mark.parametrize("path", cg.tp_paths(2))
+@pytest.mark.parametrize("path", cg.tp_paths(3))
 def test_w3j_matches_sympy_up_to_sign(path):
     from sympy.physics.wigner import wigner_3j
     l1, l2, l3 = path
@@ -48,9 +48,9 @@ def test_tensor_product_is_equivariant():
     rng = np.random.default_rng(3)
     a, b, c = (v / np.linalg.norm(v) for v in rng.normal(size=(3, 3)))
     R = cg._random_rotation(rng)
-    for (l1, l2, l3) in cg.tp_paths(2):
+    for (l1, l2, l3) in cg.tp_paths(3):
         C = cg.path_coeff(l1, l2, l3)
-        s = lambda v, l: cg.real_sh(v[None], 2)[0, l * l:(l + 1) ** 2]
+        s = lambda v, l: cg.real_sh(v[None], 3)[0, l * l:(l + 1) ** 2]
         inv = np.einsum("abc,a,b,c->", C, s(a, l1), s(b, l2), s(c, l3))
         inv_r = np.einsum("abc,a,b,c->", C, s(R @ a, l1), s(R @ b, l2), s(R @ c, l3))
         assert abs(inv - inv_r) < 1e-12
@@ -60,7 +60,7 @@ def test_generated_header_is_current():
     import os
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     txt = open(os.path.join(here, "pair_allegro_amd", "csrc", "cg_tables.h")).read()
-    for lmax in (1, 2):
+    for lmax in (1, 2, 3):
         ent = cg.sparse_path_entries(lmax)
         assert f"#define AHIP_CG_L{lmax}_N {len(ent)}" in txt
         for (p, i1, i2, i3, c) in ent[:5] + ent[-5:]:

@@ -51,3 +51,14 @@ def test_model_L_shape_config5(hip_lib, model_dir):
     assert res["info"]["path"] == "generic_f32"
     util.assert_close_to(res, ref, 5e-4, what="model L generic f32 vs f64 oracle")
     assert np.abs(res["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
+
+
+def test_l_max_3_and_off_shape_widths_load_and_run(hip_lib, model_dir):
+    """l_max and the widths are free hyper-parameters of /root/reference/tests/test_data/test_repro_allegro.yaml:89-99 and the reference executes
+    any archive (/root/reference/pair_nequip_allegro.cpp:222,425).  A model outside every fused shape -- l_max = 3, 48 scalars, 16 tensor features, MLP width 40 --
+    loads and is evaluated by the layer-at-a-time kernels under the DEFAULT options (path=auto), float32 to the reference's tolerance and float64 to 1e-8."""
+    for tag in ("Cu2AgO4_r5_l3", "Cu-cubic_r5_l3"):
+        res, g = pc.check_golden(hip_lib, model_dir, tag, "float32")
+        assert res["info"]["path"] == "generic_f32" and int(g["cfg"]["l_max"]) == 3
+        res, g = pc.check_golden(hip_lib, model_dir, tag, "float64")
+        assert res["info"]["path"] == "generic_f64"

@@ -46,10 +46,11 @@ def test_single_rank_forces_and_energy_conservation(emu_lib, model_dir):
     model.close()
 
 
-def _run_workers(emu_lib, model_dir, tmp_path, world, port, extra=()):
+def _run_workers(emu_lib, model_dir, tmp_path, world, port, extra=(), env_extra=None):
     out = tmp_path / f"mr{world}.npz"
     worker = os.path.join(ROOT, "tests", "md_worker.py")
     env = dict(os.environ, PYTHONPATH=ROOT + ":" + os.path.join(ROOT, "tests"), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    env.update(env_extra or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), worker, str(out), emu_lib.path, model_dir] + [str(e) for e in extra]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
@@ -75,6 +76,26 @@ def test_gloo_rebuild_and_migration(emu_lib, model_dir, tmp_path):
     assert int(z["nreb"]) >= 3 and int(z["nreb1"]) >= 3
     np.testing.assert_allclose(z["x2"], z["x1"], atol=1e-8)
     np.testing.assert_allclose(z["e2"], z["e1"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("world,port", [(2, 29751), (4, 29753), (8, 29755)])
+def test_gloo_library_borders_equal_the_swap_chain(emu_lib, model_dir, tmp_path, world, port):
+    """at several ranks a re-neighboring is library kernels + the communicator's transport (ahip_comm_migrate, ahip_comm_borders: csrc/comm.hip),
+    not six rounds of torch mask / nonzero / cat.  Hot system, small skin, 12 steps on 2 / 4 / 8 bricks (migrations included): after the last re-neighboring
+    every rank holds the same owned atoms in the same order and the same ghost rows -- bit for bit, order included -- as the torch swap chain
+    (AHIP_LIB_BORDERS=0, what LAMMPS' Comm::exchange / Comm::borders do for the reference, /root/reference/pair_nequip_allegro.cpp:366-368), and the
+    trajectory equals the single-rank run."""
+    z = _run_workers(emu_lib, model_dir, tmp_path, world, port, extra=(4000.0, 12, 0.3), env_extra={"AHIP_TEST_COMPARE_BORDERS": "1"})
+    assert int(z["nreb"]) >= 2
+    np.testing.assert_allclose(z["x2"], z["x1"], atol=1e-8)
+    np.testing.assert_allclose(z["e2"], z["e1"], rtol=1e-9)
+
+
+def test_gloo_torch_swap_chain_still_works(emu_lib, model_dir, tmp_path):
+    """the torch re-neighboring path (AHIP_LIB_BORDERS=0; also what a backend without the library communicator runs): migration test on 2x2x1 bricks"""
+    z = _run_workers(emu_lib, model_dir, tmp_path, 4, 29757, extra=(6000.0, 20, 0.2), env_extra={"AHIP_LIB_BORDERS": "0"})
+    assert int(z["nreb"]) >= 2
+    np.testing.assert_allclose(z["x2"], z["x1"], atol=1e-8)
 
 
 def test_gloo_switching_the_exchange_schedule_keeps_the_trajectory(emu_lib, model_dir, tmp_path):

@@ -11,7 +11,8 @@ from pair_allegro_amd.pair import PairAllegro, atom_from_rank_system, list_from_
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDEN_TAGS = ["Si64_r5", "Cu-cubic_r5", "Cu-cubic_r15", "Cu2AgO4_r5", "aspirin_r5", "aspirin_r15", "CuPd-cubic-big_r5",
-               "Li3PO4_128_r5", "water_192_r5"]        # the last two: samples of the BASELINE config 3 / 5 workloads (model S / model L)
+               "Li3PO4_128_r5", "water_192_r5",        # these two: samples of the BASELINE config 3 / 5 workloads (model S / model L)
+               "Cu2AgO4_r5_l3", "Cu-cubic_r5_l3"]      # round 6: l_max = 3, widths off every fused shape (S 48, U 16, MLP 40, read-out 24): layer-at-a-time kernels
 
 _model_cache = {}
 

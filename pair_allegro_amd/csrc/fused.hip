@@ -108,7 +108,7 @@ struct FusedArgs {
 
 template <int NW, int NL = MAXNL> struct __attribute__((aligned(16))) Lds {
   static constexpr int SLOTS = 16 * NW;
-  static constexpr int MAXA = NW == 2 ? 3 : NW == 4 ? 6 : 12;   // centre atoms per tile (LDS budget)
+  static constexpr int MAXA = NW == 4 ? 6 : 12;   // centre atoms per tile (LDS budget)
   float stage[SLOTS * STG_LD];
   float env[NL][MAXA * ENV_LD];
   float denv[MAXA * ENV_LD];
@@ -323,6 +323,22 @@ __device__ __forceinline__ void lin(__amdgpu_buffer_rsrc_t W, int &wp, const f32
   } else {
     linear_s<KT, NT, ACC, (4 * RPI) % RING, Epi>(W, wp, in, out, v16, ring.f, epi);
   }
+}
+
+// The three m components of an l = 1 row share ONE channel-mixing matrix: on the f16x2 arithmetic they go through the linear as three GROUPS that share every weight
+// fragment (linear_h<3, ...>: one fragment load, three B operands, three accumulator sets) instead of three passes over three copies of the matrix in the stream:
+// 8 KiB of fragments fewer per mixing block and direction and wave-tile.
+template <int RPI, class Epi>
+__device__ __forceinline__ void lin_m3(__amdgpu_buffer_rsrc_t W, int &wp, const f32x4 (&in0)[2], const f32x4 (&in1)[2], const f32x4 (&in2)[2], f32x4 (&out)[3][2], int v16,
+                                       RingT<3> &ring, Epi (&epi)[3]) {
+  if (!ring.act) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { out[q][0] = f32x4{0.f, 0.f, 0.f, 0.f}; out[q][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    return;
+  }
+  Hop b[3][1], unused[3][1];
+  b[0][0] = split_pair_h(in0[0], in0[1]); b[1][0] = split_pair_h(in1[0], in1[1]); b[2][0] = split_pair_h(in2[0], in2[1]);
+  linear_h<3, 1, 2, false, false, (4 * RPI) % RINGH, Epi>(W, wp, b, out, unused, v16, ring.b, epi);
 }
 
 // MD: hidden layers of the latent MLP (allegro_mlp_hidden_layers_depth of /root/reference/tests/test_data/test_repro_allegro.yaml:94; 2 there).  1 and 3 exist for the
@@ -585,7 +601,20 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
       // channel mixing -> V^{kk+1}: saved in the next layer's VIN rows and parked in LDS
       if (!last) {
         f32x4 o2[2];
-        if (PARKV && kk + 1 == NL - 1) {
+        if constexpr (AR == 3) {
+          // f16x2: the l = 0 block, then the l = 1 block once for its three components (lin_m3)
+          f32x4 o3[3][2];
+          if (PARKV && kk + 1 == NL - 1) {                 // (the LAST layer's input tensor is not saved: see below)
+            lin<AR, 2, 2, false, 0>(WB, wp, Vp[0], o2, v16t, ring, EpiPark{pk, 0, lane});
+            EpiPark ep[3] = {EpiPark{pk, 2, lane}, EpiPark{pk, 4, lane}, EpiPark{pk, 6, lane}};
+            lin_m3<1>(WB, wp, Vp[1], Vp[2], Vp[3], o3, v16t, ring, ep);
+          } else {
+            lin<AR, 2, 2, false, 0>(WB, wp, Vp[0], o2, v16t, ring, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 0, v16t}, pk, 0, lane});
+            EpiSavePark ep[3] = {EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 2, v16t}, pk, 2, lane}, EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 4, v16t}, pk, 4, lane},
+                                 EpiSavePark{{SB, R_LAYER(kk + 1, MD) + OVIN + 6, v16t}, pk, 6, lane}};
+            lin_m3<1>(WB, wp, Vp[1], Vp[2], Vp[3], o3, v16t, ring, ep);
+          }
+        } else if (PARKV && kk + 1 == NL - 1) {
           // the LAST layer's input tensor is not saved: nothing writes the park between its forward tensor product and its backward one (the last layer has
           // no channel mixing), so the backward pass reads it from there -- 8 row stores and 8 row loads fewer per wave-tile
           lin<AR, 2, 2, false, 0>(WB, wp, Vp[0], o2, v16t, ring, EpiPark{pk, 0, lane});
@@ -793,12 +822,22 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
         in2[0] = park_load(pk, 0, lane); in2[1] = park_load(pk, 1, lane);
         lin<AR, 2, 2, false, 0>(WB, wp, in2, o2, v16t, ring, EpiNone{});
         dVp[0][0] += o2[0]; dVp[0][1] += o2[1];
-        in2[0] = park_load(pk, 2, lane); in2[1] = park_load(pk, 3, lane);
-        lin<AR, 2, 2, false, 1>(WB, wp, in2, dVp[1], v16t, ring, EpiNone{});
-        in2[0] = park_load(pk, 4, lane); in2[1] = park_load(pk, 5, lane);
-        lin<AR, 2, 2, false, 2>(WB, wp, in2, dVp[2], v16t, ring, EpiNone{});
-        in2[0] = park_load(pk, 6, lane); in2[1] = park_load(pk, 7, lane);
-        lin<AR, 2, 2, false, 3>(WB, wp, in2, dVp[3], v16t, ring, EpiNone{});
+        if constexpr (AR == 3) {
+          f32x4 i1[2] = {park_load(pk, 2, lane), park_load(pk, 3, lane)}, i2[2] = {park_load(pk, 4, lane), park_load(pk, 5, lane)},
+                i3[2] = {park_load(pk, 6, lane), park_load(pk, 7, lane)};
+          f32x4 o3[3][2];
+          EpiNone ep[3];
+          lin_m3<1>(WB, wp, i1, i2, i3, o3, v16t, ring, ep);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) { dVp[1 + q][0] = o3[q][0]; dVp[1 + q][1] = o3[q][1]; }
+        } else {
+          in2[0] = park_load(pk, 2, lane); in2[1] = park_load(pk, 3, lane);
+          lin<AR, 2, 2, false, 1>(WB, wp, in2, dVp[1], v16t, ring, EpiNone{});
+          in2[0] = park_load(pk, 4, lane); in2[1] = park_load(pk, 5, lane);
+          lin<AR, 2, 2, false, 2>(WB, wp, in2, dVp[2], v16t, ring, EpiNone{});
+          in2[0] = park_load(pk, 6, lane); in2[1] = park_load(pk, 7, lane);
+          lin<AR, 2, 2, false, 3>(WB, wp, in2, dVp[3], v16t, ring, EpiNone{});
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       PHASE(PH_BMIX);
@@ -1045,10 +1084,6 @@ void fused_launch_f16(int nw, bool prof, int md, int grid, hipStream_t s, const 
 #define AHIP_LAUNCH_NL(NWV, PROFV, NLV, MDV) hipLaunchKernelGGL((k_fused<NWV, PROFV, 3, true, NLV, MDV>), dim3(grid), dim3(NWV * 64), 0, s, A)
 #define AHIP_LAUNCH(NWV, PROFV, MDV) do { if (A.NL == 1) AHIP_LAUNCH_NL(NWV, PROFV, 1, MDV); else if (A.NL == 2) AHIP_LAUNCH_NL(NWV, PROFV, 2, MDV); else AHIP_LAUNCH_NL(NWV, PROFV, 3, MDV); } while (0)
 #define AHIP_LAUNCH_NW(PROFV, MDV) do { if (nw == 4) AHIP_LAUNCH(4, PROFV, MDV); else AHIP_LAUNCH(8, PROFV, MDV); } while (0)
-  if (nw == 2) {          // 32-slot tiles, four workgroups per CU (depth-2 MLP, <= 2 layers: the LDS of four workgroups)
-    if (A.NL == 1) AHIP_LAUNCH_NL(2, false, 1, 2); else AHIP_LAUNCH_NL(2, false, 2, 2);
-    return;
-  }
   if (md == 1) AHIP_LAUNCH_NW(false, 1);
   else if (md == 3) AHIP_LAUNCH_NW(false, 3);
   else if (prof) AHIP_LAUNCH_NW(true, 2);
@@ -1212,7 +1247,7 @@ static void fused_prepare(Model &m) {
     if (k < NL - 1) {
       const double *mx = T_(lk + ".mix");            // [2][32][32]; the l=1 block serves m = -1, 0, 1
       fwd(mx, 32, 32);
-      for (int c = 0; c < 3; ++c) fwd(mx + 1024, 32, 32);
+      for (int c = 0; c < (st.arith == 3 ? 1 : 3); ++c) fwd(mx + 1024, 32, 32);      // f16x2: once, shared by the three components (k_fused: lin_m3)
     }
     fwd(T_(lk + ".lat.w0"), 96, 64);
     for (int hl = 1; hl < MD; ++hl) fwd(T_(lk + ".lat.w" + std::to_string(hl)), 64, 64);
@@ -1232,7 +1267,7 @@ static void fused_prepare(Model &m) {
     if (k < NL - 1) {
       const double *mx = T_(lk + ".mix");
       bwd(mx, 32, 32);
-      for (int c = 0; c < 3; ++c) bwd(mx + 1024, 32, 32);
+      for (int c = 0; c < (st.arith == 3 ? 1 : 3); ++c) bwd(mx + 1024, 32, 32);
     }
     bwd(T_(lk + ".env"), 64, 64);
   }
@@ -1287,10 +1322,10 @@ static void fused_prepare(Model &m) {
   A.wave_scratch = (long long)R_TOTAL(NL, MD) * ROW;
   st.scratch.reserve((size_t)st.ncu * 8 * A.wave_scratch * sizeof(float));
   A.scratch = st.scratch.as<float>();
-  st.partial.reserve((size_t)st.ncu * 4 * 7 * sizeof(double));
+  st.partial.reserve((size_t)st.ncu * 2 * 7 * sizeof(double));
   if (const char *nwe = std::getenv("AHIP_FUSED_NW")) st.force_nw = std::atoi(nwe);
   st.ntiles.reserve(64);
-  st.prof.reserve((64 + 4 * 4 * (size_t)st.ncu) * sizeof(long long));
+  st.prof.reserve((64 + 4 * 2 * (size_t)st.ncu) * sizeof(long long));
   const char *pe = std::getenv("AHIP_FUSED_PROF");
   st.prof_on = pe && pe[0] == '1';
   st.clk_on = std::getenv("AHIP_FUSED_CLK") != nullptr;
@@ -1318,12 +1353,11 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
     if (st.force_nw == 8 || (st.force_nw == 4 && m.last_max_deg <= 64)) nw = st.force_nw;
   } else if (st.force_nw == 8) nw = 8;
   else if (m.max_list_row >= 0 && m.max_list_row <= 64) nw = 4;
-  if (st.force_nw == 2 && st.arith == 3 && st.md == 2 && m.hm.num_layers <= 2) nw = 2;      // EXPERIMENT: the caller vouches for <= 32 edges per centre
   const int *maxdeg_sel = nw == 0 ? m.d_maxdeg : nullptr;
   m.last_fused_arith = st.arith;
   hipStream_t s = a.stream;
   const int inum = m.inum;
-  const int tile_slots = nw == 8 ? 128 : nw == 2 ? 32 : 64, maxa = nw == 8 ? Lds<8>::MAXA : nw == 2 ? Lds<2>::MAXA : Lds<4>::MAXA;      // nw == 0: the packing kernels widen them themselves
+  const int tile_slots = nw == 8 ? 128 : 64, maxa = nw == 8 ? Lds<8>::MAXA : Lds<4>::MAXA;      // nw == 0: the packing kernels widen them themselves
   const int nseg = (inum + SEG - 1) / SEG;
   st.seg_count.reserve((size_t)(nseg + 1) * sizeof(int));
   st.seg_base.reserve((size_t)(nseg + 2) * sizeof(int));
@@ -1371,8 +1405,8 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
   const long long nedges_est = !m.counts_pending ? m.nedges : m.nedges_hint > 0 ? m.nedges_hint : (long long)(0.58 * (double)m.nneigh);
   // persistent workgroups fill every CU; reserve_wgs leaves a few slots free so that the exchange kernels of another stream
   // (ghost pack / unpack, RCCL send / recv) can be scheduled while this kernel runs (md.py, overlapped schedule)
-  const int grid4 = std::max(1, st.ncu * 2 - m.reserve_wgs), grid8 = std::max(1, st.ncu - m.reserve_wgs), grid2 = std::max(1, st.ncu * 4 - m.reserve_wgs);
-  const int grid = nw == 8 ? grid8 : nw == 2 ? grid2 : grid4;     // rows of `partial` that are summed
+  const int grid4 = std::max(1, st.ncu * 2 - m.reserve_wgs), grid8 = std::max(1, st.ncu - m.reserve_wgs);
+  const int grid = nw == 8 ? grid8 : grid4;     // rows of `partial` that are summed
   if (nw == 0) AHIP_CHECK(hipMemsetAsync(st.partial.p, 0, (size_t)grid * 7 * sizeof(double), s));     // the shape that returns at once writes nothing
   {
     StageTimer tm(m, "model_fused", s);
@@ -1385,9 +1419,9 @@ bool fused_run(Model &m, const ComputeArgs &a, std::string *why) {
       AHIP_CHECK(hipMemsetAsync(st.prof.p, 0, (64 + 4 * (size_t)grid) * sizeof(long long), s));
       A.prof = st.prof.as<long long>();
     }
-    for (int shape = 2; shape <= 8; shape *= 2) {
-      if (nw != shape && (nw != 0 || shape == 2)) continue;
-      const int g = shape == 8 ? grid8 : shape == 2 ? grid2 : grid4;
+    for (int shape = 4; shape <= 8; shape += 4) {
+      if (nw != 0 && nw != shape) continue;
+      const int g = shape == 8 ? grid8 : grid4;
       A.wg_scratch = shape * A.wave_scratch;
       // claims of TCHUNK tiles amortise the counter's round trip; with few tiles per workgroup the last claim decides the makespan
       // (10 648 Si atoms: 4 659 tiles on 512 workgroups = 12 instead of 10 tile times with claims of 4)

@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256) k_embed_bwd_Y_rows(long long E, int D, in
   const int nl = D == 1 ? 1 : (D == 4 ? 2 : (D == 9 ? 3 : 4));
   for (long long e = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); e < E; e += nw) {
     for (int lm = 0; lm < D; ++lm) {
-      const int l = lm == 0 ? 0 : (lm < 4 ? 1 : 2);
+      const int l = lm == 0 ? 0 : (lm < 4 ? 1 : (lm < 9 ? 2 : 3));
       float acc = 0.f;
       for (int q = lane; q < U; q += 64) acc += dV[(e * D + lm) * U + q] * w[e * nl * U + l * U + q];
       acc = wave_sum(acc);
@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256) k_env_bwd_Y_rows(long long E, int D, int 
   for (long long e = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); e < E; e += nw) {
     const float *de = denv + (long long)(e_ii[e] - c0) * D * U;
     for (int lm = 0; lm < D; ++lm) {
-      const int l = lm == 0 ? 0 : (lm < 4 ? 1 : 2);
+      const int l = lm == 0 ? 0 : (lm < 4 ? 1 : (lm < 9 ? 2 : 3));
       float acc = 0.f;
       for (int q = lane; q < U; q += 64) acc += de[lm * U + q] * om[e * nl * U + l * U + q];
       acc = wave_sum(acc);

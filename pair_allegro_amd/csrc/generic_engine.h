@@ -103,7 +103,7 @@ static void generic_chunk(Model &m, const ComputeArgs &a, Arena &A, int c0, int 
       if (gemm_f32(s, Ec, N, K, dout, lddout, Wp, N, true, din, lddin, accumulate != 0)) return;
     launch(k_linear_bwd<T>, Ec * K, s, Ec, K, N, dout, lddout, Wp, din, lddin, accumulate);
   };
-  auto lofl = [](int lm) { return lm == 0 ? 0 : (lm < 4 ? 1 : 2); };
+  auto lofl = [](int lm) { return lm == 0 ? 0 : (lm < 4 ? 1 : (lm < 9 ? 2 : 3)); };
   // channel mixing V[e][lm][:] = Vp[e][lm][:] @ mix[l]: one GEMM per lm with row stride D*U (float32), else k_mix
   auto mix_fwd = [&](int Dm, const T *Vp_, const T *mixw, T *Vout) {
     if (!go) return;

@@ -468,7 +468,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE.get(used_path, "f32"), "data": "synthetic",
             "config": {"workload": f"{('BASELINE config ' + str(args.config)) if args.config <= 5 else 'extra config 6 (not in BASELINE.json)'}: {wl['name']}, r_max {cfg['r_max']} A + skin 1.0 A, NVE dt=1 fs",
-                       "grid": "x".join(map(str, grid)), "kernel_path": used_path, "rebuilds": sim.nrebuild,
+                       "grid": "x".join(map(str, grid)), "kernel_path": used_path, "arith_note": model.arith_note, "rebuilds": sim.nrebuild,
                        "rebuilds_in_timed_steps": rebuilds_timed, "rebuild_ms": round(rebuild_ms, 3),
                        "steps_per_rebuild": (round(args.steps / rebuilds_timed, 1) if rebuilds_timed else None),
                        "rebuild_cadence_measured": ({"steps": cadence_steps, "rebuilds": cadence_rebuilds} if cadence_steps else None),

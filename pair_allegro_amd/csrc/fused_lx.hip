@@ -61,7 +61,13 @@ template <int L, int UT, int NW> struct __attribute__((aligned(16))) LdsX {
   float scale[16], shift[16];
   float res[LX_MAXNL][2];
   int chunk[2];
+  // Round 6: rows of the LAST layer that never travel to memory.  One workgroup per CU leaves ~58 KB of LDS unused: per wave NLROW register-image rows hold the last
+  // layer's omega rows (l >= 1) and the first rows of its input tensor; its 8 latent-MLP rows go to the wave's own slots of stage[0], idle between that layer's
+  // environment sum and its backward tensor product (as in k_fused: EpiSiluSaveDL / EpiSiluSaveZL).  22 of the 118 rows a wave-tile of the reference YAML's shape saves.
+  static constexpr int NLROW = 14;
+  float rowsl[NW][NLROW * ROW];
 };
+static_assert(sizeof(LdsX<2, 2, 4>) <= 160 * 1024, "LDS budget of one CU");
 
 
 // Per-centre sum of one staged K-tile: env[a][lm][16 t + f] = scale * sum_{slots of a} stage[slot][lm][f].
@@ -109,9 +115,9 @@ __device__ __forceinline__ void reduce_stage_x(const float *stg, const int *aoff
 // saved as the next layer's V_in) or V[lm] <- V[lm] @ M_l^T (+ ds on the scalar row: backward).  With 32 tensor features a row
 // is 2 x 2 tiles = 4 weight fragments = half a ring: rows alternate the ring phase, and the last (ninth) row is zero-padded on
 // the host to 8 fragments so that the stream stays ring-aligned.
-template <int LM, int D, int UT, bool FWD, int AR>
+template <int LM, int D, int UT, bool FWD, int AR, bool LSPLIT = false>
 __device__ __forceinline__ void mix_rows(float (&V)[D][UT][4], __amdgpu_buffer_rsrc_t WB, int &wp, int v16, LxRing<AR> &ring,
-                                         __amdgpu_buffer_rsrc_t SB, int row0, const f32x4 (&ds)[UT]) {
+                                         __amdgpu_buffer_rsrc_t SB, int row0, const f32x4 (&ds)[UT], float *lbase = nullptr, int lrow0 = 0, int nlds = 0) {
   if constexpr (LM < D) {
     constexpr bool PADDED = (UT == 2) && (LM == D - 1) && (D % 2 == 1);
     constexpr int NTO = PADDED ? 4 : UT;
@@ -119,12 +125,16 @@ __device__ __forceinline__ void mix_rows(float (&V)[D][UT][4], __amdgpu_buffer_r
     f32x4 vi[UT], o[NTO];
 #pragma unroll
     for (int t = 0; t < UT; ++t) vi[t] = acc_get4(V[LM][t]);
-    if constexpr (FWD) lx_lin<AR, UT, NTO, false, RP>(WB, wp, vi, o, v16, ring, EpiSaveN<UT>{SB, row0 + LM * UT, v16});
-    else lx_lin<AR, UT, NTO, false, RP>(WB, wp, vi, o, v16, ring, EpiNone{});
+    v16 = fresh_lane() << 4;          // formed here (as fused_lx2.hip does): the value computed at kernel entry was spilled and reloaded in front of every row store
+    if constexpr (FWD) {
+      // (lbase: the output rows are the LAST layer's input tensor -- its first nlds rows stay in LDS)
+      if constexpr (LSPLIT) lx_lin<AR, UT, NTO, false, RP>(WB, wp, vi, o, v16, ring, EpiSaveNSplit<UT>{SB, row0, v16, lbase, LM * UT, lrow0, nlds, fresh_lane()});
+      else lx_lin<AR, UT, NTO, false, RP>(WB, wp, vi, o, v16, ring, EpiSaveN<UT>{SB, row0 + LM * UT, v16});
+    } else lx_lin<AR, UT, NTO, false, RP>(WB, wp, vi, o, v16, ring, EpiNone{});
 #pragma unroll
     for (int t = 0; t < UT; ++t) acc_put4(V[LM][t], (!FWD && LM == 0) ? o[t] + ds[t] : o[t]);
     __builtin_amdgcn_sched_barrier(0);
-    mix_rows<LM + 1, D, UT, FWD, AR>(V, WB, wp, v16, ring, SB, row0, ds);
+    mix_rows<LM + 1, D, UT, FWD, AR, LSPLIT>(V, WB, wp, v16, ring, SB, row0, ds, lbase, lrow0, nlds);
   }
 }
 
@@ -139,6 +149,9 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
   using S = ShapeX<L, UT, NW>;
   constexpr int NTHREADS = NW * 64, D = S::D, U = S::U, EW = S::EW, MAXA = S::MAXA, STG_LD = S::STG_LD, ENVA = S::ENVA, NP = S::NP;
   constexpr bool SAVEZ = AR == 3;          // f16x2: raw pre-activation rows of the last hidden layer instead of silu' rows, no u rows (see fused.hip)
+  // last-layer rows in LDS (LdsX::rowsl, stage[0] images): LDS rows [0, NOML) = omega l >= 1, [NOML, NLROW) = the first NVL rows of the input tensor
+  constexpr int NLROW = LdsX<L, UT, NW>::NLROW, NOML = L * UT, NVL = (NLROW - NOML) < D * UT ? (NLROW - NOML) : D * UT;
+  static_assert(NOML <= NLROW, "omega rows of the last layer fit the LDS rows");
   __shared__ LdsX<L, UT, NW> lds;
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
   const int uwave = __builtin_amdgcn_readfirstlane(wave);
@@ -216,7 +229,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
     const float rc = lds.rc[ti * A.T + tj];
     const float xx = d / rc;
     float fc, dfc_dx;
-    cutoff_poly(A.p, xx, fc, dfc_dx);
+    cutoff_poly_c(A.p, A.cp, xx, fc, dfc_dx);
     if (!valid) { fc = 0.f; dfc_dx = 0.f; }
     // real spherical harmonics, component normalisation, m = -l..l (pair_allegro_amd/cg.py)
     constexpr float C3 = 1.7320508075688772f, C15 = 3.872983346207417f, C5H = 1.118033988749895f;
@@ -228,8 +241,9 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
       Y[7] = C15 * nx * nz; Y[8] = 0.5f * C15 * (nx * nx - ny * ny);
     }
     const int envoff = aloc * ENVA + 4 * g;      // + kk * MAXA*ENVA (layer) + lm * U + 16 t
-    float *const st0 = lds.stage[0] + s * STG_LD + 4 * g;
-    float *const st1 = lds.stage[1] + s * STG_LD + 4 * g;
+    // this lane's staging row in buffer b, formed where it is used from the hardware lane counter (round 6): as a value computed at the top of the tile it
+    // lived in scratch once the last layer's rows moved into the stage, and its reload in front of every staging write drained the in-order load queue
+    auto STQ = [&](int b) { const int ln = fresh_lane(); return lds.stage[b] + (uwave * 16 + (ln & 15)) * STG_LD + 4 * (ln >> 4); };
     PHASEX(PX_GEOM);
 
     // ---------------- two-body embedding x0(d; type pair) from the spline table ----------------
@@ -240,12 +254,12 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
       const float sft = d * tb_invh;
       const int kq = min((int)sft, A.tb_nk - 1);
       const float tb_t = sft - (float)kq;
-      const float *tb_ent = Wb + A.o_tbtab + ((size_t)(ti * A.T + tj) * A.tb_nk + kq) * 256 + 4 * g;
+      const int tb_off = (A.o_tbtab + ((ti * A.T + tj) * A.tb_nk + kq) * 256 + 4 * g) * 4;      // byte offset inside the weight buffer: 32 bits per lane, the 16 gathers differ in the immediate offset
       const float vm = (valid && xx < 1.f) ? 1.f : 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const f32x4 c0 = *(const f32x4 *)(tb_ent + (t * 4 + 0) * 16), c1 = *(const f32x4 *)(tb_ent + (t * 4 + 1) * 16);
-        const f32x4 c2 = *(const f32x4 *)(tb_ent + (t * 4 + 2) * 16), c3 = *(const f32x4 *)(tb_ent + (t * 4 + 3) * 16);
+        const f32x4 c0 = bload_w(WB, tb_off + (t * 4 + 0) * 64, 0), c1 = bload_w(WB, tb_off + (t * 4 + 1) * 64, 0);
+        const f32x4 c2 = bload_w(WB, tb_off + (t * 4 + 2) * 64, 0), c3 = bload_w(WB, tb_off + (t * 4 + 3) * 64, 0);
         x[t] = (c0 + tb_t * (c1 + tb_t * (c2 + tb_t * c3))) * vm;
         bstore(SB, v16, (S::R_DX0 + t) * ROW * 4, (c1 + tb_t * (2.f * c2 + (3.f * tb_t) * c3)) * (vm * tb_invh));
       }
@@ -272,12 +286,14 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
       float *const envk = lds.env[kk];
       {
         f32x4 om[EW];
-        lx_lin<AR, 4, EW, false>(WB, wp, x, om, v16, ring, EpiSaveFrom<UT>{{SB, RL + S::O_OM, v16}});        // the backward pass reads the l >= 1 rows only
+        // the backward pass reads the l >= 1 rows only; the last layer's stay in LDS
+        if (last) lx_lin<AR, 4, EW, false>(WB, wp, x, om, v16, ring, EpiSaveFromL<UT>{lds.rowsl[uwave], fresh_lane()});
+        else lx_lin<AR, 4, EW, false>(WB, wp, x, om, v16, ring, EpiSaveFrom<UT>{{SB, RL + S::O_OM, v16}});
         // environment sum over the centre's edges, one K-tile at a time through the double-buffered stage
 #ifndef ABL_NO_ENVSTAGE
 #pragma unroll
         for (int t = 0; t < UT; ++t) {
-          float *const sp = (t & 1) ? st1 : st0;
+          float *const sp = STQ(t & 1);
 #pragma unroll
           for (int lm = 0; lm < D; ++lm) *(f32x4 *)(sp + lm * 16) = lm == 0 ? om[t] : om[l_of_lm(lm) * UT + t] * Y[lm];
           __syncthreads();
@@ -294,7 +310,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
       f32x4 sc[UT];            // scalar outputs (l3 = 0) of the tensor product: the latent MLP's second input
       {
         const float *en = envk + envoff;
-        const float *tp = lds.tp[kk] + 4 * g;
+        const float *tp = lds.tp[kk] + 4 * (fresh_lane() >> 4);      // (lane-derived offsets are formed where they are used: as tile-long values they end up in scratch)
 #ifndef ABL_NO_FTP
         if (!last) {
 #pragma unroll
@@ -341,9 +357,15 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
         for (int t = 0; t < 4; ++t) cat[t] = x[t];
 #pragma unroll
         for (int t = 0; t < UT; ++t) cat[4 + t] = sc[t];
-        lx_lin<AR, 4 + UT, 4, false>(WB, wp, cat, z, v16, ring, EpiSiluSaveD{SB, RL + S::O_Z1, v16});
-        if constexpr (SAVEZ) lx_lin<AR, 4, 4, false>(WB, wp, z, z2, v16, ring, EpiSiluSaveZ{SB, RL + S::O_Z2, v16});
-        else lx_lin<AR, 4, 4, false>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, RL + S::O_Z2, v16});
+        if (last) {          // the last layer's rows: images 0..3 / 4..7 of the wave's own slots of stage[0] (idle until this layer's backward tensor product)
+          lx_lin<AR, 4 + UT, 4, false>(WB, wp, cat, z, v16, ring, EpiSiluSaveDL{STQ(0), 0});
+          if constexpr (SAVEZ) lx_lin<AR, 4, 4, false>(WB, wp, z, z2, v16, ring, EpiSiluSaveZL{STQ(0), 4});
+          else lx_lin<AR, 4, 4, false>(WB, wp, z, z2, v16, ring, EpiSiluSaveDL{STQ(0), 4});
+        } else {
+          lx_lin<AR, 4 + UT, 4, false>(WB, wp, cat, z, v16, ring, EpiSiluSaveD{SB, RL + S::O_Z1, v16});
+          if constexpr (SAVEZ) lx_lin<AR, 4, 4, false>(WB, wp, z, z2, v16, ring, EpiSiluSaveZ{SB, RL + S::O_Z2, v16});
+          else lx_lin<AR, 4, 4, false>(WB, wp, z, z2, v16, ring, EpiSiluSaveD{SB, RL + S::O_Z2, v16});
+        }
         const float ra = lds.res[kk][0], rbf = lds.res[kk][1] * fc;
         f32x4 xn[4];
         if constexpr (SAVEZ) lx_lin<AR, 4, 4, false>(WB, wp, z2, xn, v16, ring, EpiResidualNS<4>{x, ra, rbf});
@@ -357,7 +379,10 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
       PHASEX(PX_LAT);
       // channel mixing, in place per (l, m) row -> V^{kk+1}, saved as the next layer's V_in rows
 #ifndef ABL_NO_MIX
-      if (!last) mix_rows<0, D, UT, true, AR>(V, WB, wp, v16, ring, SB, S::R_LAYER(kk + 1) + S::O_VIN, sc);
+      if (!last) {
+        if (kk + 1 == NL - 1) mix_rows<0, D, UT, true, AR, true>(V, WB, wp, v16, ring, SB, S::R_LAYER(kk + 1) + S::O_VIN, sc, lds.rowsl[uwave], NOML, NVL);
+        else mix_rows<0, D, UT, true, AR>(V, WB, wp, v16, ring, SB, S::R_LAYER(kk + 1) + S::O_VIN, sc);
+      }
 #endif
       PHASEX(PX_MIX);
     }
@@ -367,7 +392,6 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
     // 1-2 us, and with one wave per SIMD nothing else covers it): u and silu'(z2) of the last layer under the read-out MFMAs
     f32x4 upre[4], zt[4], w0pre[L * UT];
     if constexpr (!SAVEZ) load_rows<4>(SB, S::R_LAYER(NL - 1) + S::O_U, upre, v16);
-    load_rows<4>(SB, S::R_LAYER(NL - 1) + S::O_Z2, zt, v16);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 zr[2];
     lx_lin<AR, 4, 2, false>(WB, wp, x, zr, v16, ring, EpiNone{});
@@ -402,6 +426,8 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
         for (int r = 0; r < 4; ++r) dzr[t][r] = deps * wo1[t][r] * dsilu1(zr[t][r]);
       lx_lin<AR, 2, 4, false>(WB, wp, dzr, dx, v16, ring, EpiNone{});
     }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) zt[t] = stg_load(STQ(0), 4 + t);            // the last layer's second hidden layer rows, from the staging tile
     float dfc_part = 0.f;
     float dY[D];
 #pragma unroll
@@ -416,7 +442,10 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
       {
         f32x4 du[4], dh[4];
         f32x4 rows1[4];
-        load_rows<4>(SB, RL + S::O_Z1, rows1, v16);            // silu'(z1): first used one linear from here
+        if (last) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) rows1[t] = stg_load(STQ(0), t);
+        } else load_rows<4>(SB, RL + S::O_Z1, rows1, v16);     // silu'(z1): first used one linear from here
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (SAVEZ) {
           // the u rows are not saved (fused.hip: SAVEZ): <u, g> falls out of the epilogue of the first backward linear, fed with the unscaled gradient
@@ -454,7 +483,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
       // tensor-product gradient in place per K-tile; the per-edge environment gradient goes through the stage
       {
         const float *en = lds.env[kk] + envoff;
-        const float *tp = lds.tp[kk] + 4 * g;
+        const float *tp = lds.tp[kk] + 4 * (fresh_lane() >> 4);      // (lane-derived offsets are formed where they are used: as tile-long values they end up in scratch)
         // the saved input rows V^{kk}[.][t] (w0 rows for the first layer) of half pass (t, h) are requested one half pass
         // ahead: their round trip (L2 miss: 1-2 us) runs under the previous half pass
         // saved input rows of half pass i = 2 t + h live in vpre2[i & 1] and are requested TWO half passes ahead (an HBM round trip
@@ -465,7 +494,10 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
           const int t = i >> 1, h = i & 1;
           if (kk > 0) {
 #pragma unroll
-            for (int lm = 0; lm < D; ++lm) vpre2[i & 1][lm] = bload_half(SB, v16 + 8 * h, (RL + S::O_VIN + lm * UT + t) * ROW * 4);
+            for (int lm = 0; lm < D; ++lm) {
+              if (last && lm * UT + t < NVL) vpre2[i & 1][lm] = *(const f32x2 *)(lds.rowsl[uwave] + (NOML + lm * UT + t) * ROW + fresh_lane() * 4 + 2 * h);
+              else vpre2[i & 1][lm] = bload_half(SB, v16 + 8 * h, (RL + S::O_VIN + lm * UT + t) * ROW * 4);
+            }
           } else {
 #pragma unroll
             for (int l = 0; l <= L; ++l) vpre2[i & 1][l] = bload_half(SB, v16 + 8 * h, (S::R_W0 + l * UT + t) * ROW * 4);
@@ -475,7 +507,6 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
         request_vin(1);
 #pragma unroll
         for (int t = 0; t < UT; ++t) {
-          float *const sp = (t & 1) ? st1 : st0;
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             f32x2 vin[D], a[D], b[D], ee[D];
@@ -491,7 +522,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
             // request and those reads would wait on vmcnt(0), i.e. on the rows just requested (loads return in order)
             // the stage pointer is needed after the tensor-product arithmetic: if it sits in a scratch slot, reload it NOW -- after
             // the request below a reload waits (vmcnt(0), in-order return) for the rows coming from HBM
-            asm volatile("" ::"v"(sp));
+            float *const sp = STQ(t & 1);
             if (2 * t + h + 2 < 2 * UT) request_vin(2 * t + h + 2);
             __builtin_amdgcn_sched_barrier(0);
             if (!last) {
@@ -520,7 +551,12 @@ __global__ void __launch_bounds__(NW * 64, 1) k_fused_lx(FusedLxArgs A) {
             for (int lm = 0; lm < D; ++lm) { acc_put2(V[lm][t], h, a[lm]); *(f32x2 *)(sp + lm * 16 + 2 * h) = b[lm]; }
             __builtin_amdgcn_sched_barrier(0);
           }
-          if (t == UT - 1) load_rows<L * UT>(SB, RL + S::O_OM + UT, omall, v16);
+          if (t == UT - 1) {
+            if (last) {
+#pragma unroll
+              for (int r = 0; r < L * UT; ++r) omall[r] = lrow_load(lds.rowsl[uwave], r, fresh_lane());
+            } else load_rows<L * UT>(SB, RL + S::O_OM + UT, omall, v16);
+          }
           __syncthreads();
           reduce_stage_x<L, UT, NW>(lds.stage[t & 1], aoffp, lds.denv, na, A.cenv, t, uwave);
           __builtin_amdgcn_sched_barrier(0);
@@ -775,6 +811,10 @@ template <int L, int UT> static void fusedlx_prepare_t(Model &m, FusedLxState &s
   A.wbytes = (int)(w.size() * sizeof(float));
   A.T = T; A.NL = NL; A.p = h.poly_p;
   A.cenv = (float)(1.0 / std::sqrt(h.avg_num_neighbors));
+  {
+    const float pf = (float)h.poly_p, ca = 0.5f * (pf + 1) * (pf + 2), cb = pf * (pf + 2), cc = 0.5f * pf * (pf + 1);      // the expressions of cutoff_poly
+    A.cp[0] = ca; A.cp[1] = cb; A.cp[2] = cc; A.cp[3] = ca * pf; A.cp[4] = cb * (pf + 1); A.cp[5] = cc * (pf + 2);
+  }
   A.bscale = A.ibscale = 1.f;
   if (st.arith == 3) {
     arith_range_verdict(m, h_flags);                 // auto: ArithDegraded (run_model falls back to the f32 instance); explicit f16x2: an overflow is an error

@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
     const float rc = lds.rc[ti * A.T + tj];
     const float xx = d / rc;
     float fc, dfc_dx;
-    cutoff_poly(A.p, xx, fc, dfc_dx);
+    cutoff_poly_c(A.p, A.cp, xx, fc, dfc_dx);
     if (!valid) { fc = 0.f; dfc_dx = 0.f; }
     constexpr float C3 = 1.7320508075688772f, C15 = 3.872983346207417f, C5H = 1.118033988749895f;
     float Y[D];
@@ -320,12 +320,12 @@ __global__ void __launch_bounds__(512, 1) k_fused_lx2(FusedLxArgs A) {
       const float sft = d * tb_invh;
       const int kq = min((int)sft, A.tb_nk - 1);
       const float tb_t = sft - (float)kq;
-      const float *tb_ent = Wb + A.o_tbtab + ((size_t)(ti * A.T + tj) * A.tb_nk + kq) * 256 + 4 * g;
+      const int tb_off = (A.o_tbtab + ((ti * A.T + tj) * A.tb_nk + kq) * 256 + 4 * g) * 4;      // byte offset inside the weight buffer: 32 bits per lane
       const float vm = (valid && xx < 1.f) ? 1.f : 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const float *te = tb_ent + (((t + 2 * hf) & 3) * 4) * 16;
-        const f32x4 c0 = *(const f32x4 *)(te), c1 = *(const f32x4 *)(te + 16), c2 = *(const f32x4 *)(te + 32), c3 = *(const f32x4 *)(te + 48);
+        const int te = (((t + 2 * hf) & 3) * 4) * 64;                 // wave-uniform: the instruction's scalar offset
+        const f32x4 c0 = bload_w(WB, tb_off, te), c1 = bload_w(WB, tb_off, te + 64), c2 = bload_w(WB, tb_off, te + 128), c3 = bload_w(WB, tb_off, te + 192);
         x[t] = (c0 + tb_t * (c1 + tb_t * (c2 + tb_t * c3))) * vm;
         bstore(SB, V16(), (S::R_DX0 + t) * ROW * 4, (c1 + tb_t * (2.f * c2 + (3.f * tb_t) * c3)) * (vm * tb_invh));
       }
@@ -895,6 +895,10 @@ static void fusedlx2_prepare(Model &m) {
   A.wbytes = (int)(w.size() * sizeof(float));
   A.T = T; A.NL = NL; A.p = h.poly_p;
   A.cenv = (float)(1.0 / std::sqrt(h.avg_num_neighbors));
+  {
+    const float pf = (float)h.poly_p, ca = 0.5f * (pf + 1) * (pf + 2), cb = pf * (pf + 2), cc = 0.5f * pf * (pf + 1);      // the expressions of cutoff_poly
+    A.cp[0] = ca; A.cp[1] = cb; A.cp[2] = cc; A.cp[3] = ca * pf; A.cp[4] = cb * (pf + 1); A.cp[5] = cc * (pf + 2);
+  }
   A.bscale = A.ibscale = 1.f;
   if (st.arith == 3) {
     arith_range_verdict(m, h_flags | model_tiny_linear(h));      // auto: ArithDegraded (run_model falls back to the f32 instance); explicit f16x2: an overflow is an error

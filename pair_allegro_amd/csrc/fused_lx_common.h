@@ -44,7 +44,8 @@ struct FusedLxArgs {
   // outputs
   double *f, *eatom, *partial;            // partial [gridDim.x][7]
   long long *prof;
-  float bscale, ibscale;                  // f16x2 arithmetic: the backward pass runs scaled by this power of two (fused_h.h), undone on the edge gradient
+  float cp[6];                            // cutoff polynomial coefficients (fused_common.h: cutoff_poly_c): wave-uniform kernel arguments instead of per-lane values held over a tile
+  float bscale, ibscale;                  // (unused since round 6: the backward scale of the f16x2 arithmetic is per centre type, derived in the kernels)
   int *err;                               // host-mapped word: set when an edge gradient comes out non-finite (float16 range exceeded)
 };
 
@@ -354,6 +355,30 @@ __device__ __forceinline__ int fresh_lane() {
   return l;
 }
 
+// Last-layer rows of k_fused_lx that live in LDS instead of scratch (round 6; register images: 16 B per lane, like the park rows of fused.hip)
+__device__ __forceinline__ void lrow_store(float *base, int row, f32x4 v, int lane) { *(f32x4 *)(base + row * ROW + lane * 4) = v; }
+__device__ __forceinline__ f32x4 lrow_load(const float *base, int row, int lane) { return *(const f32x4 *)(base + row * ROW + lane * 4); }
+// omega rows (output tiles FIRST ..) of the last layer -> LDS rows 0 ..
+template <int FIRST> struct EpiSaveFromL {
+  static constexpr bool STORES = false;
+  float *base; int lane;
+  __device__ __forceinline__ void tile_done(int ot, const f32x4 &acc) const { if (ot >= FIRST) lrow_store(base, ot - FIRST, acc, lane); }
+  __device__ __forceinline__ float apply(int, int, float v) const { return v; }
+  __device__ __forceinline__ void flush(int) const {}
+};
+// the last layer's input tensor rows (first NMAX output tiles of a mixing row): row index row0 + ot goes to LDS row lrow0 + index while index < NLDS, else to scratch
+template <int NMAX> struct EpiSaveNSplit {
+  static constexpr bool STORES = true;
+  __amdgpu_buffer_rsrc_t S; int srow0, v16;
+  float *base; int idx0, lrow0, nlds, lane;
+  __device__ __forceinline__ void tile_done(int ot, const f32x4 &acc) const {
+    if (ot >= NMAX) return;
+    if (idx0 + ot < nlds) lrow_store(base, lrow0 + idx0 + ot, acc, lane);
+    else bstore(S, v16, (srow0 + idx0 + ot) * ROW * 4, acc);
+  }
+  __device__ __forceinline__ float apply(int, int, float v) const { return v; }
+  __device__ __forceinline__ void flush(int) const {}
+};
 // Saves only the first NMAX output tiles of a linear (the rest is zero padding of a ring-aligned fragment block)
 template <int NMAX> struct EpiSaveN {
   static constexpr bool STORES = true;

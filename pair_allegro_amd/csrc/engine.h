@@ -114,6 +114,10 @@ struct Model {
   int arith_check_attempts = 0;
   std::string arith_note;                   // what auto decided and why, one line (ahip_arith_note)
   DevBuf b_chk;                             // self-check: two force arrays + the 2-word reduction
+  // A model narrower than a fused kernel's fixed widths runs on it zero-padded (round 6; model_io.h: pad_host_model): S <= 64 scalars, MLP width <= 64, read-out
+  // width <= 32, U <= 32 tensor features for l_max = 1, U <= 32 / <= 64 for l_max = 2.  hm stays the model as loaded (layer-at-a-time kernels, metadata).
+  HostModel hm_fused;
+  bool hm_fused_ready = false;
   long long chunk_edges = 2000000;
   int reserve_wgs = 0;                      // workgroup slots the persistent fused kernels leave free (for kernels of other streams)
   bool timing = false;
@@ -244,6 +248,15 @@ void fused_free(Model &m);
 int *alarm_word(Model &m);
 bool alarm_take(Model &m);                  // true (and cleared) when a kernel has raised the word since the last call
 void fused_poll_alarm(Model &m);            // alarm_take + the policy: auto -> degrade to f32 and report once; explicit f16x2 -> StateError
+// the fused kernels' fixed widths and whether a model fits them (exactly, or narrower: then padded)
+inline int fused_UF(const HostModel &h) { return h.l_max == 1 ? 32 : (h.U <= 32 ? 32 : 64); }
+inline bool fused_widths_fit(const HostModel &h) { return h.S >= 1 && h.S <= 64 && h.mlp_width >= 1 && h.mlp_width <= 64 && h.readout_width >= 1 && h.readout_width <= 32 && h.U >= 1 && h.U <= (h.l_max == 1 ? 32 : 64); }
+inline const HostModel &fused_host_model(Model &m) {
+  const HostModel &h = m.hm;
+  if (h.S == 64 && h.mlp_width == 64 && h.readout_width == 32 && h.U == fused_UF(h)) return h;
+  if (!m.hm_fused_ready) { m.hm_fused = pad_host_model(h, 64, fused_UF(h), 64, 32); m.hm_fused_ready = true; }
+  return m.hm_fused;
+}
 // option fused_arith as it applies (the environment variable of the A/B tools wins)
 inline std::string arith_option(const Model &m) {
   const char *ar = std::getenv("AHIP_FUSED_ARITH");

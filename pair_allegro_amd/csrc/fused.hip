@@ -24,7 +24,8 @@
 //            products, f32 accumulate: fused_h.h); bf16x3 (exact 3-way bf16 split, six bf16-MFMA terms); tf32eq (two bf16 terms,
 //            only for model files that set allow_tf32).
 //
-// Supported model shape (others run the generic path): l_max = 1, 32 tensor features, 64 scalars,
+// Supported model shape (others run the generic path): l_max = 1, up to 32 tensor features, up to 64 scalars, MLP width up to 64, read-out width up to 32 (narrower than
+// the kernel's fixed 32 / 64 / 64 / 32: zero-padded by the host, model_io.cpp: pad_host_model),
 // MLPs of 2 hidden layers x 64 (1 or 3 hidden layers on the f16x2 instances with the tabulated two-body embedding: template parameter MD, round 5),
 // read-out 1 x 32, <= 3 layers, <= 16 types; any number of Bessel functions and any cutoff-polynomial order (the radial basis only
 // enters through the tabulated two-body embedding; fused_tb=mlp needs 8).  Reference graph:
@@ -1174,7 +1175,7 @@ bool fused_model_supported(const Model &m, std::string *why) {
   const HostModel &h = m.hm;
   auto no = [&](const char *msg) { if (why) *why = msg; return false; };
   if (h.l_max != 1) return no("fused kernels need l_max = 1");
-  if (h.U != 32 || h.S != 64 || h.mlp_width != 64 || h.readout_width != 32) return no("fused kernels need U=32, S=64, MLP width 64, read-out width 32");
+  if (!fused_widths_fit(h)) return no("fused kernels hold at most U=32, S=64, MLP width 64, read-out width 32 (narrower models run zero-padded)");
   if (h.mlp_depth < 1 || h.mlp_depth > 3 || h.readout_depth != 1) return no("fused kernels need MLP depth 1..3 and read-out depth 1");
   if (h.mlp_depth != 2) {           // round 5: depth 1 and 3 on the f16x2 instances with the tabulated two-body embedding
     bool tbt;
@@ -1196,7 +1197,7 @@ static void fused_prepare(Model &m) {
   if (!m.fused_state) m.fused_state = new FusedState();
   FusedState &st = *(FusedState *)m.fused_state;
   if (st.ready) return;
-  const HostModel &h = m.hm;
+  const HostModel &h = fused_host_model(m);          // the model at the kernel's fixed widths (zero-padded when it is narrower)
   const int T = h.num_types, NL = h.num_layers;
   std::vector<float> w;
   FusedArgs &A = st.args;

@@ -718,8 +718,7 @@ bool fusedlx_model_supported(const Model &m, std::string *why) {
   const HostModel &h = m.hm;
   auto no = [&](const char *msg) { if (why) *why = msg; return false; };
   if (h.l_max != 2) return no("wide fused kernels are built for l_max = 2");
-  if (h.U != 32 && h.U != 64) return no("wide fused kernels need 32 or 64 tensor features");
-  if (h.S != 64 || h.mlp_width != 64 || h.readout_width != 32) return no("fused kernels need S=64, MLP width 64, read-out width 32");
+  if (!fused_widths_fit(h)) return no("wide fused kernels hold at most 64 tensor features, S=64, MLP width 64, read-out width 32 (narrower models run zero-padded)");
   if (h.mlp_depth != 2 || h.readout_depth != 1) return no("fused kernels need MLP depth 2 and read-out depth 1");
   if (h.num_bessels < 1) return no("no radial basis");      // any number of Bessel functions: the two-body embedding is always tabulated here
   if (h.num_layers < 1 || h.num_layers > LX_MAXNL) return no("fused kernels need 1..3 layers");
@@ -729,7 +728,7 @@ bool fusedlx_model_supported(const Model &m, std::string *why) {
 
 template <int L, int UT> static void fusedlx_prepare_t(Model &m, FusedLxState &st) {
   using S = ShapeX<L, UT, 4>;
-  const HostModel &h = m.hm;
+  const HostModel &h = fused_host_model(m);          // at the kernel's fixed widths (zero-padded when the model is narrower)
   const int T = h.num_types, NL = h.num_layers, U = S::U, D = S::D;
   std::vector<float> w;
   FusedLxArgs &A = st.args;
@@ -827,7 +826,7 @@ static void fusedlx_prepare(Model &m) {
   if (!m.fusedlx_state) m.fusedlx_state = new FusedLxState();
   FusedLxState &st = *(FusedLxState *)m.fusedlx_state;
   if (st.ready) return;
-  st.L = m.hm.l_max; st.UT = m.hm.U / 16;
+  st.L = m.hm.l_max; st.UT = fused_UF(m.hm) / 16;
   fusedlx_prepare_t<2, 2>(m, st);
   hipDeviceProp_t prop;
   AHIP_CHECK(hipGetDeviceProperties(&prop, m.device));
@@ -853,7 +852,7 @@ bool fusedlx_run(Model &m, const ComputeArgs &a, std::string *why) {
     return false;
   }
   if (m.edges_T_size != 4) { if (why) *why = "edge vectors are not float32"; return false; }
-  if (m.hm.U == 64) {
+  if (fused_UF(m.hm) == 64) {
     return fusedlx2_run(m, a, why);          // 64 tensor features: the wave-pair kernel (fused_lx2.hip)
   }
   fusedlx_prepare(m);

@@ -52,7 +52,8 @@ struct ShapeP {
   static constexpr int L = 2, D = 9, NLP = 3, UT = 4, HT = 2, U = 64, EWH = NLP * HT;    // EWH: own 16-feature tiles of an (l, u) weight vector
   static constexpr int NW = 8, SLOTS = 64, MAXA = 4;
   static constexpr int STG_LD = D * 16 + 4;             // one K-tile of a slot: [lm][16] + pad
-  static constexpr int ENVA = D * U + 4;                // environment row of one centre: [lm][u] + pad
+  static constexpr int ENVA = D * U + 16;               // environment row of one centre: [lm][u] + pad.  ENVA = 16 (mod 64): the rows of the (<= 4) centres of a tile and the four lane groups (+ 4 g)
+                                                        // start in 16 distinct 4-bank groups (round 6; with + 4 centre 1 / group 0 met centre 0 / group 1: 229.1 -> 227.7 ms on config 5)
   static constexpr int NP = CgX<2>::NP;
   // scratch rows (per wave, 1 KiB each): d x0/dd 4 | w0 EWH | per layer: omega EWH, silu'(z1) 2, silu'(z2) 2, u 2, V_in D*HT
   static constexpr int R_DX0 = 0, R_W0 = 4, LSZ = EWH + 6 + D * HT;
@@ -808,7 +809,7 @@ static void fusedlx2_prepare(Model &m) {
   FusedLxState &st = *(FusedLxState *)m.fusedlx2_state;
   if (st.ready) return;
   st.L = 2; st.UT = 4;
-  const HostModel &h = m.hm;
+  const HostModel &h = fused_host_model(m);          // at the kernel's fixed widths (zero-padded when the model is narrower: 33..63 tensor features, ...)
   const int T = h.num_types, NL = h.num_layers, U = S::U, D = S::D, UT = S::UT;
   std::vector<float> w;
   FusedLxArgs &A = st.args;

@@ -21,6 +21,52 @@ const HostTensor &HostModel::get(const std::string &name) const {
   return it->second;
 }
 
+HostModel pad_host_model(const HostModel &h, int SF, int UF, int WF, int RF) {
+  const int S = h.S, U = h.U, W = h.mlp_width, R = h.readout_width, L = h.l_max, T = h.num_types, B = h.num_bessels, dep = h.mlp_depth;
+  if (S > SF || U > UF || W > WF || R > RF) throw std::runtime_error("pad_host_model: the model is wider than the target shape");
+  HostModel p = h;
+  p.S = SF; p.U = UF; p.mlp_width = WF; p.readout_width = RF;
+  // out[rmap(r)][cmap(c)] = in[r][c] for every leading block of a [..][R0][C0] tensor
+  auto pad = [&](const std::string &name, int R0, int C0, int R1, int C1, auto rmap, auto cmap) {
+    const HostTensor &t = h.get(name);
+    const long long blk = (long long)R0 * C0, nb = blk > 0 ? t.numel() / blk : 0;
+    HostTensor o;
+    o.shape = t.shape;
+    o.shape[o.shape.size() - 2] = R1; o.shape[o.shape.size() - 1] = C1;
+    o.data.assign((size_t)nb * R1 * C1, 0.0);
+    for (long long b = 0; b < nb; ++b)
+      for (int r = 0; r < R0; ++r)
+        for (int c = 0; c < C0; ++c) o.data[(size_t)(b * R1 + rmap(r)) * C1 + cmap(c)] = t.data[(size_t)(b * R0 + r) * C0 + c];
+    p.tensors[name] = o;
+  };
+  auto id = [](int i) { return i; };
+  auto lu = [&](int c) { return (c / U) * UF + (c % U); };          // (l, u) column of an embedding / environment weight vector
+  auto cat = [&](int r) { return r < S ? r : SF + (r - S); };        // row of the latent MLP's input [x, scalars]
+  auto mlp = [&](const std::string &pre, int din, int din1, int dout, int dout1, auto rmap0) {
+    if (dep == 0) { pad(pre + ".w0", din, dout, din1, dout1, rmap0, id); return; }
+    pad(pre + ".w0", din, W, din1, WF, rmap0, id);
+    for (int k = 1; k < dep; ++k) pad(pre + ".w" + std::to_string(k), W, W, WF, WF, id, id);
+    pad(pre + ".w" + std::to_string(dep), W, dout, WF, dout1, id, id);
+  };
+  mlp("tb", 2 * T + B, 2 * T + B, S, SF, id);
+  pad("emb.w", S, U * (L + 1), SF, UF * (L + 1), id, lu);
+  for (int k = 1; k <= h.num_layers; ++k) {
+    const std::string lk = "l" + std::to_string(k);
+    pad(lk + ".env", S, U * (L + 1), SF, UF * (L + 1), id, lu);
+    { const HostTensor &tp = h.get(lk + ".tp"); pad(lk + ".tp", tp.shape[0], U, tp.shape[0], UF, id, id); }
+    mlp(lk + ".lat", S + U, SF + UF, S, SF, cat);
+    if (k < h.num_layers) pad(lk + ".mix", U, U, UF, UF, id, id);
+  }
+  // read-out MLP S -> R (x readout_depth) -> 1
+  if (h.readout_depth == 0) pad("out.w0", S, 1, SF, 1, id, id);
+  else {
+    pad("out.w0", S, R, SF, RF, id, id);
+    for (int k = 1; k < h.readout_depth; ++k) pad("out.w" + std::to_string(k), R, R, RF, RF, id, id);
+    pad("out.w" + std::to_string(h.readout_depth), R, 1, RF, 1, id, id);
+  }
+  return p;
+}
+
 static std::vector<unsigned char> read_all(const std::string &path) {
   std::ifstream f(path, std::ios::binary);
   if (!f) throw std::runtime_error("cannot open model file " + path);

@@ -32,6 +32,11 @@ struct HostModel {
 // Throws std::runtime_error with a user-facing message.
 HostModel load_model_file(const std::string &path);
 
+// The same model with its widths zero-padded to the fixed widths of a fused kernel (round 6): S scalar features -> SF, U tensor features -> UF (the columns of the
+// (l, u) weight vectors move from l U + u to l UF + u), MLP width W -> WF, read-out width R -> RF.  Padded features are exact zeros all the way (no biases, silu(0) = 0,
+// zero path weights, zero rows / columns in every linear), so the padded model computes the same energies and forces; needs S <= SF, U <= UF, W <= WF, R <= RF.
+HostModel pad_host_model(const HostModel &h, int SF, int UF, int WF, int RF);
+
 // Parses an in-memory blob.
 HostModel parse_blob(const unsigned char *p, size_t n, const std::string &origin);
 

@@ -120,3 +120,18 @@ def test_model_L_six_species(hip_lib, model_dir):
     assert res["info"]["path"] in pc.FUSED_F32EQ
     util.assert_close_to(res, ref, 5e-4, what="6 species model L")
     assert np.abs(res["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
+
+
+@pytest.mark.parametrize("U,S,W,R", [(16, 48, 40, 24), (48, 64, 48, 32), (24, 32, 64, 16)])
+def test_narrower_l2_models_run_on_the_wide_kernels_zero_padded(hip_lib, model_dir, U, S, W, R):
+    """l_max = 2 models narrower than the wide kernels' fixed widths run on them zero-padded (model_io.cpp: pad_host_model): up to 32 tensor features on k_fused_lx, 33..64 on
+    k_fused_lx2; any S / MLP width <= 64, read-out width <= 32 (free hyper-parameters of /root/reference/tests/test_data/test_repro_allegro.yaml:89-99).  Cu2AgO4 (3 types, ragged)."""
+    g = util.load_golden("Cu2AgO4_r5")
+    cfg = model_file.model_L(type_names=["Cu", "Ag", "O"], num_tensor_features=U, num_scalar_features=S, mlp_width=W, readout_width=R, avg_num_neighbors=30.0)
+    path, types, names, ref = _case(model_dir, f"L_narrow_U{U}_S{S}_W{W}_R{R}", cfg, g["cell"], g["pos"], g["symbols"])
+    res = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names)
+    assert res["info"]["path"] == pc.FUSED_DEFAULT, res["info"]
+    util.assert_close_to(res, ref, 5e-4, what=f"narrow l_max = 2 model U={U} S={S} W={W} R={R}")
+    assert np.abs(res["forces"] - ref["forces"]).max() < pc.NORTH_STAR_DF
+    gen = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "generic"})
+    np.testing.assert_allclose(res["forces"], gen["forces"], atol=2e-5)

@@ -663,8 +663,10 @@ static void run_model(ahip_model *m, const ComputeArgs &a) {
   const bool wants_check = !m->arith_checked && !m->arith_degraded && m->inum > 0 && !f64 && m->opt_path != "generic" && arith_option(*m) == "auto" &&
                            !m->hm.allow_tf32 && (fused_model_supported(*m, nullptr) || fusedlx_model_supported(*m, nullptr)) &&
                            std::getenv("AHIP_NO_ARITH_SELFCHECK") == nullptr;
-  if (wants_check) run_model_selfcheck(m, a);
-  else run_model_dispatch(m, a);
+  if (wants_check) {
+    run_model_selfcheck(m, a);
+    if (m->arith_checked) m->b_chk.release();      // two force arrays of the whole system: not kept for the model's life (hipFree waits for the kernels that still read them)
+  } else run_model_dispatch(m, a);
 }
 static void run_model_once(ahip_model *m, const ComputeArgs &a) {
   m->nedges = 0;

@@ -384,6 +384,8 @@ class Simulation:
         brick = np.maximum(np.asarray(self.hi) - np.asarray(self.lo), 1e-9)
         est = int(nl * (np.prod(1.0 + 2.0 * self.rc / brick) - 1.0) * 1.3) + 2048
         cap = nl + max(est, int(1.25 * getattr(self, "_nghost_last", 0)))
+        if os.environ.get("AHIP_TEST_SMALL_BORDERS_CAP") == "1":      # tests only: start too small, so that the collective overflow answer and the retry are exercised
+            cap = nl + 8
         while True:
             xa = torch.empty((cap, 3), dtype=torch.float64, device=self.dev); xa[:nl] = self.x[:nl]
             mta = torch.empty(cap, dtype=torch.int32, device=self.dev); mta[:nl] = self.mtype[:nl]

@@ -91,6 +91,14 @@ def test_gloo_library_borders_equal_the_swap_chain(emu_lib, model_dir, tmp_path,
     np.testing.assert_allclose(z["e2"], z["e1"], rtol=1e-9)
 
 
+def test_gloo_library_borders_overflow_is_agreed_on_and_retried(emu_lib, model_dir, tmp_path):
+    """ahip_comm_borders with arrays that are too small (8 ghost rows): every rank gets the same "needs N rows" answer -- the ranks that overflow keep exchanging messages of the
+    announced sizes, nobody waits for ever -- and the caller's retry with larger arrays gives the ordinary result (4 ranks, forces and trajectory equal the single-rank run)."""
+    z = _run_workers(emu_lib, model_dir, tmp_path, 4, 29759, extra=(300.0, 3, 1.0), env_extra={"AHIP_TEST_SMALL_BORDERS_CAP": "1"})
+    np.testing.assert_allclose(z["f2"], z["f1"], atol=1e-10)
+    np.testing.assert_allclose(z["x2"], z["x1"], atol=1e-12)
+
+
 def test_gloo_torch_swap_chain_still_works(emu_lib, model_dir, tmp_path):
     """the torch re-neighboring path (AHIP_LIB_BORDERS=0; also what a backend without the library communicator runs): migration test on 2x2x1 bricks"""
     z = _run_workers(emu_lib, model_dir, tmp_path, 4, 29757, extra=(6000.0, 20, 0.2), env_extra={"AHIP_LIB_BORDERS": "0"})

@@ -44,12 +44,6 @@
 // weight fragments in flight per wave: 4 (two steps ahead) instead of the wide kernels' 8 -- the 16 registers are worth more to this kernel than the deeper prefetch
 // (1 M-atom Si: 58.3 -> 56.8 ms; 2 fragments: slower than 4)
 #define AHIP_RING 4
-#ifndef AHIP_X_PARKV
-#define AHIP_X_PARKV 1
-#endif
-#ifndef AHIP_X_STGROWS
-#define AHIP_X_STGROWS 1
-#endif
 #include "fused_common.h"
 #include "fused_h.h"
 #include "prims.h"
@@ -103,7 +97,6 @@ struct FusedArgs {
   long long *prof;                        // [PH_N] or unused
   float *dbg;                             // [E][8] per-edge diagnostics or null
   float cp[6];                            // cutoff polynomial: a, b, c of f = 1 - a x^p + b x^(p+1) - c x^(p+2) and a p, b (p + 1), c (p + 2) of its derivative (scalar registers, not per-lane values held over a tile)
-  float bscale, ibscale;                  // (unused since round 6: the backward scale of the f16x2 arithmetic is per centre type, derived in the kernel)
   int *err;                               // host-mapped word: set when an edge gradient comes out non-finite (float16 range exceeded)
 };
 
@@ -374,10 +367,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fused(FusedArgs A) {
   // pass needs u only for <u, g> (the cutoff gradient), and <u, g> = <silu(z), g W^T> falls out of its first linear's epilogue (EpiMulSiluZ), which rebuilds silu and silu'
   // from z -- 6 row stores and 6 row loads fewer per wave-tile of a two-layer model for ~10 VALU operations per value there: 45.8 -> 44.4 ms at 1 M Si atoms.
   constexpr bool SAVEZ = AR == 3;
-  constexpr bool PARKV = AHIP_X_PARKV != 0;
+  constexpr bool PARKV = true;             // (round 6; its A/B: profiles/r06_a_ab_k_fused_rows_and_spills.txt, 39.7 -> 37.8 ms)
   // The LAST layer's activation rows (silu' / pre-activations of its last two hidden layers) live in the wave's own slots of the staging tile instead of scratch rows:
   // the tile is idle from that layer's environment sum to its backward tensor product (EpiSiluSaveDL / EpiSiluSaveZL): 8 row stores and 8 row loads fewer per wave-tile.
-  constexpr bool STGROWS = AHIP_X_STGROWS != 0;
+  constexpr bool STGROWS = true;           // (36.0 -> 34.3 ms)
   constexpr int OZL = 4 + 4 * (MD - 1), OU = 4 + 4 * MD, OVIN = 8 + 4 * MD;      // row offsets inside a layer: silu' of the LAST hidden layer, u, V_in (MD = 2: 8, 12, 16)
   static_assert(MD >= 1 && MD <= 3 && (MD == 2 || (AR == 3 && TBT)), "latent MLP depth 1 / 3: f16x2 instances with the two-body table only");
   __shared__ Lds<NW, NLT> lds;
@@ -1312,7 +1305,6 @@ static void fused_prepare(Model &m) {
     const float pf = (float)h.poly_p, ca = 0.5f * (pf + 1) * (pf + 2), cb = pf * (pf + 2), cc = 0.5f * pf * (pf + 1);      // the expressions of cutoff_poly
     A.cp[0] = ca; A.cp[1] = cb; A.cp[2] = cc; A.cp[3] = ca * pf; A.cp[4] = cb * (pf + 1); A.cp[5] = cc * (pf + 2);
   }
-  A.bscale = A.ibscale = 1.f;
   if (st.arith == 3) {
     arith_range_verdict(m, h_flags);                 // auto: ArithDegraded (run_model falls back to the f32 instance); explicit f16x2: an overflow is an error
     A.err = alarm_word(m);

@@ -12,7 +12,8 @@
 // max|dF| vs the float64 oracle 2.9e-6 against 2.8e-6 for float32 fmaf chains; tests/test_arith_emulation.py emulates all three on the CPU).
 // What float16 does NOT have is bf16's exponent range: operands must stay inside [2^-14, 65504] to keep their precision.  Forward activations of a
 // sane model do (O(1e-3 .. 1e2)); the backward pass is linear in the upstream gradient, so k_fused runs it scaled by a power of two chosen from the
-// model's energy scale (FusedArgs::bscale, undone on the three force components); a non-finite edge gradient raises FusedArgs::err (host: StateError).
+// centre type's energy scale (derived in the kernels with frexp since round 6, undone on the edge gradient); a non-finite edge gradient raises FusedArgs::err (host: under
+// fused_arith=auto the model switches to the f32 instance, engine.h; with an explicit f16x2: StateError).
 //
 // linear_h<G, ...>: G = 1 or 2 edge groups (16 slots each) of the wave share every weight fragment (two B operands, two accumulator sets per
 // fragment): the fragment stream through the 64 B/clk/CU register-return path per edge halves with G = 2.

@@ -814,7 +814,6 @@ template <int L, int UT> static void fusedlx_prepare_t(Model &m, FusedLxState &s
     const float pf = (float)h.poly_p, ca = 0.5f * (pf + 1) * (pf + 2), cb = pf * (pf + 2), cc = 0.5f * pf * (pf + 1);      // the expressions of cutoff_poly
     A.cp[0] = ca; A.cp[1] = cb; A.cp[2] = cc; A.cp[3] = ca * pf; A.cp[4] = cb * (pf + 1); A.cp[5] = cc * (pf + 2);
   }
-  A.bscale = A.ibscale = 1.f;
   if (st.arith == 3) {
     arith_range_verdict(m, h_flags);                 // auto: ArithDegraded (run_model falls back to the f32 instance); explicit f16x2: an overflow is an error
     A.err = alarm_word(m);

@@ -45,7 +45,6 @@ struct FusedLxArgs {
   double *f, *eatom, *partial;            // partial [gridDim.x][7]
   long long *prof;
   float cp[6];                            // cutoff polynomial coefficients (fused_common.h: cutoff_poly_c): wave-uniform kernel arguments instead of per-lane values held over a tile
-  float bscale, ibscale;                  // (unused since round 6: the backward scale of the f16x2 arithmetic is per centre type, derived in the kernels)
   int *err;                               // host-mapped word: set when an edge gradient comes out non-finite (float16 range exceeded)
 };
 

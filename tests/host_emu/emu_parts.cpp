@@ -65,3 +65,12 @@ bool tp_bwd_f32(hipStream_t, long long, int, bool, int, const float *, const flo
 
 extern "C" int ahip_debug_fused_linear(int, int, const double *, const float *, float *) { return 5; }
 extern "C" int ahip_debug_fused_edges(void *, float *, long long) { return 5; }
+
+// TEST INFRASTRUCTURE ONLY (tests/test_host_logic.py): replaces a freshly loaded model by its zero-padded copy (model_io.cpp: pad_host_model, what the fused kernels of the
+// product run for models narrower than their fixed widths) BEFORE anything was evaluated, so that the layer-at-a-time kernels of the emulation evaluate the padded model.
+extern "C" int ahip_emu_pad_model(void *mh, int SF, int UF, int WF, int RF) {
+  ahip::Model *m = (ahip::Model *)mh;
+  if (!m) return 1;
+  try { m->hm = ahip::pad_host_model(m->hm, SF, UF, WF, RF); } catch (...) { return 2; }
+  return 0;
+}

@@ -65,6 +65,22 @@ def run(lib, path, wl, vel, grid, rank, d, nsteps, overlap, one_device_shared):
     out["virial1"] = np.array(th["virial"])
     out["path"] = model.last_path
     out["rebuilds"] = int(sim.nrebuild)
+    out["lib_borders"] = bool(getattr(sim, "_lib_plan", False))
+    # cost of one re-neighboring per rank (migration + borders + plan + neighbor list), twice: inside the library (ahip_comm_migrate / ahip_comm_borders, round 6)
+    # and by the torch swap chain (AHIP_LIB_BORDERS=0); several ranks share this GPU, so the numbers are upper bounds of what a rank of its own sees
+    out["rebuild_ms"] = {}
+    if sim.nranks > 1:
+        for label, flag in (("library", "1"), ("torch_swap_chain", "0")):
+            os.environ["AHIP_LIB_BORDERS"] = flag
+            sim.rebuild()                              # (first one after a switch: allocations)
+            if d is not None:
+                d.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sim.rebuild()
+            torch.cuda.synchronize()
+            out["rebuild_ms"][label] = 1e3 * (time.perf_counter() - t0)
+        os.environ["AHIP_LIB_BORDERS"] = "1"
     ci = getattr(sim, "comm_info", None) or {"transport": "none"}
     out["transport"] = ci.get("transport", "none")
     torch.cuda.synchronize()
@@ -100,9 +116,10 @@ def main():
         allc = [torch.zeros_like(counts) for _ in range(world)]
         dist.all_gather(allc, counts)
         r["counts"] = [c.view(-1).tolist() for c in allc]
-        tt = torch.tensor([r["step_ms_wall"], r["comm_ms"]], dtype=torch.float64)
+        tt = torch.tensor([r["step_ms_wall"], r["comm_ms"], r["rebuild_ms"].get("library", 0.0), r["rebuild_ms"].get("torch_swap_chain", 0.0)], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         r["step_ms_wall"], r["comm_ms"] = float(tt[0]), float(tt[1])
+        r["rebuild_ms"] = {"library": float(tt[2]), "torch_swap_chain": float(tt[3])}
         res[name] = r
     dist.barrier()
     ok = True
@@ -118,7 +135,8 @@ def main():
                  "d_pe_per_atom_setup": float(abs(r["pe0"] - ref["pe0"])), "d_pe_per_atom_after_steps": float(abs(r["pe1"] - ref["pe1"])),
                  "max_abs_dx_after_steps": float(np.abs(r["x"] - ref["x"]).max()), "max_abs_dvirial": float(np.abs(r["virial1"] - ref["virial1"]).max()),
                  "comm_transport": r["transport"], "comm_ms_per_step_max_over_ranks": round(r["comm_ms"], 4),
-                 "step_ms_wall_max_over_ranks_shared_gpu": round(r["step_ms_wall"], 3), "rebuilds": r["rebuilds"], "kernel_path": r["path"]}
+                 "step_ms_wall_max_over_ranks_shared_gpu": round(r["step_ms_wall"], 3), "rebuilds": r["rebuilds"], "kernel_path": r["path"],
+                 "re_neighboring_in_the_library": r["lib_borders"], "rebuild_ms_max_over_ranks_shared_gpu": {k: round(v, 3) for k, v in r["rebuild_ms"].items()}}
             good = (sum(nl) == n and e["max_abs_dF_setup"] < TOL_F and e["max_abs_dF_after_steps"] < TOL_F and e["d_pe_per_atom_setup"] < TOL_PE
                     and e["d_pe_per_atom_after_steps"] < TOL_PE and e["max_abs_dx_after_steps"] < TOL_X)
             e["ok"] = bool(good)

@@ -204,6 +204,11 @@ void PairAllegroHIP::compute(int eflag, int vflag)
   eng_vdwl = eng;                                         // sum over local atoms only (:366-380)
   if (vflag) for (int k = 0; k < 6; k++) virial[k] = vir[k];    // xx,yy,zz,xy,xz,yz, no sign change (:387-392)
 
+  if (!arith_note_printed) {                              // once: what the library's default arithmetic decided for this model (f16x2 kept, or the float32 instance and why)
+    arith_note_printed = true;
+    const char *note = ahip_arith_note(model);
+    if (comm->me == 0 && note && *note) std::cout << "NequIP/Allegro: " << note << "\n";
+  }
   if (debug_mode) ahip_debug_dump_edges(model, atom->tag);    // "Allegro edges: i j rij" (:562-565,620-633)
 }
 

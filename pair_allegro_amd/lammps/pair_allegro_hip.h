@@ -54,6 +54,7 @@ class PairAllegroHIP : public Pair {
   double **cutoff_matrix = nullptr;    // [ntypes][ntypes], LAMMPS type index
   ahip_model *model = nullptr;
   bigint last_list_build = -1;         // < 0: the library holds no valid copy of the list (set by init_style at every run init)
+  bool arith_note_printed = false;     // ahip_arith_note is reported once, after the first evaluation
 };
 
 }    // namespace LAMMPS_NS

@@ -488,3 +488,51 @@ def test_narrower_models_run_fused_zero_padded(hip_lib, model_dir):
     res = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names)
     assert res["info"]["path"] == "generic_f32"
     util.assert_close_to(res, ref, 5e-4, what="S = 80: layer-at-a-time kernels")
+
+
+def test_auto_on_the_device_resident_path_reports_once_and_continues_on_float32(hip_lib, model_dir, monkeypatch):
+    """The `_dev` entry points never wait for the device, so a float16-range alarm of one evaluation is met at the NEXT one.  Under fused_arith=auto: that next
+    call returns AHIP_ERR_STATE once -- the earlier forces were invalid and have been handed out --, switches the model to the f32 instance, and every call after it evaluates
+    normally (the reference's float32 evaluates such a model, /root/reference/pair_nequip_allegro.cpp:267-270 only ever relaxes precision).  The first-evaluation self-check
+    is switched off here; with it on the very first call already lands on the f32 instance and nothing is ever reported (second half)."""
+    import torch
+    from pair_allegro_amd import capi, md
+    g, cfg, w, path, names, types = _blown_up_model(model_dir)
+    ref32 = util.run_pair(hip_lib, path, g["cell"], g["pos"], types, names, options={"path": "fused", "fused_arith": "f32"})
+    dev = torch.device("cuda", 0)
+    box = np.diag(np.asarray(g["cell"]))
+    for selfcheck in (False, True):
+        if selfcheck:
+            monkeypatch.delenv("AHIP_NO_ARITH_SELFCHECK", raising=False)
+        else:
+            monkeypatch.setenv("AHIP_NO_ARITH_SELFCHECK", "1")
+        model = capi.Model(path, 0, hip_lib)
+        sim = md.Simulation(md.HipBackend(model, [63.5, 106.4]), box, cfg["r_max"], 1.0, np.asarray(g["pos"]), (types - 1).astype(np.int32),
+                            np.zeros_like(np.asarray(g["pos"])), dev, grid=(1, 1, 1), rank=0, dist=None, dt=0.001)
+        sim.rebuild()
+        ev = torch.zeros(7, dtype=torch.float64, device=dev)
+
+        def evaluate():
+            sim.f.zero_()
+            sim.backend.compute(sim.x, sim.mtype, sim.f, sim.nlocal, ev)
+            torch.cuda.synchronize()
+            f = torch.zeros((sim.nlocal, 3), dtype=torch.float64, device=dev)
+            f.index_add_(0, torch.arange(sim.nlocal, device=dev), sim.f[: sim.nlocal])
+            if sim.nall > sim.nlocal:
+                f.index_add_(0, sim._ghost_src, sim.f[sim.nlocal:])
+            out = np.zeros((sim.nlocal, 3)); out[sim.tag[: sim.nlocal].cpu().numpy()] = f.cpu().numpy()
+            return out
+        if not selfcheck:
+            f1 = evaluate()                                       # f16x2: overflows, non-finite forces, alarm raised -- nobody has looked yet
+            assert not np.isfinite(f1).all() and model.last_path == "fused_f16x2"
+            with pytest.raises(capi.AhipError) as ei:             # the next call reports the EARLIER evaluation, once
+                evaluate()
+            assert "EARLIER evaluation" in str(ei.value.msg) and "float32 instance" in model.arith_note
+        f2 = evaluate()
+        assert model.last_path == "fused_f32" and np.isfinite(f2).all()
+        # (forces of ~1e6 from float32 sums in another neighbour order than the host-path reference: a few 1e-4 of max|F| apart)
+        np.testing.assert_allclose(f2, ref32["forces"], rtol=0, atol=2e-3 * np.abs(ref32["forces"]).max())
+        f3 = evaluate()                                           # and stays there
+        assert model.last_path == "fused_f32"
+        np.testing.assert_allclose(f3, f2, rtol=0, atol=1e-9 * np.abs(f2).max())
+        model.close()

@@ -197,6 +197,7 @@ def main():
     ap.add_argument("--cpu-sample-ncell", type=int, default=11)
     ap.add_argument("--no-overlap", action="store_true", help="serial ghost exchange (A/B against the overlapped schedule)")
     ap.add_argument("--mlp-depth", type=int, default=0, help="configs 2 / 3 / 4 only: hidden layers of the two-body and latent MLPs (default: the model's 2; 1 and 3 select the depth instances of k_fused)")
+    ap.add_argument("--l-max", type=int, default=-1, help="override the model's l_max (e.g. 3 on config 2: a shape outside every fused kernel, i.e. a line of the layer-at-a-time path on an l_max = 3 model)")
     ap.add_argument("--eval-only", action="store_true", help="ablation runs only (timing builds that compute wrong forces): time force evaluations at fixed positions instead of NVE steps; the line is NOT a benchmark result")
     ap.add_argument("--force-overlap", action="store_true", help="overlapped three-range schedule even on one rank (A/B: what the schedule itself costs)")
     args = ap.parse_args()
@@ -245,6 +246,9 @@ def main():
     if args.mlp_depth:
         cfg["mlp_depth"] = args.mlp_depth
         wl["name"] += f", MLP depth {args.mlp_depth}"
+    if args.l_max >= 0:
+        cfg["l_max"] = args.l_max
+        wl["name"] += f", l_max overridden to {args.l_max}"
     weights = model_file.init_weights(cfg)
     tmpdir = tempfile.mkdtemp(prefix="ahip_bench_")
     model_path = os.path.join(tmpdir, f"model_{rank}.ahip")

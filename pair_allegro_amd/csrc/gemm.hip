@@ -7,6 +7,7 @@
 // Optional fused epilogues: silu_out (forward: also store h = silu(C)), dsilu_z (backward: C *= silu'(z), z with C's layout).
 // Replaces the one-thread-per-output kernels k_linear / k_linear_bwd (generic_kernels.h), which stay for the float64
 // debug build and the CPU-emulated tests: they ran at 80-400 GB/s (78 % of the generic path's time).
+#include <utility>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -141,6 +142,7 @@ __global__ void __launch_bounds__(256) k_embed_bwd_Y_rows(long long E, int D, in
 template <int L> struct CgTab;
 template <> struct CgTab<1> { static constexpr const AhipCgEntry *tab = ahip_cg_l1; static constexpr int N = AHIP_CG_L1_N, NS = AHIP_CG_L1_NSCALAR, NP = AHIP_CG_L1_NPATHS; };
 template <> struct CgTab<2> { static constexpr const AhipCgEntry *tab = ahip_cg_l2; static constexpr int N = AHIP_CG_L2_N, NS = AHIP_CG_L2_NSCALAR, NP = AHIP_CG_L2_NPATHS; };
+template <> struct CgTab<3> { static constexpr const AhipCgEntry *tab = ahip_cg_l3; static constexpr int N = AHIP_CG_L3_N, NS = AHIP_CG_L3_NSCALAR, NP = AHIP_CG_L3_NPATHS; };      // round 6: 611 entries, 34 paths
 
 template <int L, bool SCALAR>
 __global__ void __launch_bounds__(256) k_tp_fwd_unrolled(long long E, int U, const float *__restrict__ pw, const float *__restrict__ V,
@@ -168,8 +170,30 @@ __global__ void __launch_bounds__(256) k_tp_fwd_unrolled(long long E, int U, con
 #pragma unroll
   for (int k = 0; k < DOUT; ++k) Vp[(e * DOUT + k) * U + u] = out[k];
 }
+// The backward table walk is unrolled by template expansion, not by `#pragma unroll`: the l_max = 3 body (611 entries) is over the
+// compiler's pragma-unroll budget, which left a run-time loop of 47-entry blocks with the path weights in scratch and the
+// accumulators selected by compare chains -- 47 instructions per entry, 5.8 ms per call on 300 k edges (40 % of an evaluation).
+template <int L, int Q, int D, int DOUT, int NP>
+__device__ __forceinline__ void tp_bwd_entry(const float (&pp)[NP], const float (&gg)[DOUT], const float (&vv)[D], const float (&ee)[D], float (&a)[D], float (&b)[D]) {
+  constexpr AhipCgEntry t = CgTab<L>::tab[Q];
+  const float wv = pp[t.path] * (float)t.c * gg[t.i3];
+  a[t.i1] += wv * ee[t.i2];
+  b[t.i2] += wv * vv[t.i1];
+}
+template <int L, int Q0, int D, int DOUT, int NP, int... I>
+__device__ __forceinline__ void tp_bwd_block(std::integer_sequence<int, I...>, const float (&pp)[NP], const float (&gg)[DOUT], const float (&vv)[D], const float (&ee)[D], float (&a)[D], float (&b)[D]) {
+  (tp_bwd_entry<L, Q0 + I, D, DOUT, NP>(pp, gg, vv, ee, a, b), ...);
+}
+template <int L, int N, int Q0, int D, int DOUT, int NP>
+__device__ __forceinline__ void tp_bwd_walk(const float (&pp)[NP], const float (&gg)[DOUT], const float (&vv)[D], const float (&ee)[D], float (&a)[D], float (&b)[D]) {
+  if constexpr (Q0 < N) {
+    constexpr int B = N - Q0 < 64 ? N - Q0 : 64;
+    tp_bwd_block<L, Q0, D, DOUT, NP>(std::make_integer_sequence<int, B>{}, pp, gg, vv, ee, a, b);
+    tp_bwd_walk<L, N, Q0 + B, D, DOUT, NP>(pp, gg, vv, ee, a, b);
+  }
+}
 template <int L, bool SCALAR>
-__global__ void __launch_bounds__(256) k_tp_bwd_unrolled(long long E, int U, const float *__restrict__ pw, const float *__restrict__ V,
+__global__ void __launch_bounds__(256, 2) k_tp_bwd_unrolled(long long E, int U, const float *__restrict__ pw, const float *__restrict__ V,
                                                           const float *__restrict__ env, const int *__restrict__ e_ii, int c0,
                                                           const float *__restrict__ dVp, float *__restrict__ dV, float *__restrict__ denv_e) {
   constexpr int D = (L + 1) * (L + 1), DOUT = SCALAR ? 1 : D, N = SCALAR ? CgTab<L>::NS : CgTab<L>::N, NP = CgTab<L>::NP;
@@ -186,36 +210,32 @@ __global__ void __launch_bounds__(256) k_tp_bwd_unrolled(long long E, int U, con
   for (int k = 0; k < NP; ++k) pp[k] = pw[k * U + u];
 #pragma unroll
   for (int k = 0; k < DOUT; ++k) gg[k] = dVp[(e * DOUT + k) * U + u];
-#pragma unroll
-  for (int q = 0; q < N; ++q) {
-    constexpr const AhipCgEntry *tab = CgTab<L>::tab;
-    const float wv = pp[tab[q].path] * (float)tab[q].c * gg[tab[q].i3];
-    a[tab[q].i1] += wv * ee[tab[q].i2];
-    b[tab[q].i2] += wv * vv[tab[q].i1];
-  }
+  tp_bwd_walk<L, N, 0, D, DOUT, NP>(pp, gg, vv, ee, a, b);
 #pragma unroll
   for (int k = 0; k < D; ++k) { dV[(e * D + k) * U + u] = a[k]; denv_e[(e * D + k) * U + u] = b[k]; }
 }
 
 bool tp_fwd_f32(hipStream_t s, long long E, int L, bool scalar_only, int U, const float *pw, const float *V, const float *env,
                 const int *e_ii, int c0, float *Vp) {
-  if (L != 1 && L != 2) return false;
+  if (L < 1 || L > 3) return false;
   if (E <= 0) return true;
   const dim3 grid((unsigned)((E * U + 255) / 256));
 #define TPF(LV, SV) hipLaunchKernelGGL((k_tp_fwd_unrolled<LV, SV>), grid, dim3(256), 0, s, E, U, pw, V, env, e_ii, c0, Vp)
   if (L == 1) { if (scalar_only) TPF(1, true); else TPF(1, false); }
-  else { if (scalar_only) TPF(2, true); else TPF(2, false); }
+  else if (L == 2) { if (scalar_only) TPF(2, true); else TPF(2, false); }
+  else { if (scalar_only) TPF(3, true); else TPF(3, false); }
 #undef TPF
   return true;
 }
 bool tp_bwd_f32(hipStream_t s, long long E, int L, bool scalar_only, int U, const float *pw, const float *V, const float *env,
                 const int *e_ii, int c0, const float *dVp, float *dV, float *denv_e) {
-  if (L != 1 && L != 2) return false;
+  if (L < 1 || L > 3) return false;
   if (E <= 0) return true;
   const dim3 grid((unsigned)((E * U + 255) / 256));
 #define TPB(LV, SV) hipLaunchKernelGGL((k_tp_bwd_unrolled<LV, SV>), grid, dim3(256), 0, s, E, U, pw, V, env, e_ii, c0, dVp, dV, denv_e)
   if (L == 1) { if (scalar_only) TPB(1, true); else TPB(1, false); }
-  else { if (scalar_only) TPB(2, true); else TPB(2, false); }
+  else if (L == 2) { if (scalar_only) TPB(2, true); else TPB(2, false); }
+  else { if (scalar_only) TPB(3, true); else TPB(3, false); }
 #undef TPB
   return true;
 }

@@ -1074,7 +1074,10 @@ void fused_launch_f16(int nw, bool prof, int md, int grid, hipStream_t s, const 
 // the f16x2 instances (fused_h.o): two-body table only; latent MLP depth 1..3 (profiling build for depth 2 only)
 void fused_launch_f16(int nw, bool prof, int md, int grid, hipStream_t s, const FusedArgs &A) {
 #ifdef AHIP_ASM_ONLY      // tools/asm_k_fused.sh: the headline instance alone, for a quick look at its code (static census, spills)
-  hipLaunchKernelGGL((k_fused<4, false, 3, true, 2, 2>), dim3(grid), dim3(256), 0, s, A);
+#ifndef AHIP_ASM_NW
+#define AHIP_ASM_NW 4
+#endif
+  hipLaunchKernelGGL((k_fused<AHIP_ASM_NW, false, 3, true, 2, 2>), dim3(grid), dim3(AHIP_ASM_NW * 64), 0, s, A);
 #else
 #define AHIP_LAUNCH_NL(NWV, PROFV, NLV, MDV) hipLaunchKernelGGL((k_fused<NWV, PROFV, 3, true, NLV, MDV>), dim3(grid), dim3(NWV * 64), 0, s, A)
 #define AHIP_LAUNCH(NWV, PROFV, MDV) do { if (A.NL == 1) AHIP_LAUNCH_NL(NWV, PROFV, 1, MDV); else if (A.NL == 2) AHIP_LAUNCH_NL(NWV, PROFV, 2, MDV); else AHIP_LAUNCH_NL(NWV, PROFV, 3, MDV); } while (0)
